@@ -1,0 +1,215 @@
+/*
+ * vaura_hip.h — C ABI of libvaura_hip.so, the MI355X (gfx950) generation hot path of V-AURA.
+ *
+ * The reference (ilpoviertola/V-AURA) has no native code and no FFI: its hot path is the Python
+ * call chain  VAURAModel.generate() -> _sample_next_token() -> llama.Transformer.forward()
+ * -> sample_top_k/top_p -> DacModelWrapper.decode().  This header is the native boundary a
+ * maintainer binds *under* those Python plugin classes (ctypes stub: INTEGRATION.md).  Each entry
+ * point cites the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers / sizes / a POD descriptor struct; no torch types.
+ *   - every pointer is a DEVICE pointer unless its name ends in _host.
+ *   - returns 0 on success, a negative vaura_status on an argument error, a positive value = hipError_t.
+ *   - never allocates device memory, never synchronises the stream, never throws.
+ *   - everything is enqueued on the hipStream_t that is passed in (pass torch's current stream).
+ *   - one caller thread per device; re-entrant across devices, not within one descriptor.
+ *
+ * Activation layout ("packed rows"): a (rows x C) fp32 matrix is stored in blocks of 16 rows as
+ *     [row_block][C/4][16 rows][4 cols]   ->  float index  ((rb*(C/4) + c/4)*16 + r%16)*4 + c%4
+ *   so that one 64-lane wavefront reads/writes one 16x16 MFMA operand tile as a contiguous 1 KiB.
+ *   rows beyond the live ones in the last block must be zero.
+ *
+ * Streamed-weight layout ("MFMA tiles"): an (N x K) matrix, N%16==0, K%32==0, is stored as
+ *     [N/16][K/32][64 lanes][8]  with lane = (n%16) + 16*((k%32)/8), element j = k%8
+ *   (fp32: [N/16][K/32][2 halves][64 lanes][4]); see vaura_pack_weight().
+ */
+#ifndef VAURA_HIP_H
+#define VAURA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vaura_stream_t; /* hipStream_t */
+
+typedef enum vaura_status {
+  VAURA_OK = 0,
+  VAURA_ERR_ARG = -1,       /* null pointer / size out of range            */
+  VAURA_ERR_SHAPE = -2,     /* dims not supported by the compiled kernels  */
+  VAURA_ERR_DTYPE = -3,
+  VAURA_ERR_STATE = -4      /* e.g. step graph not built                   */
+} vaura_status;
+
+typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1 } vaura_wdtype;
+
+/* ---- model geometry: configs/modules/samplers/llama_9cbs.yaml:3-17 + sampler/llama.py:308-361 */
+typedef struct vaura_dims {
+  int32_t n_layer;      /* 24   */
+  int32_t d_model;      /* 1536 */
+  int32_t n_head;       /* 16   (head_dim = d_model / n_head = 96) */
+  int32_t ffn_dim;      /* 4096 */
+  int32_t n_codebooks;  /* 9    */
+  int32_t vocab;        /* 1024 (special token id == vocab) */
+  int32_t cond_dim;     /* 512  */
+  int32_t tok_dim;      /* 1024 */
+  int32_t cond_in;      /* 768  */
+  int32_t codebook_dim; /* 8    */
+  int32_t tokens_per_frame; /* 7, scripts/generate.py:216 */
+  float   eps;          /* 1e-5 */
+} vaura_dims;
+
+/* ---- per-layer streamed weights, MFMA-tile layout, dtype = vaura_decoder.wdtype */
+typedef struct vaura_layer_weights {
+  const void*  wqkv;       /* (3*d_model x d_model)                       llama.py:211 */
+  const void*  wo;         /* (d_model x d_model)                         llama.py:212 */
+  const void*  w13;        /* (2*ffn x d_model): 16-row tiles interleaved w1,w3   llama.py:171-172 */
+  const void*  w2;         /* (d_model x ffn)                             llama.py:173 */
+  const float* attn_norm;  /* (d_model) gain                              llama.py:268 */
+  const float* ffn_norm;   /* (d_model) gain                              llama.py:269 */
+} vaura_layer_weights;
+
+/* ---- sampling parameters: VAURAModel._sample_next_token, models/vaura_model.py:775-827 */
+typedef struct vaura_sampling {
+  int32_t use_sampling;   /* 0 -> greedy argmax of the logits (vaura_model.py:825) */
+  float   temp;           /* <= 0 -> greedy                                        */
+  int32_t top_k;          /* used when top_p <= 0 and top_k > 0 (utils/utils.py:163-178) */
+  float   top_p;          /* > 0 wins over top_k (vaura_model.py:818-819; utils/utils.py:181-196) */
+  float   cfg_scale;      /* > 1 -> rows [B,2B) are the null-condition branch (vaura_model.py:786-813) */
+  uint64_t seed;          /* Philox key when noise == NULL                          */
+  uint64_t clip_base;     /* global index of clip 0 (keeps draws invariant to batch sharding) */
+} vaura_sampling;
+
+/* ---- everything one decode step touches.  All buffers are owned by the caller (torch tensors). */
+typedef struct vaura_decoder {
+  vaura_dims dims;
+  int32_t wdtype;          /* vaura_wdtype of the streamed matrices                */
+  int32_t batch;           /* B  = clips                                           */
+  int32_t rows;            /* Bs = B, or 2B when cfg_scale > 1                     */
+  int32_t max_len;         /* KV capacity in positions (>= S)                      */
+  int32_t timesteps;       /* T  = max_new_tokens                                  */
+  int32_t seq_len;         /* S  = T + n_codebooks                                 */
+  int32_t n_cond_tokens;   /* Tv                                                   */
+  int32_t _pad0;
+
+  const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
+  const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles           llama.py:356-361 */
+  const float* final_norm;   /* (d_model)                                          llama.py:355 */
+  const float* tok_emb;      /* (K, vocab+1, codebook_dim)                         llama.py:392-404 */
+  const float* tok_proj_w;   /* (K, tok_dim, codebook_dim) weight-norm folded      llama.py:405-409 */
+  const float* tok_proj_b;   /* (K, tok_dim)                                                */
+  const float* empty_video;  /* (cond_dim)                                         llama.py:336-338 */
+  const float* rope;         /* (max_len, head_dim/2, 2) cos,sin                   llama.py:593-603 */
+  const float* cond_proj;    /* packed rows (rows*Tv x cond_dim): vaura_prefill_cond output */
+
+  float*   kcache;           /* (n_layer, rows, n_head, max_len, head_dim) fp32, rotated keys */
+  float*   vcache;           /* same shape                                          */
+  int32_t* seq;              /* (B, K, S) pattern sequence, -1 = unknown            vaura_model.py:485-493 */
+  int32_t* state;            /* [0]=position of the token being fed, [1]=arrival counter, [2]=step index, [3] spare */
+  const float* noise;        /* optional (n_steps, B*K, vocab) Exp(1) draws; NULL -> Philox */
+
+  float* ws_h;               /* packed rows (rows x d_model) residual stream        */
+  float* ws_qkv;             /* packed rows (rows x 3*d_model)                      */
+  float* ws_attn;            /* packed rows (rows x d_model)                        */
+  float* ws_ffn;             /* packed rows (rows x ffn_dim)                        */
+  float* ws_logits;          /* row-major (rows, K*vocab)                           */
+} vaura_decoder;
+
+/* -------------------------------------------------------------------------------------------
+ * Weight ingress (once, at load).  Replaces nn.Module.load_state_dict for the streamed matrices.
+ * src: row-major fp32 (N x K) as stored in the reference checkpoint (nn.Linear.weight).          */
+int vaura_pack_weight(const float* src, void* dst, int64_t N, int64_t K, int wdtype, vaura_stream_t s);
+size_t vaura_packed_weight_bytes(int64_t N, int64_t K, int wdtype);
+
+/* row-major (rows x C) fp32 <-> packed rows.  `rows_padded` = ceil(rows/16)*16 rows are written.   */
+int vaura_pack_rows(const float* src, float* dst, int64_t rows, int64_t C, vaura_stream_t s);
+int vaura_unpack_rows(const float* src, float* dst, int64_t rows, int64_t C, vaura_stream_t s);
+
+/* -------------------------------------------------------------------------------------------
+ * a5  AVCLIPEmbedder.forward / MLP (llama.py:79-92,136-141): fc2(gelu_tanh(fc1(x))), hoisted to
+ * once per clip.  feats: packed rows (n_rows x 768); tmp: packed rows (n_rows x cond_dim);
+ * out: packed rows (n_rows x cond_dim).  fc1/fc2: MFMA tiles, wdtype as given.                   */
+int vaura_prefill_cond(const vaura_dims* d, const float* feats, const void* fc1, const void* fc2, int wdtype,
+                       float* tmp, float* out, int64_t n_rows, vaura_stream_t s);
+
+/* -------------------------------------------------------------------------------------------
+ * a14 Pattern.build_pattern_sequence (codebook_patterns.py:180-207) for DelayedPatternProvider
+ * (:390-406).  codes (B,K,T) int32 with -1 = unknown -> seq (B,K,T+K); special = d_codebook.     */
+int vaura_pattern_build(const int32_t* codes, int32_t* seq, int B, int K, int T, int special, vaura_stream_t s);
+/* a14 Pattern.revert_pattern_sequence (codebook_patterns.py:260-285) + the [..., :T] slice
+ * (vaura_model.py:568-569).  seq (B,K,S) -> codes (B,K,T); positions with no source get `fill`.  */
+int vaura_pattern_revert(const int32_t* seq, int32_t* codes, int B, int K, int T, int S, int fill, vaura_stream_t s);
+
+/* -------------------------------------------------------------------------------------------
+ * a2/a13/a15  logits (rows, K*vocab) -> next tokens.  Standalone form of the sampler used inside
+ * vaura_decode_step (same kernel).  noise: (B*K, vocab) Exp(1) draws or NULL (Philox, step index
+ * `step`).  tokens_out (B,K) int32.                                                              */
+int vaura_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,
+                 int64_t step, int32_t* tokens_out, vaura_stream_t s);
+
+/* -------------------------------------------------------------------------------------------
+ * a3..a12 + a2/a13/a15 for ONE position: Transformer.inference (llama.py:445-504) restricted to the
+ * position state[0] with a K/V cache, followed by _sample_next_token and the fix-up
+ * (vaura_model.py:536-544) that writes seq[..., state[0]+1] and advances state.
+ * sample == 0: teacher-forced step (prompt prefill): no heads, no sampling, state still advances. */
+int vaura_decode_step(const vaura_decoder* dec, const vaura_sampling* sp, int sample, vaura_stream_t s);
+
+/* a1  the hot loop of VAURAModel.generate (vaura_model.py:502-547): `n_prefill` teacher-forced
+ * positions then `n_steps` sampled ones, all enqueued back-to-back.  use_graph != 0 replays a
+ * captured single-step hipGraph (must have been built with vaura_step_graph_build).             */
+int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_prefill, int n_steps,
+                        int use_graph, vaura_stream_t s);
+int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s);
+void vaura_step_graph_free(void);
+
+/* -------------------------------------------------------------------------------------------
+ * op-level entry points (parity tests call the same kernels the step uses)                      */
+/* out = epilogue( W x (x*gain) * rinv ):  epi 0 store, 1 +residual, 2 SwiGLU pairs, 3 gelu_tanh,
+ * 4 row-major logits.  K must be one of the compiled depths (512, 768, 1024, 1536, 4096).        */
+int vaura_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
+               int64_t rows, int64_t N, int64_t K, int epilogue, float eps, vaura_stream_t s);
+/* a8/a9 for one layer at position `pos` (host value): rope(q,k), append, softmax(qK^T/sqrt(hd)) V. */
+int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
+                         int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s);
+
+/* -------------------------------------------------------------------------------------------
+ * a16 DacModelWrapper.decode (models/modules/dac/model.py:41-48): quantizer.from_codes + DAC
+ * decoder (descript-audio-codec 1.0.0, un-vendored).  Weight-norm is folded by the caller.      */
+typedef struct vaura_conv {
+  const float* w;     /* conv: [taps][Cout][Cin]; transposed (stride r, k = 2r, pad r/2): [r][2][Cout][Cin] */
+  const float* bias;  /* (Cout) */
+  int32_t cin, cout, taps, dilation, stride, _pad;
+} vaura_conv;
+
+typedef struct vaura_codec {
+  int32_t n_codebooks, codebook_size, codebook_dim, latent_dim;
+  int32_t n_blocks, n_units;        /* 4 decoder blocks, 3 residual units each */
+  int32_t rates[4];
+  const float* codebooks;           /* (K, size, dim)                    quantizer.quantizers[k].codebook */
+  const float* out_proj_w;          /* (K, latent, dim) weight-norm folded                     .out_proj   */
+  const float* out_proj_b;          /* (K, latent) */
+  vaura_conv conv_in;               /* latent -> C0, k7                                  decoder.model.0   */
+  const float* alpha_up[4];         /* Snake in front of each transposed conv   decoder.model.{b+1}.block.0 */
+  vaura_conv up[4];                 /*                                           decoder.model.{b+1}.block.1 */
+  const float* alpha_res[4][3][2];  /* Snakes of each residual unit              ...block.{u+2}.block.{0,2} */
+  vaura_conv res[4][3][2];          /* {k7 dilated, k1}                          ...block.{u+2}.block.{1,3} */
+  const float* alpha_out;           /* final Snake                               decoder.model.{n+1}        */
+  vaura_conv conv_out;              /* C_last -> 1, k7, w as [7][C_last]; tanh   decoder.model.{n+2}        */
+  float* ws[4];                     /* activation buffers, channels-last (B, L, C) fp32, ws_elems floats each */
+  size_t ws_elems;
+} vaura_codec;
+
+/* codes (B, K, T) int32 -> wav (B, 1, T*prod(rates)) fp32 */
+int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, float* wav, vaura_stream_t s);
+/* floats each of the 4 workspaces must hold for (B, T) */
+size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T);
+
+const char* vaura_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAURA_HIP_H */

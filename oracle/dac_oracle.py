@@ -1,0 +1,72 @@
+"""DAC 44.1 kHz decode, fp32 torch-CPU restatement (oracle — see oracle/__init__.py).
+
+PARITY UNPINNED BY THE REFERENCE: the arithmetic is in ``descript-audio-codec==1.0.0``
+(/root/reference/conda_env_cuda12.1.yaml:298), which is not vendored; the reference's call
+sites are models/modules/dac/model.py:41-48 (``quantizer.from_codes`` then ``model.decode``)
+and it ships no vectors for them.  Restated from the published DAC architecture
+(dac/model/dac.py, dac/nn/layers.py, dac/nn/quantize.py of that release):
+
+  from_codes   z = sum_k out_proj_k(codebook_k[codes_k])        out_proj = WNConv1d(8 -> latent, k=1)
+  Decoder      WNConv1d(latent -> C, k=7, pad=3)
+               for r in rates:  Snake(C) -> WNConvTranspose1d(C -> C/2, k=2r, stride=r, pad=ceil(r/2))
+                                -> 3 x ResidualUnit(C/2, dilation in (1,3,9));  C /= 2
+               Snake(C) -> WNConv1d(C -> 1, k=7, pad=3) -> tanh
+  ResidualUnit y = WNConv1d(k=1)(Snake(WNConv1d(k=7, dil=d, pad=3d)(Snake(x))));  out = x + y
+  Snake        x + (alpha + 1e-9)^-1 * sin(alpha * x)^2,  alpha per channel
+  WN*          weight = g * v / ||v||  (norm over all dims but 0)
+
+Structure cross-check: tests/golden/codec_hf.npz (transformers' independent DacModel).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Sequence
+
+import torch
+import torch.nn.functional as F
+
+
+def fold(sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    g, v = sd[prefix + "weight_g"].float(), sd[prefix + "weight_v"].float()
+    return v * (g / v.norm(2, dim=tuple(range(1, v.dim())), keepdim=True))
+
+
+def snake(x: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    return x + (alpha + 1e-9).reciprocal() * torch.sin(alpha * x).pow(2)
+
+
+def from_codes(sd: Dict[str, torch.Tensor], codes: torch.Tensor) -> torch.Tensor:
+    """codes (B, K, T) int64 -> z (B, latent, T)."""
+    z = None
+    for k in range(codes.shape[1]):
+        p = f"quantizer.quantizers.{k}."
+        e = F.embedding(codes[:, k], sd[p + "codebook.weight"].float()).transpose(1, 2)
+        zk = F.conv1d(e, fold(sd, p + "out_proj."), sd[p + "out_proj.bias"].float())
+        z = zk if z is None else z + zk
+    return z
+
+
+def decode_latent(sd: Dict[str, torch.Tensor], z: torch.Tensor, rates: Sequence[int] = (8, 8, 4, 2),
+                  dilations: Sequence[int] = (1, 3, 9)) -> torch.Tensor:
+    """z (B, latent, T) -> wav (B, 1, T * prod(rates))."""
+    x = F.conv1d(z, fold(sd, "decoder.model.0."), sd["decoder.model.0.bias"].float(), padding=3)
+    for b, r in enumerate(rates):
+        p = f"decoder.model.{b + 1}.block."
+        x = snake(x, sd[p + "0.alpha"].float())
+        x = F.conv_transpose1d(x, fold(sd, p + "1."), sd[p + "1.bias"].float(), stride=r, padding=math.ceil(r / 2))
+        for u, d in enumerate(dilations):
+            q = p + f"{u + 2}.block."
+            y = snake(x, sd[q + "0.alpha"].float())
+            y = F.conv1d(y, fold(sd, q + "1."), sd[q + "1.bias"].float(), dilation=d, padding=3 * d)
+            y = snake(y, sd[q + "2.alpha"].float())
+            y = F.conv1d(y, fold(sd, q + "3."), sd[q + "3.bias"].float())
+            x = x + y
+    n = len(rates) + 1
+    x = snake(x, sd[f"decoder.model.{n}.alpha"].float())
+    x = F.conv1d(x, fold(sd, f"decoder.model.{n + 1}."), sd[f"decoder.model.{n + 1}.bias"].float(), padding=3)
+    return torch.tanh(x)
+
+
+@torch.no_grad()
+def decode(sd: Dict[str, torch.Tensor], codes: torch.Tensor, rates: Sequence[int] = (8, 8, 4, 2)) -> torch.Tensor:
+    return decode_latent(sd, from_codes(sd, codes), rates)

@@ -1,0 +1,283 @@
+"""Generate tests/golden/*.npz by running the REAL reference (build container only).
+
+    python tests/golden/make_golden.py small         # patterns, sampler, tiny-model cases (seconds)
+    python tests/golden/make_golden.py full_greedy   # 24-layer model, B=2, T=220, greedy   (~4 min)
+    python tests/golden/make_golden.py full_sample   # 24-layer, B=2, cfg 6, top-k 250      (~8 min)
+    python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
+
+Inputs are never stored when they can be regenerated: weights and features come from
+``vaura_amd.synth`` (name-keyed seeds), sampling noise from ``synth.exp_noise(seed)``.
+Each fixture records the seeds/arguments needed to rebuild its inputs.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+from vaura_amd import synth  # noqa: E402
+import ref_harness as rh  # noqa: E402
+
+
+def sha1(a: np.ndarray) -> str:
+    return hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------- patterns
+def gold_patterns():
+    rh.install()
+    from models.modules.misc.codebook_patterns import DelayedPatternProvider
+    out = {}
+    prov = DelayedPatternProvider(n_q=9)
+    for T, Tp in [(4, 0), (55, 0), (220, 0), (221, 166), (20, 8)]:
+        pat = prov.get_pattern(T)
+        g = torch.Generator().manual_seed(100 + T)
+        codes = torch.full((2, 9, T), -1, dtype=torch.long)
+        if Tp:
+            codes[..., :Tp] = torch.randint(0, 1024, (2, 9, Tp), generator=g)
+        seq, idx, mask = pat.build_pattern_sequence(codes, 1024)
+        filled = torch.where(seq == -1, torch.randint(0, 1024, seq.shape, generator=g), seq)
+        filled = torch.where(mask[None], filled, torch.full_like(filled, 1024))
+        rev, ridx, rmask = pat.revert_pattern_sequence(filled, special_token=-1)
+        k = f"T{T}_p{Tp}"
+        out[k + "_codes"] = codes.numpy().astype(np.int16)
+        out[k + "_seq"] = seq.numpy().astype(np.int16)
+        out[k + "_idx"] = idx.numpy().astype(np.int32)
+        out[k + "_mask"] = mask.numpy()
+        out[k + "_filled"] = filled.numpy().astype(np.int16)
+        out[k + "_rev"] = rev.numpy().astype(np.int16)
+        out[k + "_ridx"] = ridx.numpy().astype(np.int32)
+        out[k + "_rmask"] = rmask.numpy()
+        out[k + "_first"] = np.int64(pat.get_first_step_with_timesteps(Tp))
+    save("patterns.npz", **out)
+
+
+# ------------------------------------------------------------------------------------- sampling
+def gold_sampling():
+    rh.install()
+    from utils.utils import multinomial, sample_top_k, sample_top_p
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(3, 9, 1024, generator=g) * 1.5
+    # exact ties: duplicate a few logits so that the k-th largest value is shared
+    logits[0, 0, 10:20] = logits[0, 0, 5]
+    logits[1, 3, :] = logits[1, 3, :].round(decimals=1)
+    out["logits"] = logits.numpy()
+    seed = 4242
+    cases = [("topk1", dict(k=1)), ("topk128", dict(k=128)), ("topk250", dict(k=250)),
+             ("topp90", dict(p=0.9)), ("topp30", dict(p=0.3)), ("plain", dict())]
+    for temp in (1.0, 0.7):
+        for name, kw in cases:
+            probs = torch.softmax(logits / temp, dim=-1)
+            torch.manual_seed(seed)
+            if "k" in kw:
+                tok = sample_top_k(probs.clone(), kw["k"])
+            elif "p" in kw:
+                tok = sample_top_p(probs.clone(), kw["p"])
+            else:
+                tok = multinomial(probs.clone(), num_samples=1)
+            # the noise the call consumed, re-drawn from the same seed (one draw of (rows, V))
+            noise = synth.exp_noise(1, 27, 1024, seed)[0]
+            chk = torch.argmax(probs.reshape(27, 1024) / noise, -1)
+            if name == "plain":
+                assert torch.equal(chk, tok.reshape(-1)), "multinomial != argmax(p/Exp(1))"
+            out[f"{name}_t{temp}_tok"] = tok.numpy().astype(np.int16)
+    out["noise_seed"] = np.int64(seed)
+    save("sampling.npz", **out)
+
+
+# ------------------------------------------------------------------------------------- tiny model
+def _capture_logits(model, store, rows=None):
+    def hook(_m, _inp, outp):
+        lg = outp[0]  # (Bs, K, L, V)
+        store.append((lg.shape[2], lg[:, :, -1, :].detach().clone()))
+    return model.sampler.register_forward_hook(hook)
+
+
+def gold_tiny():
+    cfg = synth.tiny_sampler(2)
+    sd = synth.sampler_state_dict(cfg, seed=3)
+    model = rh.build_reference_model(cfg.yaml_params(), sd)
+    out = {"layers": np.int64(2), "weight_seed": np.int64(3), "feat_seed": np.int64(5)}
+    feats = synth.video_features(2, seed=5)
+    frames = feats.reshape(2, 4, 8, 768)
+
+    # (1) full forward logits on a random sequence (all-position check of the decoder itself)
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, 1025, (2, 9, 12), generator=g)
+    with torch.no_grad():
+        lg, _, _ = model.sampler(tgt=idx, memory=feats)
+    out["fwd_idx"] = idx.numpy().astype(np.int16)
+    out["fwd_logits_pos"] = np.array([0, 6, 7, 11])
+    out["fwd_logits"] = lg[:, :, [0, 6, 7, 11], :].numpy()
+
+    # (1b) positions past Tv*7 read empty_video_emb: 4 video tokens -> positions >= 28
+    feats4 = feats[:, :4]
+    idx2 = torch.randint(0, 1025, (1, 9, 31), generator=g)
+    with torch.no_grad():
+        lg2, _, _ = model.sampler(tgt=idx2, memory=feats4[:1])
+    out["pad_idx"] = idx2.numpy().astype(np.int16)
+    out["pad_logits"] = lg2[:, :, [27, 28, 30], :].numpy()
+
+    # (2) greedy generate, T=20
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True,
+                       use_sampling=False, prompt_is_encoded=True, cfg_scale=1.0)
+    out["greedy_T20"] = r["sampled_indices"].numpy().astype(np.int16)
+
+    # (3) greedy + CFG 6.0
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True,
+                       use_sampling=False, prompt_is_encoded=True, cfg_scale=6.0)
+    out["greedy_cfg6_T20"] = r["sampled_indices"].numpy().astype(np.int16)
+
+    # (4) sampling: top-k 250, cfg 6, temp 1.0, seed 99
+    torch.manual_seed(99)
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True,
+                       use_sampling=True, temp=1.0, top_k=250, top_p=0.0, prompt_is_encoded=True, cfg_scale=6.0)
+    out["topk250_cfg6_seed99_T20"] = r["sampled_indices"].numpy().astype(np.int16)
+
+    # (5) sampling: top-p 0.8, temp 0.9, cfg 1, seed 98
+    torch.manual_seed(98)
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True,
+                       use_sampling=True, temp=0.9, top_k=250, top_p=0.8, prompt_is_encoded=True, cfg_scale=1.0)
+    out["topp80_t09_seed98_T20"] = r["sampled_indices"].numpy().astype(np.int16)
+
+    # (6) plain multinomial, seed 97
+    torch.manual_seed(97)
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True,
+                       use_sampling=True, temp=1.0, top_k=0, top_p=0.0, prompt_is_encoded=True, cfg_scale=1.0)
+    out["plain_seed97_T20"] = r["sampled_indices"].numpy().astype(np.int16)
+
+    # (7) prompt continuation (the sliding-window caller's shape, scaled down): Tp=8 of T=20
+    prompt = torch.from_numpy(out["greedy_T20"].astype(np.int64))[:, :, 5:13]
+    r = model.generate(frames=frames, audio=prompt, max_new_tokens=20, return_sampled_indices=True,
+                       use_sampling=False, prompt_is_encoded=True, cfg_scale=1.0, remove_prompts=False)
+    out["prompt8_greedy_T20"] = r["sampled_indices"].numpy().astype(np.int16)
+    save("tiny_model.npz", **out)
+
+
+# ------------------------------------------------------------------------------------- full size
+def _full_model():
+    cfg = synth.FULL_SAMPLER
+    t = time.time()
+    sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
+    print(f"weights in {time.time() - t:.1f}s")
+    return rh.build_reference_model(cfg.yaml_params(), sd)
+
+
+def gold_full_greedy():
+    model = _full_model()
+    B = 2
+    feats = synth.video_features(B, seed=0)
+    store = []
+    h = _capture_logits(model, store)
+    t = time.time()
+    r = model.generate(frames=feats.reshape(B, 4, 8, 768), audio=None, max_new_tokens=220,
+                       return_sampled_indices=True, use_sampling=False, prompt_is_encoded=True, cfg_scale=1.0)
+    dt = time.time() - t
+    h.remove()
+    tok = r["sampled_indices"].numpy()
+    keep = [1, 8, 9, 10, 100, 224, 225, 228]
+    logits = {L: lg for (L, lg) in store}
+    margins = []
+    for (L, lg) in store:
+        top2 = torch.topk(lg, 2, dim=-1).values
+        margins.append((top2[..., 0] - top2[..., 1]).numpy())
+    margins = np.stack(margins)  # (steps, B, K)
+    save("full_greedy_B2_T220.npz",
+         tokens=tok.astype(np.int16), sha1=np.array(sha1(tok.astype(np.int16))),
+         logits_steps=np.array(keep), logits=np.stack([logits[L].numpy() for L in keep]),
+         margins=margins.astype(np.float32), ref_seconds=np.float64(dt),
+         ref_threads=np.int64(torch.get_num_threads()), weight_seed=np.int64(0), feat_seed=np.int64(0))
+    print(f"reference generate(): {dt:.1f}s  min margin {margins.min():.3e}")
+
+
+def gold_full_sample():
+    model = _full_model()
+    B = 2
+    feats = synth.video_features(B, seed=0)
+    torch.manual_seed(2024)
+    t = time.time()
+    r = model.generate(frames=feats.reshape(B, 4, 8, 768), audio=None, max_new_tokens=220,
+                       return_sampled_indices=True, use_sampling=True, temp=1.0, top_k=250, top_p=0.0,
+                       prompt_is_encoded=True, cfg_scale=6.0)
+    dt = time.time() - t
+    tok = r["sampled_indices"].numpy()
+    save("full_topk250_cfg6_B2_T220.npz", tokens=tok.astype(np.int16), sha1=np.array(sha1(tok.astype(np.int16))),
+         noise_seed=np.int64(2024), ref_seconds=np.float64(dt), weight_seed=np.int64(0), feat_seed=np.int64(0))
+    print(f"reference generate(): {dt:.1f}s")
+
+
+# ------------------------------------------------------------------------------------- codec
+def gold_codec():
+    """DAC decode golden from transformers' independent DacModel (NOT the reference's dependency:
+    structure cross-check only — see oracle/__init__.py 'parity unpinned')."""
+    from transformers import DacConfig, DacModel
+    from transformers.models.dac import modeling_dac  # noqa: F401
+    ccfg = synth.CodecCfg(decoder_dim=192, decoder_rates=(8, 8, 4, 2))
+    hf = DacConfig(sampling_rate=44100, decoder_hidden_size=ccfg.decoder_dim, upsampling_ratios=list(ccfg.decoder_rates),
+                   n_codebooks=9, codebook_size=1024, codebook_dim=8, hidden_size=ccfg.latent_dim)
+    m = DacModel(hf).eval()
+    sd = synth.codec_state_dict(ccfg, seed=1)
+    # load folded weights into HF's plain convs (HF names differ; map by module order)
+    dec = m.decoder
+    fold = synth.fold_weight_norm
+
+    def put(conv, prefix):
+        conv.weight.data.copy_(fold(sd[prefix + "weight_g"], sd[prefix + "weight_v"]))
+        conv.bias.data.copy_(sd[prefix + "bias"])
+
+    put(dec.conv1, "decoder.model.0.")
+    for b, blk in enumerate(dec.block):
+        p = f"decoder.model.{b + 1}.block."
+        blk.snake1.alpha.data.copy_(sd[p + "0.alpha"])
+        put(blk.conv_t1, p + "1.")
+        for u, ru in enumerate([blk.res_unit1, blk.res_unit2, blk.res_unit3]):
+            q = p + f"{u + 2}.block."
+            ru.snake1.alpha.data.copy_(sd[q + "0.alpha"])
+            put(ru.conv1, q + "1.")
+            ru.snake2.alpha.data.copy_(sd[q + "2.alpha"])
+            put(ru.conv2, q + "3.")
+    n = len(ccfg.decoder_rates) + 1
+    dec.snake1.alpha.data.copy_(sd[f"decoder.model.{n}.alpha"])
+    put(dec.conv2, f"decoder.model.{n + 1}.")
+    for i, q in enumerate(m.quantizer.quantizers):
+        p = f"quantizer.quantizers.{i}."
+        q.codebook.weight.data.copy_(sd[p + "codebook.weight"])
+        put(q.out_proj, p + "out_proj.")
+    g = torch.Generator().manual_seed(21)
+    codes = torch.randint(0, 1024, (2, 9, 24), generator=g)
+    with torch.no_grad():
+        z = m.quantizer.from_codes(codes)[0]
+        wav = m.decoder(z)
+    save("codec_hf.npz", codes=codes.numpy().astype(np.int16), z=z.numpy(), wav=wav.numpy(),
+         decoder_dim=np.int64(ccfg.decoder_dim), codec_seed=np.int64(1))
+
+
+if __name__ == "__main__":
+    torch.set_float32_matmul_precision("highest")  # NOT main.py:34's "medium" 
+    what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what == "small":
+        gold_patterns(); gold_sampling(); gold_tiny()
+    elif what == "full_greedy":
+        gold_full_greedy()
+    elif what == "full_sample":
+        gold_full_sample()
+    elif what == "codec":
+        gold_codec()
+    else:
+        raise SystemExit(f"unknown target {what}")

@@ -1,0 +1,119 @@
+// Step driver: chains the kernels of one decode position and the generate() hot loop.
+//   VAURAModel.generate loop           models/vaura_model.py:502-547
+//   VAURAModel._sample_next_token      models/vaura_model.py:775-827
+//   Transformer.inference              models/modules/sampler/llama.py:445-504
+//   TransformerBlock.forward           llama.py:272-283
+#include "common.h"
+
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
+
+static int check_decoder(const vaura_decoder* d) {
+  if (!d || !d->layers_host || !d->heads || !d->final_norm || !d->tok_emb || !d->tok_proj_w || !d->tok_proj_b ||
+      !d->empty_video || !d->rope || !d->cond_proj || !d->kcache || !d->vcache || !d->seq || !d->state || !d->ws_h ||
+      !d->ws_qkv || !d->ws_attn || !d->ws_ffn || !d->ws_logits)
+    return VAURA_ERR_ARG;
+  const vaura_dims& m = d->dims;
+  if (m.d_model != 1536 || m.ffn_dim != 4096 || m.n_head != 16 || m.vocab != 1024) return VAURA_ERR_SHAPE;
+  if (m.cond_dim + m.tok_dim != m.d_model) return VAURA_ERR_SHAPE;
+  if (d->rows != d->batch && d->rows != 2 * d->batch) return VAURA_ERR_ARG;
+  if (d->seq_len > d->max_len || d->batch <= 0) return VAURA_ERR_ARG;
+  return 0;
+}
+
+static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
+  const vaura_dims& m = d->dims;
+  const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
+  const int rows = d->rows;
+  int rc = va_launch_embed(d, s);
+  if (rc) return rc;
+  const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
+  for (int l = 0; l < m.n_layer; ++l) {
+    const vaura_layer_weights& L = d->layers_host[l];
+    // h -> qkv  (attention_norm fused)                                   llama.py:280, 228
+    rc = va_launch_gemv(L.wqkv, d->wdtype, d->ws_h, L.attn_norm, nullptr, d->ws_qkv, rows, 3 * D, D, EPI_STORE, m.eps, s);
+    if (rc) return rc;
+    // rope + cache append + softmax(qK^T)V                               llama.py:234-257
+    rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, rows, H, hd,
+                             d->max_len, d->state, 0, s);
+    if (rc) return rc;
+    // h += wo . attn                                                      llama.py:259, 279
+    rc = va_launch_gemv(L.wo, d->wdtype, d->ws_attn, nullptr, d->ws_h, d->ws_h, rows, D, D, EPI_RESID, 0.f, s);
+    if (rc) return rc;
+    // ffn = silu(w1 x) * (w3 x)  (ffn_norm fused)                        llama.py:282, 177
+    rc = va_launch_gemv(L.w13, d->wdtype, d->ws_h, L.ffn_norm, nullptr, d->ws_ffn, rows, 2 * F, D, EPI_SWIGLU, m.eps, s);
+    if (rc) return rc;
+    // h += w2 . ffn                                                       llama.py:177, 282
+    rc = va_launch_gemv(L.w2, d->wdtype, d->ws_ffn, nullptr, d->ws_h, d->ws_h, rows, D, F, EPI_RESID, 0.f, s);
+    if (rc) return rc;
+  }
+  if (!sample) return va_launch_advance(d->state, s);
+  // logits = heads . norm(h)                                              llama.py:503-504
+  rc = va_launch_gemv(d->heads, d->wdtype, d->ws_h, d->final_norm, nullptr, d->ws_logits, rows, (int64_t)m.n_codebooks * m.vocab, D,
+                      EPI_LOGITS, m.eps, s);
+  if (rc) return rc;
+  return va_launch_sample(d->ws_logits, d->batch, m.n_codebooks, m.vocab, sp, d->noise, d->batch * m.n_codebooks, d->state, 0,
+                          nullptr, d->seq, d->timesteps, d->seq_len, d->state, s);
+}
+
+static hipGraphExec_t g_step_exec = nullptr;
+static hipGraph_t g_step_graph = nullptr;
+
+extern "C" {
+
+const char* vaura_version(void) { return "vaura_hip 0.1 (gfx950)"; }
+
+int vaura_decode_step(const vaura_decoder* dec, const vaura_sampling* sp, int sample, vaura_stream_t s) {
+  int rc = check_decoder(dec);
+  if (rc) return rc;
+  if (sample && !sp) return VAURA_ERR_ARG;
+  return enqueue_step(dec, sp, sample, as_stream(s));
+}
+
+void vaura_step_graph_free(void) {
+  if (g_step_exec) { (void)hipGraphExecDestroy(g_step_exec); g_step_exec = nullptr; }
+  if (g_step_graph) { (void)hipGraphDestroy(g_step_graph); g_step_graph = nullptr; }
+}
+
+int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s) {
+  int rc = check_decoder(dec);
+  if (rc) return rc;
+  if (!sp) return VAURA_ERR_ARG;
+  vaura_step_graph_free();
+  hipStream_t st = as_stream(s);
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return (int)e;
+  rc = enqueue_step(dec, sp, 1, st);
+  e = hipStreamEndCapture(st, &g_step_graph);
+  if (rc) { vaura_step_graph_free(); return rc; }
+  if (e != hipSuccess) return (int)e;
+  e = hipGraphInstantiate(&g_step_exec, g_step_graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { vaura_step_graph_free(); return (int)e; }
+  return 0;
+}
+
+int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_prefill, int n_steps, int use_graph,
+                        vaura_stream_t s) {
+  int rc = check_decoder(dec);
+  if (rc) return rc;
+  if (!sp || n_prefill < 0 || n_steps < 0) return VAURA_ERR_ARG;
+  hipStream_t st = as_stream(s);
+  for (int i = 0; i < n_prefill; ++i) {
+    rc = enqueue_step(dec, sp, 0, st);
+    if (rc) return rc;
+  }
+  if (use_graph) {
+    if (!g_step_exec) return VAURA_ERR_STATE;
+    for (int i = 0; i < n_steps; ++i) {
+      hipError_t e = hipGraphLaunch(g_step_exec, st);
+      if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+  }
+  for (int i = 0; i < n_steps; ++i) {
+    rc = enqueue_step(dec, sp, 1, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+// Decode-step causal self-attention for ONE new position per sequence, with the K/V cache the
+// reference lacks.  Replaces, for the last row of the causal product,
+//   apply_rotary_emb(q), apply_rotary_emb(k)       models/modules/sampler/llama.py:234-235, 633-650
+//   F.scaled_dot_product_attention(is_causal=True) llama.py:246-255   (scale = 1/sqrt(head_dim))
+//   merge heads                                    llama.py:257
+//
+// Bound: HBM (every cached K and V element of the (row, head) is read once; fp32 cache).
+// One 256-thread workgroup per (head, row).  8 lanes cover one cached position (3 x 16 B each,
+// 128-B segments per load instruction), 32 positions per pass; scores -> LDS, block softmax,
+// then the same mapping accumulates P.V, reduced through shuffles + LDS.  The rotated key and the
+// value of the new position are appended to the cache by this kernel.
+#include "common.h"
+
+#define ATT_THREADS 256
+
+template <int HD>
+__global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
+    const float* __restrict__ qkv,   // packed rows (rows x 3*D)
+    const float* __restrict__ rope,  // (max_len, HD/2, 2)
+    float* __restrict__ kcache,      // (rows, H, max_len, HD)
+    float* __restrict__ vcache,
+    float* __restrict__ out,         // packed rows (rows x D)
+    int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
+  constexpr int QUADS = HD / 4;          // 24
+  constexpr int QPL = QUADS / 8;         // float4 per lane per position = 3
+  static_assert(QUADS % 8 == 0, "head_dim must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sq = smem;                      // HD   rotated query (pre-scaled by nothing; scale applied to score)
+  float* sk = sq + HD;                   // HD   rotated key of the new position
+  float* sv = sk + HD;                   // HD   value of the new position
+  float* red = sv + HD;                  // 4*HD cross-wave P.V partials
+  float* rbuf = red + 4 * HD;            // 8    block reductions
+  float* sc = rbuf + 8;                  // pos+1 scores / probabilities
+
+  const int h = blockIdx.x, row = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int D = n_head * HD;
+  const int pos = pos_dev ? pos_dev[0] : pos_host;
+  const int L = pos + 1;
+  const float scale = 1.0f / sqrtf((float)HD);
+
+  float* kc = kcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+
+  // ---- 1. gather q, k, v of this head; rotate q and k; append k, v
+  if (tid < 3 * QUADS) {
+    const int which = tid / QUADS, cq = tid % QUADS;
+    const int col = which * D + h * HD + cq * 4;
+    f32x4 x = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, col >> 2, 3 * D)];
+    if (which < 2) {
+      const f32x4 cs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
+      f32x4 y;
+      y[0] = x[0] * cs[0] - x[1] * cs[1];
+      y[1] = x[1] * cs[0] + x[0] * cs[1];
+      y[2] = x[2] * cs[2] - x[3] * cs[3];
+      y[3] = x[3] * cs[2] + x[2] * cs[3];
+      x = y;
+    }
+    reinterpret_cast<f32x4*>(which == 0 ? sq : (which == 1 ? sk : sv))[cq] = x;
+    if (which == 1) reinterpret_cast<f32x4*>(kc + (size_t)pos * HD)[cq] = x;
+    if (which == 2) reinterpret_cast<f32x4*>(vc + (size_t)pos * HD)[cq] = x;
+  }
+  __syncthreads();
+
+  // ---- 2. scores over cached positions [0, pos) + the new one from LDS
+  const int sub = tid & 7;       // which 16-B column group (x3) of the position
+  const int prow = tid >> 3;     // position inside a pass of 32
+  f32x4 qf[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) qf[i] = reinterpret_cast<const f32x4*>(sq)[sub + 8 * i];
+
+  for (int p0 = 0; p0 < pos; p0 += 32 * 4) {
+    f32x4 kf[4][QPL];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 32 + prow;
+#pragma unroll
+      for (int i = 0; i < QPL; ++i)
+        kf[u][i] = (p < pos) ? reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < QPL; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kf[u][i][c], d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      const int p = p0 + u * 32 + prow;
+      if (sub == 0 && p < pos) sc[p] = d * scale;
+    }
+  }
+  if (tid < 64) {  // new position: one wave, lanes 0..23 hold a quad each
+    float d = 0.f;
+    if (tid < QUADS) {
+      const f32x4 a = reinterpret_cast<const f32x4*>(sq)[tid], b = reinterpret_cast<const f32x4*>(sk)[tid];
+      d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    }
+    d = wave_sum(d);
+    if (tid == 0) sc[pos] = d * scale;
+  }
+  __syncthreads();
+
+  // ---- 3. softmax over sc[0..L)
+  float mx = -INFINITY;
+  for (int i = tid; i < L; i += ATT_THREADS) mx = fmaxf(mx, sc[i]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) rbuf[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(rbuf[0], rbuf[1]), fmaxf(rbuf[2], rbuf[3]));
+  float sm = 0.f;
+  for (int i = tid; i < L; i += ATT_THREADS) {
+    const float e = expf(sc[i] - mx);
+    sc[i] = e;
+    sm += e;
+  }
+  sm = wave_sum(sm);
+  if ((tid & 63) == 0) rbuf[4 + (tid >> 6)] = sm;
+  __syncthreads();
+  const float inv = 1.0f / (((rbuf[4] + rbuf[5]) + rbuf[6]) + rbuf[7]);
+
+  // ---- 4. P.V with the same lane mapping
+  f32x4 av[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p0 = 0; p0 < pos; p0 += 32 * 4) {
+    f32x4 vf[4][QPL];
+    float pw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 32 + prow;
+      pw[u] = (p < pos) ? sc[p] * inv : 0.f;
+#pragma unroll
+      for (int i = 0; i < QPL; ++i)
+        vf[u][i] = (p < pos) ? reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) av[i] += vf[u][i] * pw[u];
+  }
+  // reduce over the 8 position-rows of the wave (lane bits 3..5), then over the 4 waves
+#pragma unroll
+  for (int i = 0; i < QPL; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = av[i][c];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      av[i][c] = v;
+    }
+  const int wv = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) reinterpret_cast<f32x4*>(red + wv * HD)[lane + 8 * i] = av[i];
+  }
+  __syncthreads();
+  if (tid < QUADS) {
+    f32x4 o = reinterpret_cast<const f32x4*>(red)[tid];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) o += reinterpret_cast<const f32x4*>(red + i * HD)[tid];
+    o += reinterpret_cast<const f32x4*>(sv)[tid] * (sc[pos] * inv);
+    reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
+  }
+}
+
+int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, int rows, int n_head,
+                        int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s) {
+  if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
+  if (head_dim != 96) return VAURA_ERR_SHAPE;
+  const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
+  hipLaunchKernelGGL(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, rope, kc, vc, out,
+                     n_head, max_len, pos_dev, pos_host);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
+                                    int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s) {
+  if (pos < 0 || pos >= max_len) return VAURA_ERR_ARG;
+  return va_launch_attention(qkv, rope, kcache, vcache, out, rows, n_head, head_dim, max_len, nullptr, pos, as_stream(s));
+}

@@ -1,0 +1,57 @@
+// Shared device helpers for libvaura_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vaura_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define VA_CHECK_LAUNCH()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return (int)e__;    \
+  } while (0)
+
+// packed-rows index (see vaura_hip.h): float index of (row, col) in a (rows x C) matrix
+__host__ __device__ __forceinline__ size_t packed_index(int row, int col, int C) {
+  return ((((size_t)(row >> 4) * (size_t)(C >> 2) + (size_t)(col >> 2)) << 4) + (size_t)(row & 15)) * 4 + (size_t)(col & 3);
+}
+// float4 index of (row, 4-col quad cq) in packed rows
+__host__ __device__ __forceinline__ size_t packed_quad(int row, int cq, int C) {
+  return (((size_t)(row >> 4) * (size_t)(C >> 2) + (size_t)cq) << 4) + (size_t)(row & 15);
+}
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// round-to-nearest-even fp32 -> bf16 bits (inputs are finite weights)
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+inline hipStream_t as_stream(vaura_stream_t s) { return (hipStream_t)s; }
+
+// ---- launchers implemented across the .hip files (host side, internal)
+int va_launch_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
+                   int64_t rows, int64_t N, int64_t K, int epilogue, float eps, hipStream_t s);
+int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, int rows, int n_head,
+                        int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s);
+int va_launch_embed(const vaura_decoder* d, hipStream_t s);
+int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,
+                     int noise_rows_per_step, const int32_t* state, int64_t step_host, int32_t* tokens_out,
+                     int32_t* seq, int T, int S, int32_t* state_rw, hipStream_t s);
+int va_launch_advance(int32_t* state, hipStream_t s);

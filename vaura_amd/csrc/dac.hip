@@ -1,0 +1,261 @@
+// DAC 44.1 kHz decode: codes -> latent -> waveform.
+//   call site          models/modules/dac/model.py:41-48  (quantizer.from_codes, model.decode)
+//   arithmetic         descript-audio-codec==1.0.0 (un-vendored; conda_env_cuda12.1.yaml:298):
+//                      Decoder / DecoderBlock / ResidualUnit / Snake1d / WNConv1d / WNConvTranspose1d
+//
+// Bound: MFMA.  Every Conv1d / ConvTranspose1d is one "multi-tap GEMM"
+//     out[j*ostride + oshift][co] = bias[co] + sum_t sum_ci  act[j + off_t][ci] * W_t[co][ci]
+// over channels-last activations (B, L, C): a k=7 dilated conv has 7 taps (off_t = (t-3)*dil), a k=1
+// conv one, and a stride-r transposed conv (k = 2r, pad = r/2) is r independent 2-tap problems, one
+// per output phase (off = {0, -1}, ostride = r, oshift = phase - r/2).  Products run on
+// v_mfma_f32_16x16x4_f32 (exact fp32), with A = weight tile (rows = co) and B = activation tile
+// (cols = position), so each lane ends up holding 4 consecutive channels of one position and the
+// epilogue is float4: + bias, + residual, raw store, and Snake with the NEXT layer's alpha — the
+// activation is evaluated once per element by its producer, never per tap by the consumer.
+#include "common.h"
+
+#define BM 128   // positions per workgroup tile
+#define BN 96    // output channels per workgroup tile (divides 1536, 768, 384, 192, 96)
+#define BK 32    // input channels per k-tile
+
+struct ConvArgs {
+  const float* in;     // (B, Lin, Cin) already activated
+  const float* w;      // [phase][tap][Cout][Cin]
+  const float* bias;   // (Cout)
+  const float* res;    // optional (B, Lout, Cout)
+  const float* alpha;  // (Cout) Snake alpha for out_act
+  float* out_raw;      // optional (B, Lout, Cout)
+  float* out_act;      // optional (B, Lout, Cout)
+  int Lin, Lout, Cin, Cout, NT;
+  int off_base, off_step;   // off_t = off_base + t*off_step
+  int ostride, oshift0;     // output row = j*ostride + oshift0 + phase
+  int jcount;               // j in [0, jcount)
+};
+
+__device__ __forceinline__ float snake_f(float v, float al) {
+  const float sn = sinf(al * v);
+  return v + (1.0f / (al + 1e-9f)) * (sn * sn);
+}
+
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+  __shared__ f32x4 Ws[2][BK / 4][BN + 1];
+  __shared__ f32x4 Xs[2][BK / 4][BM + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wn = wv & 1, wm = wv >> 1;
+  const int j0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tiles_m = gridDim.x;
+  (void)tiles_m;
+  const int phases = a.ostride;              // transposed conv: one phase per blockIdx.z % ostride
+  const int b = blockIdx.z / phases, ph = blockIdx.z % phases;
+  const float* in = a.in + (size_t)b * a.Lin * a.Cin;
+  const float* wbase = a.w + (size_t)ph * a.NT * a.Cout * a.Cin;
+  const int kc = a.Cin / BK;
+  const int nk = a.NT * kc;
+
+  f32x4 wreg[3], xreg[4];
+  auto load_tile = [&](int kt) {
+    const int t = kt / kc, ci0 = (kt % kc) * BK;
+    const float* wt = wbase + (size_t)t * a.Cout * a.Cin;
+    const int off = a.off_base + t * a.off_step;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      wreg[i] = *reinterpret_cast<const f32x4*>(wt + (size_t)(n0 + row) * a.Cin + ci0 + 4 * kq);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      const int jr = j0 + row + off;
+      xreg[i] = (jr >= 0 && jr < a.Lin) ? *reinterpret_cast<const f32x4*>(in + (size_t)jr * a.Cin + ci0 + 4 * kq)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; Ws[buf][qd & 7][qd >> 3] = wreg[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs[buf][qd & 7][qd >> 3] = xreg[i]; }
+  };
+
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 af[3], bf[4];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) af[i] = Ws[buf][4 * c + (lane >> 4)][wn * 48 + i * 16 + (lane & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = Xs[buf][4 * c + (lane >> 4)][wm * 64 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds channels co..co+3 of one position
+  const size_t obase = (size_t)b * a.Lout * a.Cout;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jr = j0 + wm * 64 + j * 16 + (lane & 15);
+    if (jr >= a.jcount) continue;
+    const int orow = jr * a.ostride + a.oshift0 + ph;
+    if (orow < 0 || orow >= a.Lout) continue;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int co = n0 + wn * 48 + i * 16 + 4 * (lane >> 4);
+      const size_t o = obase + (size_t)orow * a.Cout + co;
+      f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + co);
+      if (a.res) v = *reinterpret_cast<const f32x4*>(a.res + o) + v;
+      if (a.out_raw) *reinterpret_cast<f32x4*>(a.out_raw + o) = v;
+      if (a.out_act) {
+        const f32x4 al = *reinterpret_cast<const f32x4*>(a.alpha + co);
+        f32x4 s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = snake_f(v[r], al[r]);
+        *reinterpret_cast<f32x4*>(a.out_act + o) = s;
+      }
+    }
+  }
+}
+
+// z[b][t][c] = sum_k ( W_k[c][:] . codebook_k[code] + b_k[c] )   — quantizer.from_codes
+__global__ __launch_bounds__(256) void from_codes_kernel(const int32_t* __restrict__ codes, const float* __restrict__ cb,
+                                                          const float* __restrict__ pw, const float* __restrict__ pb,
+                                                          float* __restrict__ z, int K, int T, int size, int dim, int latent) {
+  __shared__ float e[16][8];
+  const int t = blockIdx.x, b = blockIdx.y;
+  if (threadIdx.x < K * dim) {
+    const int k = threadIdx.x / dim, i = threadIdx.x % dim;
+    const int code = codes[((size_t)b * K + k) * T + t];
+    e[k][i] = cb[((size_t)k * size + code) * dim + i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < latent; c += blockDim.x) {
+    float o = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float* wr = pw + ((size_t)k * latent + c) * dim;
+      float zk = 0.f;
+      for (int i = 0; i < dim; ++i) zk = fmaf(wr[i], e[k][i], zk);
+      o += zk + pb[(size_t)k * latent + c];
+    }
+    z[((size_t)b * T + t) * latent + c] = o;
+  }
+}
+
+// wav[b][l] = tanh( bias + sum_t sum_c act[l + t - 3][c] * w[t][c] )   — last conv (C -> 1, k = 7)
+__global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__ act, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ wav, int L, int C) {
+  const int b = blockIdx.y;
+  const int sub = threadIdx.x & 7;
+  const int l = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const float* in = act + (size_t)b * L * C;
+  float d = 0.f;
+  for (int t = 0; t < 7; ++t) {
+    const int r = l + t - 3;
+    if (r < 0 || r >= L || l >= L) continue;
+    for (int cq = sub; cq < C / 4; cq += 8) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)r * C + 4 * cq);
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + 4 * cq);
+      d = fmaf(x[0], ww[0], d); d = fmaf(x[1], ww[1], d); d = fmaf(x[2], ww[2], d); d = fmaf(x[3], ww[3], d);
+    }
+  }
+  d += __shfl_xor(d, 1, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 4, 64);
+  if (sub == 0 && l < L) wav[(size_t)b * L + l] = tanhf(d + bias[0]);
+}
+
+static int launch_conv(const vaura_conv& cv, const float* in, const float* res, const float* alpha, float* out_raw,
+                       float* out_act, int B, int Lin, hipStream_t s) {
+  if (!cv.w || !cv.bias || (cv.cin % BK) || (cv.cout % BN)) return VAURA_ERR_SHAPE;
+  if (out_act && !alpha) return VAURA_ERR_ARG;
+  ConvArgs a;
+  a.in = in; a.w = cv.w; a.bias = cv.bias; a.res = res; a.alpha = alpha; a.out_raw = out_raw; a.out_act = out_act;
+  a.Lin = Lin; a.Cin = cv.cin; a.Cout = cv.cout;
+  int phases = 1;
+  if (cv.stride > 1) {   // transposed: k = 2r, pad = r/2
+    if (cv.stride % 2) return VAURA_ERR_SHAPE;
+    a.NT = 2; a.off_base = 0; a.off_step = -1; a.ostride = cv.stride; a.oshift0 = -(cv.stride / 2);
+    a.Lout = Lin * cv.stride; a.jcount = Lin + 1; phases = cv.stride;
+  } else {
+    a.NT = cv.taps; a.off_base = -((cv.taps - 1) / 2) * cv.dilation; a.off_step = cv.dilation;
+    a.ostride = 1; a.oshift0 = 0; a.Lout = Lin; a.jcount = Lin;
+  }
+  dim3 grid((a.jcount + BM - 1) / BM, cv.cout / BN, B * phases);
+  hipLaunchKernelGGL(conv_mfma_kernel, grid, dim3(256), 0, s, a);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" {
+
+size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T) {
+  if (!c || B <= 0 || T <= 0) return 0;
+  size_t L = (size_t)T, best = (size_t)T * (size_t)c->latent_dim;
+  int ch = c->conv_in.cout;
+  if ((size_t)T * ch > best) best = (size_t)T * ch;
+  for (int b = 0; b < c->n_blocks; ++b) {
+    L *= (size_t)c->rates[b];
+    ch = c->up[b].cout;
+    if (L * ch > best) best = L * ch;
+  }
+  return best * (size_t)B;
+}
+
+int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, float* wav, vaura_stream_t s_) {
+  if (!c || !codes || !wav || B <= 0 || T <= 0) return VAURA_ERR_ARG;
+  if (c->n_blocks < 1 || c->n_blocks > 4 || c->n_units != 3 || c->n_codebooks > 16 || c->codebook_dim > 8)
+    return VAURA_ERR_SHAPE;
+  if (c->ws_elems < vaura_dac_workspace_elems(c, B, T)) return VAURA_ERR_ARG;
+  for (int i = 0; i < 4; ++i) if (!c->ws[i]) return VAURA_ERR_ARG;
+  hipStream_t s = as_stream(s_);
+  float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
+
+  hipLaunchKernelGGL(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
+                     c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim);
+  VA_CHECK_LAUNCH();
+  // conv_in: only the activated output is consumed (by the first transposed conv)
+  int rc = launch_conv(c->conv_in, Y, nullptr, c->alpha_up[0], nullptr, A, B, T, s);
+  if (rc) return rc;
+  int L = T;
+  for (int b = 0; b < c->n_blocks; ++b) {
+    // Snake (already applied by the producer) -> transposed conv; raw kept for the first residual
+    rc = launch_conv(c->up[b], A, nullptr, c->alpha_res[b][0][0], Y, Z, B, L, s);
+    if (rc) return rc;
+    L *= c->rates[b];
+    { float* t = R; R = Y; Y = t; t = A; A = Z; Z = t; }
+    for (int u = 0; u < 3; ++u) {
+      // y = Snake2(conv7(Snake1(x)))  (Snake1 applied by the producer)
+      rc = launch_conv(c->res[b][u][0], A, nullptr, c->alpha_res[b][u][1], nullptr, Y, B, L, s);
+      if (rc) return rc;
+      // x = x + conv1(y); emit Snake_next(x)
+      const float* next_alpha = (u < 2) ? c->alpha_res[b][u + 1][0] : (b + 1 < c->n_blocks ? c->alpha_up[b + 1] : c->alpha_out);
+      rc = launch_conv(c->res[b][u][1], Y, R, next_alpha, (u < 2) ? R : nullptr, A, B, L, s);
+      if (rc) return rc;
+    }
+  }
+  const int C = c->conv_out.cin;
+  if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,352 @@
+// Per-step bookkeeping kernels around the layer stack: input embedding, next-token selection,
+// delay-pattern build / revert.
+//
+//   embed    models/modules/sampler/llama.py:455-472, 555-586  (token projection sum + video concat)
+//   sample   models/vaura_model.py:807-825, 536-544; utils/utils.py:139-196
+//   pattern  models/modules/misc/codebook_patterns.py:137-285, 390-406 (delayed pattern, closed form)
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ embed
+// h0[row] = [ cond(row, pos // tpf) | sum_k ( W_k . emb_k[tok(row % B, k, pos)] + b_k ) ]  -> packed rows
+__global__ __launch_bounds__(256) void embed_kernel(
+    const int32_t* __restrict__ seq, const int32_t* __restrict__ state, const float* __restrict__ cond_proj,
+    const float* __restrict__ empty_video, const float* __restrict__ tok_emb, const float* __restrict__ proj_w,
+    const float* __restrict__ proj_b, float* __restrict__ h, int B, int K, int S, int Tv, int tpf, int vocab1,
+    int cdim, int cond_dim, int tok_dim) {
+  __shared__ float e[16][8];  // K <= 16 codebooks, codebook_dim <= 8
+  const int row = blockIdx.x;
+  const int b = row % B;
+  const int pos = state[0];
+  const int D = cond_dim + tok_dim;
+  if (threadIdx.x < K * cdim) {
+    const int k = threadIdx.x / cdim, i = threadIdx.x % cdim;
+    const int tok = seq[((size_t)b * K + k) * S + pos];
+    e[k][i] = tok_emb[((size_t)k * vocab1 + tok) * cdim + i];
+  }
+  __syncthreads();
+  const int frame = pos / tpf;
+  for (int cq = threadIdx.x; cq < D / 4; cq += blockDim.x) {
+    f32x4 o;
+    if (cq < cond_dim / 4) {
+      if (frame < Tv)
+        o = reinterpret_cast<const f32x4*>(cond_proj)[packed_quad(row * Tv + frame, cq, cond_dim)];
+      else
+        o = reinterpret_cast<const f32x4*>(empty_video)[cq];
+    } else {
+      const int c0 = (cq - cond_dim / 4) * 4;
+      o = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float* wr = proj_w + ((size_t)k * tok_dim + c0 + j) * cdim;
+          float z = 0.f;
+          for (int i = 0; i < cdim; ++i) z = fmaf(wr[i], e[k][i], z);
+          z += proj_b[(size_t)k * tok_dim + c0 + j];
+          o[j] += z;
+        }
+      }
+    }
+    reinterpret_cast<f32x4*>(h)[packed_quad(row, cq, D)] = o;
+  }
+}
+
+int va_launch_embed(const vaura_decoder* d, hipStream_t s) {
+  const vaura_dims& m = d->dims;
+  if (m.n_codebooks > 16 || m.codebook_dim > 8 || m.n_codebooks * m.codebook_dim > 256) return VAURA_ERR_SHAPE;
+  hipLaunchKernelGGL(embed_kernel, dim3(d->rows), dim3(256), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
+                     d->tok_emb, d->tok_proj_w, d->tok_proj_b, d->ws_h, d->batch, m.n_codebooks, d->seq_len,
+                     d->n_cond_tokens, m.tokens_per_frame, m.vocab + 1, m.codebook_dim, m.cond_dim, m.tok_dim);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ sampling
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct SampleArgs {
+  const float* logits;   // (rows, K*V) row-major
+  const float* noise;    // (steps, B*K, V) or null
+  const int32_t* state;  // device {pos, arrivals, step} or null
+  int32_t* state_rw;     // same buffer, writable, or null (standalone)
+  int32_t* tokens_out;   // (B, K) or null
+  int32_t* seq;          // (B, K, S) or null
+  int B, K, V, T, S;
+  int use_sampling, top_k;
+  float temp, top_p, cfg_scale;
+  uint64_t seed, clip_base;
+  long long step_host;
+};
+
+#define SMP_THREADS 256
+
+__device__ __forceinline__ void block_argmax(float v, int i, float* sv, int* si, float& bv, int& bi) {
+  // first-index-wins argmax over the block (torch.argmax returns the first maximal index)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = v; si[threadIdx.x >> 6] = i; }
+  __syncthreads();
+  bv = sv[0]; bi = si[0];
+#pragma unroll
+  for (int w = 1; w < SMP_THREADS / 64; ++w)
+    if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sv) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((sv[0] + sv[1]) + sv[2]) + sv[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sv) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+}
+__device__ __forceinline__ int block_count(int v, int* si) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) si[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return si[0] + si[1] + si[2] + si[3];
+}
+
+// V == 1024 == 4 * SMP_THREADS: thread t owns candidates 4t .. 4t+3
+__global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
+  __shared__ float sv[8];
+  __shared__ int si[8];
+  __shared__ float sp[1024];   // top-p: sorted probabilities
+  __shared__ int sidx[1024];   // top-p: their token ids
+  __shared__ float skeep[1024];
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int pos = a.state ? a.state[0] : 0;
+  const long long step = a.state ? (long long)a.state[2] : a.step_host;
+  const int V = a.V;
+
+  const f32x4 lc = *reinterpret_cast<const f32x4*>(a.logits + ((size_t)b * a.K + k) * V + 4 * tid);
+  float x[4] = {lc[0], lc[1], lc[2], lc[3]};
+  if (a.cfg_scale > 1.0f) {  // models/vaura_model.py:810-813
+    const f32x4 lu = *reinterpret_cast<const f32x4*>(a.logits + ((size_t)(a.B + b) * a.K + k) * V + 4 * tid);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = lu[j] + (x[j] - lu[j]) * a.cfg_scale;
+  }
+
+  int token;
+  if (!(a.use_sampling && a.temp > 0.0f)) {
+    float bv = x[0]; int bi = 4 * tid;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (x[j] > bv) { bv = x[j]; bi = 4 * tid + j; }
+    float rv; int ri;
+    block_argmax(bv, bi, sv, si, rv, ri);
+    token = ri;
+  } else {
+    // softmax(logits / temp)
+    float p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = x[j] / a.temp;
+    const float mx = block_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), sv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = expf(x[j] - mx);
+    const float den = block_sum((p[0] + p[1]) + (p[2] + p[3]), sv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = p[j] / den;
+
+    // Exp(1) draws for this (clip, codebook, step)
+    float q[4];
+    if (a.noise) {
+      const f32x4 nz = *reinterpret_cast<const f32x4*>(a.noise + (((size_t)step * a.B + b) * a.K + k) * V + 4 * tid);
+      q[0] = nz[0]; q[1] = nz[1]; q[2] = nz[2]; q[3] = nz[3];
+    } else {
+      uint32_t r[4];
+      const uint64_t clip = a.clip_base + (uint64_t)b;
+      philox4x32_10((uint32_t)tid, (uint32_t)step, (uint32_t)(clip * (uint64_t)a.K + k), (uint32_t)((clip * a.K + k) >> 32),
+                    (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = -logf(((float)r[j] + 0.5f) * 2.3283064365386963e-10f);
+    }
+
+    if (a.top_p > 0.0f) {
+      // utils/utils.py:181-196 — sort descending (ties: lower id first), sequential cumsum, cut, renormalise,
+      // draw in sorted space with the noise indexed by RANK, map back.
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sp[4 * tid + j] = p[j]; sidx[4 * tid + j] = 4 * tid + j; }
+      __syncthreads();
+      for (int sz = 2; sz <= 1024; sz <<= 1) {
+        for (int st = sz >> 1; st > 0; st >>= 1) {
+          for (int t = tid; t < 512; t += SMP_THREADS) {
+            const int i = ((t / st) * (st << 1)) + (t % st);
+            const int j = i + st;
+            const bool desc = ((i & sz) == 0);
+            const float pi = sp[i], pj = sp[j];
+            const int ii = sidx[i], ij = sidx[j];
+            const bool i_first = (pi > pj) || (pi == pj && ii < ij);  // i should precede j in descending order
+            if (desc ? !i_first : i_first) { sp[i] = pj; sp[j] = pi; sidx[i] = ij; sidx[j] = ii; }
+          }
+          __syncthreads();
+        }
+      }
+      if (tid == 0) {
+        float cs = 0.f;
+        for (int i = 0; i < 1024; ++i) {
+          cs += sp[i];
+          skeep[i] = (cs - sp[i] > a.top_p) ? 0.f : 1.f;
+        }
+      }
+      __syncthreads();
+      float ps[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ps[j] = sp[4 * tid + j] * skeep[4 * tid + j];
+      const float den2 = block_sum((ps[0] + ps[1]) + (ps[2] + ps[3]), sv);
+      float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float r = (ps[j] / den2) / q[j];
+        if (r > bv) { bv = r; bi = 4 * tid + j; }
+      }
+      float rv; int ri;
+      block_argmax(bv, bi, sv, si, rv, ri);
+      token = sidx[ri];
+    } else {
+      if (a.top_k > 0) {
+        // utils/utils.py:172-176 — threshold = k-th largest probability (bitwise binary search on the
+        // IEEE bits: probabilities are >= 0 so integer order == float order), keep p >= threshold.
+        const int kk = a.top_k < V ? a.top_k : V;
+        uint32_t key[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) key[j] = __builtin_bit_cast(uint32_t, p[j]);
+        uint32_t thr = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+          const uint32_t cand = thr | (1u << bit);
+          const int c = (key[0] >= cand) + (key[1] >= cand) + (key[2] >= cand) + (key[3] >= cand);
+          if (block_count(c, si) >= kk) thr = cand;
+        }
+        const float thrf = __builtin_bit_cast(float, thr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = p[j] * (p[j] >= thrf ? 1.0f : 0.0f);
+        const float den2 = block_sum((p[0] + p[1]) + (p[2] + p[3]), sv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = p[j] / den2;
+      }
+      float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float r = p[j] / q[j];
+        if (r > bv) { bv = r; bi = 4 * tid + j; }
+      }
+      float rv; int ri;
+      block_argmax(bv, bi, sv, si, rv, ri);
+      token = ri;
+    }
+  }
+
+  if (tid == 0) {
+    if (a.tokens_out) a.tokens_out[b * a.K + k] = token;
+    if (a.seq) {
+      // vaura_model.py:536-544 — invalid pattern slots become the special token; known tokens are kept
+      const int offset = pos + 1;
+      const int t = offset - 1 - k;
+      const int tok = (t >= 0 && t < a.T) ? token : V;
+      int32_t* slot = a.seq + ((size_t)b * a.K + k) * a.S + offset;
+      if (*slot == -1) *slot = tok;
+    }
+    if (a.state_rw) {
+      __threadfence();
+      const int arrived = atomicAdd(&a.state_rw[1], 1);
+      if (arrived == (int)(gridDim.x * gridDim.y) - 1) {
+        a.state_rw[1] = 0;
+        a.state_rw[0] = pos + 1;
+        a.state_rw[2] = (int)step + 1;
+        __threadfence();
+      }
+    }
+  }
+}
+
+int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,
+                     int /*noise_rows_per_step*/, const int32_t* state, int64_t step_host, int32_t* tokens_out,
+                     int32_t* seq, int T, int S, int32_t* state_rw, hipStream_t s) {
+  if (!logits || !sp || B <= 0 || K <= 0) return VAURA_ERR_ARG;
+  if (vocab != 1024) return VAURA_ERR_SHAPE;
+  SampleArgs a;
+  a.logits = logits; a.noise = noise; a.state = state; a.state_rw = state_rw; a.tokens_out = tokens_out; a.seq = seq;
+  a.B = B; a.K = K; a.V = vocab; a.T = T; a.S = S;
+  a.use_sampling = sp->use_sampling; a.top_k = sp->top_k; a.temp = sp->temp; a.top_p = sp->top_p;
+  a.cfg_scale = sp->cfg_scale; a.seed = sp->seed; a.clip_base = sp->clip_base; a.step_host = step_host;
+  hipLaunchKernelGGL(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void advance_kernel(int32_t* state) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1;
+}
+int va_launch_advance(int32_t* state, hipStream_t s) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, state);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ pattern
+// delayed pattern, delays = 0..K-1: sequence step s of codebook q holds timestep t = s - 1 - q.
+__global__ void pattern_build_kernel(const int32_t* __restrict__ codes, int32_t* __restrict__ seq, int B, int K, int T,
+                                     int special) {
+  const int S = T + K;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * K * S) return;
+  const int s = (int)(i % S), q = (int)((i / S) % K), b = (int)(i / ((int64_t)S * K));
+  const int t = s - 1 - q;
+  seq[i] = (t >= 0 && t < T) ? codes[((size_t)b * K + q) * T + t] : special;
+}
+__global__ void pattern_revert_kernel(const int32_t* __restrict__ seq, int32_t* __restrict__ codes, int B, int K, int T,
+                                      int S, int fill) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * K * T) return;
+  const int t = (int)(i % T), q = (int)((i / T) % K), b = (int)(i / ((int64_t)T * K));
+  const int s = t + 1 + q;
+  codes[i] = (s < S) ? seq[((size_t)b * K + q) * S + s] : fill;
+}
+
+extern "C" {
+
+int vaura_pattern_build(const int32_t* codes, int32_t* seq, int B, int K, int T, int special, vaura_stream_t s) {
+  if (!codes || !seq || B <= 0 || K <= 0 || T <= 0) return VAURA_ERR_ARG;
+  const int64_t n = (int64_t)B * K * (T + K);
+  hipLaunchKernelGGL(pattern_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), codes, seq, B, K, T, special);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+int vaura_pattern_revert(const int32_t* seq, int32_t* codes, int B, int K, int T, int S, int fill, vaura_stream_t s) {
+  if (!codes || !seq || B <= 0 || K <= 0 || T <= 0 || S <= 0) return VAURA_ERR_ARG;
+  const int64_t n = (int64_t)B * K * T;
+  hipLaunchKernelGGL(pattern_revert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), seq, codes, B, K, T, S, fill);
+  VA_CHECK_LAUNCH();
+  return 0;
+}
+
+int vaura_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,
+                 int64_t step, int32_t* tokens_out, vaura_stream_t s) {
+  if (!tokens_out) return VAURA_ERR_ARG;
+  return va_launch_sample(logits, B, K, vocab, sp, noise, B * K, nullptr, step, tokens_out, nullptr, 0, 0, nullptr, as_stream(s));
+}
+
+}  // extern "C"
