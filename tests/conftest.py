@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size CPU oracle run (tens of seconds)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name))
+    return load
+
+
+@pytest.fixture(scope="session")
+def full_sampler_sd():
+    """694 M synthetic parameters (bf16-representable streamed matrices); ~10 s, shared by the session."""
+    from vaura_amd import synth
+    return synth.sampler_state_dict(synth.FULL_SAMPLER, seed=0, round_bf16=True)
+
+
+@pytest.fixture(scope="session")
+def tiny_sampler_sd():
+    from vaura_amd import synth
+    return synth.sampler_state_dict(synth.tiny_sampler(2), seed=3)

@@ -1,0 +1,132 @@
+"""ctypes binding of libvaura_hip.so (include/vaura_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load,
+``lib()`` raises.  (Building is ``python -m vaura_amd.csrc.build`` / ``__graft_entry__.build()``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvaura_hip.so")
+
+W_F32, W_BF16 = 0, 1
+EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_LOGITS = 0, 1, 2, 3, 4
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class Dims(C.Structure):
+    _fields_ = [("n_layer", C.c_int32), ("d_model", C.c_int32), ("n_head", C.c_int32), ("ffn_dim", C.c_int32),
+                ("n_codebooks", C.c_int32), ("vocab", C.c_int32), ("cond_dim", C.c_int32), ("tok_dim", C.c_int32),
+                ("cond_in", C.c_int32), ("codebook_dim", C.c_int32), ("tokens_per_frame", C.c_int32),
+                ("eps", C.c_float)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("wqkv", C.c_void_p), ("wo", C.c_void_p), ("w13", C.c_void_p), ("w2", C.c_void_p),
+                ("attn_norm", C.c_void_p), ("ffn_norm", C.c_void_p)]
+
+
+class Sampling(C.Structure):
+    _fields_ = [("use_sampling", C.c_int32), ("temp", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
+                ("cfg_scale", C.c_float), ("seed", C.c_uint64), ("clip_base", C.c_uint64)]
+
+
+class Decoder(C.Structure):
+    _fields_ = [("dims", Dims), ("wdtype", C.c_int32), ("batch", C.c_int32), ("rows", C.c_int32),
+                ("max_len", C.c_int32), ("timesteps", C.c_int32), ("seq_len", C.c_int32),
+                ("n_cond_tokens", C.c_int32), ("_pad0", C.c_int32),
+                ("layers_host", C.POINTER(LayerWeights)), ("heads", C.c_void_p), ("final_norm", C.c_void_p),
+                ("tok_emb", C.c_void_p), ("tok_proj_w", C.c_void_p), ("tok_proj_b", C.c_void_p),
+                ("empty_video", C.c_void_p), ("rope", C.c_void_p), ("cond_proj", C.c_void_p),
+                ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("seq", C.c_void_p), ("state", C.c_void_p),
+                ("noise", C.c_void_p),
+                ("ws_h", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_attn", C.c_void_p), ("ws_ffn", C.c_void_p),
+                ("ws_logits", C.c_void_p)]
+
+
+class Conv(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("taps", C.c_int32), ("dilation", C.c_int32), ("stride", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Codec(C.Structure):
+    _fields_ = [("n_codebooks", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32),
+                ("latent_dim", C.c_int32), ("n_blocks", C.c_int32), ("n_units", C.c_int32),
+                ("rates", C.c_int32 * 4),
+                ("codebooks", C.c_void_p), ("out_proj_w", C.c_void_p), ("out_proj_b", C.c_void_p),
+                ("conv_in", Conv), ("alpha_up", C.c_void_p * 4), ("up", Conv * 4),
+                ("alpha_res", ((C.c_void_p * 2) * 3) * 4), ("res", ((Conv * 2) * 3) * 4),
+                ("alpha_out", C.c_void_p), ("conv_out", Conv),
+                ("ws", C.c_void_p * 4), ("ws_elems", C.c_size_t)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/vaura_hip.h
+SIGNATURES = {
+    "vaura_version": (C.c_char_p, []),
+    "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
+    "vaura_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "vaura_pack_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "vaura_unpack_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "vaura_prefill_cond": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_int64, C.c_void_p]),
+    "vaura_pattern_build": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vaura_pattern_revert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vaura_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Sampling), C.c_void_p, C.c_int64,
+                               C.c_void_p, C.c_void_p]),
+    "vaura_decode_step": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_void_p]),
+    "vaura_generate_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vaura_step_graph_build": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_void_p]),
+    "vaura_step_graph_free": (None, []),
+    "vaura_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                             C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "vaura_attention_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vaura_dac_decode": (C.c_int, [C.POINTER(Codec), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vaura_dac_workspace_elems": (C.c_size_t, [C.POINTER(Codec), C.c_int, C.c_int]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class VauraHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the shared library; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VauraHipError(
+                f"{LIB_PATH} is missing: the HIP hot path is not built (run `python -m vaura_amd.csrc.build`). "
+                "There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        names = {-1: "VAURA_ERR_ARG", -2: "VAURA_ERR_SHAPE", -3: "VAURA_ERR_DTYPE", -4: "VAURA_ERR_STATE"}
+        raise VauraHipError(f"{what}: {names.get(rc, rc)}")
+    raise VauraHipError(f"{what}: hipError_t {rc}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (0 for None)."""
+    return 0 if t is None else int(t.data_ptr())
+
+
+def current_stream() -> int:
+    import torch
+    return int(torch.cuda.current_stream().cuda_stream)

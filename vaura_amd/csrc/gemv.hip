@@ -114,11 +114,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_kernel(GemvArgs a) {
           wv[0] = bf16_lo(u.x); wv[1] = bf16_hi(u.x); wv[2] = bf16_lo(u.y); wv[3] = bf16_hi(u.y);
           wv[4] = bf16_lo(u.z); wv[5] = bf16_hi(u.z); wv[6] = bf16_lo(u.w); wv[7] = bf16_hi(u.w);
         } else {
-          const u32x4 u0 = wb[t][g][0], u1 = wb[t][g][1];
-          wv[0] = __builtin_bit_cast(float, u0.x); wv[1] = __builtin_bit_cast(float, u0.y);
-          wv[2] = __builtin_bit_cast(float, u0.z); wv[3] = __builtin_bit_cast(float, u0.w);
-          wv[4] = __builtin_bit_cast(float, u1.x); wv[5] = __builtin_bit_cast(float, u1.y);
-          wv[6] = __builtin_bit_cast(float, u1.z); wv[7] = __builtin_bit_cast(float, u1.w);
+          // whole-vector bit_cast: element-wise __builtin_bit_cast(float, u.y) of an ext-vector member
+          // was observed to read lane element 0 for every member (hipcc 7.2)
+          const f32x4 f0 = __builtin_bit_cast(f32x4, wb[t][g][0]);
+          const f32x4 f1 = __builtin_bit_cast(f32x4, wb[t][g][1]);
+          wv[0] = f0[0]; wv[1] = f0[1]; wv[2] = f0[2]; wv[3] = f0[3];
+          wv[4] = f1[0]; wv[5] = f1[1]; wv[6] = f1[2]; wv[7] = f1[3];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], xs[j], acc[t], 0, 0, 0);

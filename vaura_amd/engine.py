@@ -1,0 +1,346 @@
+"""Host-side owners of device state for the HIP hot path (torch = memory + streams only).
+
+``DecoderEngine``  packs a sampler state dict (reference key names) into the layouts of
+                   include/vaura_hip.h, owns K/V cache + workspaces, and drives
+                   vaura_prefill_cond / vaura_pattern_* / vaura_generate_loop.
+``CodecEngine``    folds weight-norm of a DAC state dict and drives vaura_dac_decode.
+
+Neither has a CPU path: construction fails if libvaura_hip.so cannot be loaded or the
+tensors are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .synth import CodecCfg, SamplerCfg, fold_weight_norm
+
+
+def rope_table(n_pos: int, head_dim: int, base: int = 10000) -> torch.Tensor:
+    """cos/sin table with the reference's own construction (llama.py:593-603) so that the
+    table entries are bit-identical to what the reference multiplies by."""
+    inv = 1.0 / (base ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    ang = torch.outer(torch.arange(n_pos), inv)
+    z = torch.polar(torch.ones_like(ang), ang)
+    return torch.stack([z.real, z.imag], dim=-1).contiguous()
+
+
+def _require_cuda(dev: torch.device):
+    if torch.device(dev).type != "cuda":
+        raise L.VauraHipError(f"the V-AURA hot path runs on a HIP device only (got {dev}); there is no CPU fallback")
+    L.lib()
+
+
+class DecoderEngine:
+    def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "bf16"):
+        _require_cuda(device)
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.wd = {"f32": L.W_F32, "bf16": L.W_BF16}[wdtype]
+        self.wdtype = wdtype
+        self.lib = L.lib()
+        D, F, K = cfg.d_model, cfg.ffn_dim, cfg.num_codebooks
+        with torch.cuda.device(self.dev):
+            self._keep = []  # device tensors referenced by raw pointers
+            lw = (L.LayerWeights * cfg.num_layers)()
+            for l in range(cfg.num_layers):
+                p = f"layers.{l}."
+                w1 = sd[p + "feed_forward.w1.weight"].float()
+                w3 = sd[p + "feed_forward.w3.weight"].float()
+                w13 = torch.stack([w1.view(F // 16, 16, D), w3.view(F // 16, 16, D)], dim=1).reshape(2 * F, D)
+                lw[l].wqkv = L.ptr(self._pack(sd[p + "attention.wqkv.weight"], self.wd))
+                lw[l].wo = L.ptr(self._pack(sd[p + "attention.wo.weight"], self.wd))
+                lw[l].w13 = L.ptr(self._pack(w13, self.wd))
+                lw[l].w2 = L.ptr(self._pack(sd[p + "feed_forward.w2.weight"], self.wd))
+                lw[l].attn_norm = L.ptr(self._dev(sd[p + "attention_norm.weight"]))
+                lw[l].ffn_norm = L.ptr(self._dev(sd[p + "ffn_norm.weight"]))
+            self.layers = lw
+            heads = torch.cat([sd[f"lm_heads.{k}.weight"].float() for k in range(K)], dim=0)
+            self.heads = self._pack(heads, self.wd)
+            self.final_norm = self._dev(sd["norm.weight"])
+            self.fc1 = self._pack(sd["cls_embeddings.projection.fc1.weight"], L.W_F32)
+            self.fc2 = self._pack(sd["cls_embeddings.projection.fc2.weight"], L.W_F32)
+            self.uncond = self._dev(sd["cls_embeddings.uncond_embedding"])
+            self.empty_video = self._dev(sd["empty_video_emb"].reshape(-1))
+            self.tok_emb = self._dev(torch.stack([sd[f"tok_embeddings.{k}.emb.weight"].float() for k in range(K)]))
+            self.tok_w = self._dev(torch.stack([
+                fold_weight_norm(sd[f"tok_embeddings.{k}.out_proj.weight_g"].float(),
+                                 sd[f"tok_embeddings.{k}.out_proj.weight_v"].float())[:, :, 0] for k in range(K)]))
+            self.tok_b = self._dev(torch.stack([sd[f"tok_embeddings.{k}.out_proj.bias"].float() for k in range(K)]))
+            torch.cuda.synchronize(self.dev)
+        self.dims = L.Dims(cfg.num_layers, D, cfg.nhead, F, K, cfg.d_codebook, cfg.cond_dim, cfg.tok_dim, cfg.cond_in,
+                           cfg.codebook_dim, 7, cfg.layer_norm_eps)
+        self.dec: Optional[L.Decoder] = None
+        self._shape = None
+        self._graph_key = None
+        self.weight_bytes = sum(t.numel() * t.element_size() for t in self._keep)
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        d = t.detach().to(self.dev, torch.float32).contiguous()
+        self._keep.append(d)
+        return d
+
+    def _pack(self, w: torch.Tensor, wd: int) -> torch.Tensor:
+        N, K = w.shape
+        src = w.detach().to(self.dev, torch.float32).contiguous()
+        dst = torch.empty(self.lib.vaura_packed_weight_bytes(N, K, wd), dtype=torch.uint8, device=self.dev)
+        L.check(self.lib.vaura_pack_weight(L.ptr(src), L.ptr(dst), N, K, wd, L.current_stream()), "vaura_pack_weight")
+        torch.cuda.current_stream().synchronize()  # src may be freed right after
+        self._keep.append(dst)
+        return dst
+
+    @staticmethod
+    def _rows_padded(r: int) -> int:
+        return (r + 15) // 16 * 16
+
+    # ------------------------------------------------------------------ per-call state
+    def prepare(self, batch: int, timesteps: int, n_cond_tokens: int, cfg_on: bool, tokens_per_frame: int = 7,
+                block_size: Optional[int] = None):
+        c = self.cfg
+        K = c.num_codebooks
+        S = timesteps + K
+        rows = 2 * batch if cfg_on else batch
+        max_len = (max(S, block_size or 0) + 31) // 32 * 32
+        key = (batch, timesteps, n_cond_tokens, cfg_on, tokens_per_frame, max_len)
+        if self._shape == key:
+            return
+        with torch.cuda.device(self.dev):
+            rp = self._rows_padded(rows)
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            self.rope = rope_table(max_len, c.head_dim, c.rope_base).to(self.dev)
+            self.kcache = torch.zeros(c.num_layers, rows, c.nhead, max_len, c.head_dim, **f32)
+            self.vcache = torch.zeros_like(self.kcache)
+            self.seq = torch.zeros(batch, K, S, dtype=torch.int32, device=self.dev)
+            self.state = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            self.ws_h = torch.zeros(rp * c.d_model, **f32)
+            self.ws_qkv = torch.zeros(rp * 3 * c.d_model, **f32)
+            self.ws_attn = torch.zeros(rp * c.d_model, **f32)
+            self.ws_ffn = torch.zeros(rp * c.ffn_dim, **f32)
+            self.ws_logits = torch.zeros(rows, K * c.d_codebook, **f32)
+            crp = self._rows_padded(rows * n_cond_tokens)
+            self.cond_in = torch.zeros(crp * c.cond_in, **f32)
+            self.cond_tmp = torch.zeros(crp * c.cond_dim, **f32)
+            self.cond_proj = torch.zeros(crp * c.cond_dim, **f32)
+            self.codes_i32 = torch.zeros(batch, K, timesteps, dtype=torch.int32, device=self.dev)
+        d = L.Decoder()
+        d.dims = self.dims
+        d.dims.tokens_per_frame = tokens_per_frame
+        d.wdtype, d.batch, d.rows, d.max_len = self.wd, batch, rows, max_len
+        d.timesteps, d.seq_len, d.n_cond_tokens = timesteps, S, n_cond_tokens
+        d.layers_host = C.cast(self.layers, C.POINTER(L.LayerWeights))
+        d.heads, d.final_norm = L.ptr(self.heads), L.ptr(self.final_norm)
+        d.tok_emb, d.tok_proj_w, d.tok_proj_b = L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b)
+        d.empty_video, d.rope, d.cond_proj = L.ptr(self.empty_video), L.ptr(self.rope), L.ptr(self.cond_proj)
+        d.kcache, d.vcache, d.seq, d.state = L.ptr(self.kcache), L.ptr(self.vcache), L.ptr(self.seq), L.ptr(self.state)
+        d.noise = 0
+        d.ws_h, d.ws_qkv, d.ws_attn = L.ptr(self.ws_h), L.ptr(self.ws_qkv), L.ptr(self.ws_attn)
+        d.ws_ffn, d.ws_logits = L.ptr(self.ws_ffn), L.ptr(self.ws_logits)
+        self.dec = d
+        self._shape = key
+        self._graph_key = None
+        self.batch, self.rows, self.T, self.S, self.Tv, self.max_len = batch, rows, timesteps, S, n_cond_tokens, max_len
+
+    def kv_bytes_per_position(self) -> int:
+        c = self.cfg
+        return 2 * c.num_layers * self.rows * c.d_model * 4
+
+    def set_condition(self, feats: torch.Tensor):
+        """feats (B, Tv, 768) fp32 on device.  Rows [B, 2B) get the CFG null embedding
+        (models/vaura_model.py:790-793) when the engine was prepared with cfg_on."""
+        assert self.dec is not None
+        B, Tv, Cin = feats.shape
+        assert B == self.batch and Tv == self.Tv and Cin == self.cfg.cond_in
+        x = feats.to(self.dev, torch.float32)
+        if self.rows == 2 * B:
+            if Tv != self.uncond.shape[0]:
+                raise L.VauraHipError(f"CFG null embedding has {self.uncond.shape[0]} tokens, condition has {Tv}")
+            x = torch.cat([x, torch.zeros_like(x) + self.uncond], dim=0)
+        x = x.reshape(self.rows * Tv, Cin).contiguous()
+        st = L.current_stream()
+        n = self.rows * Tv
+        L.check(self.lib.vaura_pack_rows(L.ptr(x), L.ptr(self.cond_in), n, Cin, st), "vaura_pack_rows")
+        L.check(self.lib.vaura_prefill_cond(C.byref(self.dims), L.ptr(self.cond_in), L.ptr(self.fc1), L.ptr(self.fc2),
+                                            L.W_F32, L.ptr(self.cond_tmp), L.ptr(self.cond_proj), n, st),
+                "vaura_prefill_cond")
+        self._cond_keepalive = x
+
+    def cond_projection(self) -> torch.Tensor:
+        """(rows, Tv, cond_dim) row-major view of the hoisted video MLP output (tests)."""
+        n = self.rows * self.Tv
+        out = torch.empty(n, self.cfg.cond_dim, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.vaura_unpack_rows(L.ptr(self.cond_proj), L.ptr(out), n, self.cfg.cond_dim, L.current_stream()),
+                "vaura_unpack_rows")
+        return out.view(self.rows, self.Tv, self.cfg.cond_dim)
+
+    # ------------------------------------------------------------------ generation
+    def _sampling(self, use_sampling, temp, top_k, top_p, cfg_scale, seed, clip_base) -> L.Sampling:
+        return L.Sampling(int(bool(use_sampling)), float(temp), int(top_k), float(top_p),
+                          float(cfg_scale if self.rows == 2 * self.batch else 1.0), int(seed), int(clip_base))
+
+    def start_sequence(self, prompt: Optional[torch.Tensor]):
+        """codes = -1 everywhere but the prompt -> pattern sequence on device; returns Tp."""
+        K, T = self.cfg.num_codebooks, self.T
+        self.codes_i32.fill_(-1)
+        Tp = 0
+        if prompt is not None and prompt.shape[-1] > 0:
+            Tp = prompt.shape[-1]
+            assert Tp < T, "gt audio prompt can not be longer than max_new_tokens"
+            self.codes_i32[..., :Tp] = prompt.to(self.dev, torch.int32)
+        L.check(self.lib.vaura_pattern_build(L.ptr(self.codes_i32), L.ptr(self.seq), self.batch, K, T,
+                                             self.cfg.d_codebook, L.current_stream()), "vaura_pattern_build")
+        self.state.zero_()
+        return Tp
+
+    def run(self, n_prefill: int, n_steps: int, sp: L.Sampling, noise: Optional[torch.Tensor] = None,
+            use_graph: bool = True):
+        """Enqueue `n_prefill` teacher-forced positions and `n_steps` sampled ones (asynchronous).
+        With `use_graph` one decode step is captured once into a hipGraph and replayed per step; HIP
+        cannot capture on the legacy default stream, so the loop then runs on a private stream that is
+        ordered after / before the caller's current stream."""
+        self.dec.noise = L.ptr(noise)
+        self._noise_keepalive = noise
+        use_graph = bool(use_graph and n_steps > 0)
+        cur = torch.cuda.current_stream(self.dev)
+        side = None
+        if use_graph and cur.cuda_stream == 0:
+            if getattr(self, "_stream", None) is None:
+                self._stream = torch.cuda.Stream(self.dev)
+            side = self._stream
+            side.wait_stream(cur)
+        with torch.cuda.stream(side if side is not None else cur):
+            st = L.current_stream()
+            if use_graph:
+                key = (self._shape, L.ptr(noise), bytes(sp))
+                if self._graph_key != key:
+                    L.check(self.lib.vaura_step_graph_build(C.byref(self.dec), C.byref(sp), st), "vaura_step_graph_build")
+                    self._graph_key = key
+            L.check(self.lib.vaura_generate_loop(C.byref(self.dec), C.byref(sp), n_prefill, n_steps, int(use_graph), st),
+                    "vaura_generate_loop")
+        if side is not None:
+            cur.wait_stream(side)
+
+    def revert(self) -> torch.Tensor:
+        K, T = self.cfg.num_codebooks, self.T
+        L.check(self.lib.vaura_pattern_revert(L.ptr(self.seq), L.ptr(self.codes_i32), self.batch, K, T, self.S, -1,
+                                              L.current_stream()), "vaura_pattern_revert")
+        return self.codes_i32
+
+    @torch.no_grad()
+    def generate_codes(self, feats: torch.Tensor, max_new_tokens: int, *, prompt: Optional[torch.Tensor] = None,
+                       use_sampling=False, temp=1.0, top_k=0, top_p=0.0, cfg_scale=1.0, noise=None, seed=0,
+                       clip_base=0, use_graph=True, tokens_per_frame=7) -> torch.Tensor:
+        """The hot loop of generate(): (B, Tv, 768) -> codes (B, K, T) int64 (device)."""
+        B, Tv, _ = feats.shape
+        cfg_on = cfg_scale > 1.0
+        self.prepare(B, max_new_tokens, Tv, cfg_on, tokens_per_frame, block_size=self.cfg.block_size)
+        self.set_condition(feats)
+        Tp = self.start_sequence(prompt)
+        start = Tp + 1  # Pattern.get_first_step_with_timesteps(Tp) for the delayed pattern
+        sp = self._sampling(use_sampling, temp, top_k, top_p, cfg_scale, seed, clip_base)
+        if noise is not None:
+            noise = noise.to(self.dev, torch.float32).contiguous()
+            assert noise.shape == (self.S - start, B * self.cfg.num_codebooks, self.cfg.d_codebook), noise.shape
+        self.run(start - 1, self.S - start, sp, noise, use_graph)
+        return self.revert().to(torch.int64)
+
+    # ------------------------------------------------------------------ op-level access (tests / plugin forward)
+    def logits_all_positions(self, idx: torch.Tensor, feats: torch.Tensor, tokens_per_frame: int = 7) -> torch.Tensor:
+        """Teacher-forced pass: idx (Bs, K, Lq) int64, feats (Bs, Tv, 768) -> logits (Bs, K, Lq, V).
+        One decode step per position, heads evaluated every step (API-compat path of
+        ``Transformer.forward``; the generate loop never materialises this tensor)."""
+        Bs, K, Lq = idx.shape
+        self.prepare(Bs, Lq, feats.shape[1], False, tokens_per_frame, block_size=self.cfg.block_size)
+        self.set_condition(feats)
+        self.seq.zero_()
+        self.seq[:, :, :Lq] = idx.to(self.dev, torch.int32)
+        self.state.zero_()
+        out = torch.empty(Bs, K, Lq, self.cfg.d_codebook, dtype=torch.float32, device=self.dev)
+        sp = self._sampling(False, 1.0, 0, 0.0, 1.0, 0, 0)
+        st = L.current_stream()
+        keep = self.seq.clone()
+        for p in range(Lq):
+            L.check(self.lib.vaura_decode_step(C.byref(self.dec), C.byref(sp), 1, st), "vaura_decode_step")
+            out[:, :, p] = self.ws_logits.view(Bs, K, -1)
+            self.seq.copy_(keep)  # the sampler only fills -1 slots, but keep the input pristine anyway
+        return out
+
+
+class CodecEngine:
+    """DAC decode (codes -> waveform) on the HIP path; weights from a DAC-1.0.0-keyed state dict."""
+
+    def __init__(self, cfg: CodecCfg, sd: Dict[str, torch.Tensor], device="cuda:0"):
+        _require_cuda(device)
+        self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
+        self._keep = []
+        c = L.Codec()
+        c.n_codebooks, c.codebook_size, c.codebook_dim, c.latent_dim = (cfg.n_codebooks, cfg.codebook_size,
+                                                                        cfg.codebook_dim, cfg.latent_dim)
+        nb = len(cfg.decoder_rates)
+        assert nb <= 4 and len(cfg.dilations) == 3
+        c.n_blocks, c.n_units = nb, 3
+        for i, r in enumerate(cfg.decoder_rates):
+            c.rates[i] = r
+        K = cfg.n_codebooks
+        f = lambda p: fold_weight_norm(sd[p + "weight_g"].float(), sd[p + "weight_v"].float())
+        c.codebooks = L.ptr(self._dev(torch.stack([sd[f"quantizer.quantizers.{k}.codebook.weight"].float() for k in range(K)])))
+        c.out_proj_w = L.ptr(self._dev(torch.stack([f(f"quantizer.quantizers.{k}.out_proj.")[:, :, 0] for k in range(K)])))
+        c.out_proj_b = L.ptr(self._dev(torch.stack([sd[f"quantizer.quantizers.{k}.out_proj.bias"].float() for k in range(K)])))
+        self._conv(c.conv_in, sd, "decoder.model.0.", 1, 1)
+        for b, r in enumerate(cfg.decoder_rates):
+            p = f"decoder.model.{b + 1}.block."
+            c.alpha_up[b] = L.ptr(self._dev(sd[p + "0.alpha"].reshape(-1)))
+            self._conv(c.up[b], sd, p + "1.", 1, r)
+            for u, dil in enumerate(cfg.dilations):
+                q = p + f"{u + 2}.block."
+                c.alpha_res[b][u][0] = L.ptr(self._dev(sd[q + "0.alpha"].reshape(-1)))
+                self._conv(c.res[b][u][0], sd, q + "1.", dil, 1)
+                c.alpha_res[b][u][1] = L.ptr(self._dev(sd[q + "2.alpha"].reshape(-1)))
+                self._conv(c.res[b][u][1], sd, q + "3.", 1, 1)
+        n = nb + 1
+        c.alpha_out = L.ptr(self._dev(sd[f"decoder.model.{n}.alpha"].reshape(-1)))
+        self._conv(c.conv_out, sd, f"decoder.model.{n + 1}.", 1, 1)
+        self.c = c
+        self._ws_key = None
+
+    def _dev(self, t):
+        d = t.detach().to(self.dev, torch.float32).contiguous()
+        self._keep.append(d)
+        return d
+
+    def _conv(self, cv: L.Conv, sd, prefix: str, dilation: int, stride: int):
+        w = fold_weight_norm(sd[prefix + "weight_g"].float(), sd[prefix + "weight_v"].float())
+        if stride > 1:   # ConvTranspose1d weight (Cin, Cout, 2r) -> [phase][tap][Cout][Cin]
+            cin, cout, k = w.shape
+            assert k == 2 * stride
+            wl = w.permute(2, 1, 0).reshape(2, stride, cout, cin).permute(1, 0, 2, 3)
+            taps = 2
+        else:            # Conv1d weight (Cout, Cin, k) -> [tap][Cout][Cin]
+            cout, cin, k = w.shape
+            wl = w.permute(2, 0, 1)
+            taps = k
+        cv.w = L.ptr(self._dev(wl))
+        cv.bias = L.ptr(self._dev(sd[prefix + "bias"]))
+        cv.cin, cv.cout, cv.taps, cv.dilation, cv.stride = cin, cout, taps, dilation, stride
+
+    @torch.no_grad()
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """codes (B, K, T) integer tensor on device -> wav (B, 1, T*hop) fp32."""
+        B, K, T = codes.shape
+        ci = codes.to(self.dev, torch.int32).contiguous()
+        need = self.lib.vaura_dac_workspace_elems(C.byref(self.c), B, T)
+        if self._ws_key is None or self._ws_key < need:
+            self._ws = [torch.empty(need, dtype=torch.float32, device=self.dev) for _ in range(4)]
+            for i in range(4):
+                self.c.ws[i] = L.ptr(self._ws[i])
+            self.c.ws_elems = need
+            self._ws_key = need
+        wav = torch.empty(B, 1, T * self.cfg.hop, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.vaura_dac_decode(C.byref(self.c), L.ptr(ci), B, T, L.ptr(wav), L.current_stream()),
+                "vaura_dac_decode")
+        self._codes_keepalive = ci
+        return wav

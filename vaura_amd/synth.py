@@ -218,7 +218,7 @@ def codec_state_dict(cfg: CodecCfg = FULL_CODEC, seed: int = 0) -> Dict[str, tor
     cl = ch // (2 ** len(cfg.decoder_rates))
     n = len(cfg.decoder_rates) + 1
     sd[f"decoder.model.{n}.alpha"] = uniform(f"decoder.model.{n}.alpha", (1, cl, 1), 0.5, 1.5, seed)
-    _wn_conv(sd, f"decoder.model.{n + 1}.", 1, cl, 7, seed, gain=0.25)
+    _wn_conv(sd, f"decoder.model.{n + 1}.", 1, cl, 7, seed, gain=0.04)
     return sd
 
 
