@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py — V-AURA generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic clips on each GPU:
+video-feature MLP -> 228-step KV-cached decode loop (CFG + top-k sampling, delay pattern) ->
+DAC decode to a 44.1 kHz waveform, with features / weights already resident in HBM.
+Workload (BASELINE.json configs[1]): 8 clips per GPU of 2.56 s (T=220 frames, 9 codebooks),
+top-k 250, temperature 1.0, cfg_scale 6.0 (the reference's default, configs/generate_vgg.yaml:27).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from vaura_amd import _lib as L  # noqa: E402
+from vaura_amd import dist as vdist  # noqa: E402
+from vaura_amd import synth  # noqa: E402
+from vaura_amd.engine import CodecEngine, DecoderEngine  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+T_FRAMES, K_CB, TV = 220, 9, 32
+HOP = 512
+
+
+def algorithmic_bytes_per_launch(kind: str, cfg: synth.SamplerCfg, wbytes: int, rows: int) -> float:
+    """Weight bytes a launch of each GEMV kind must stream."""
+    D, F = cfg.d_model, cfg.ffn_dim
+    n = {"qkv": 3 * D * D, "wo": D * D, "w13": 2 * F * D, "w2": D * F, "heads": cfg.num_codebooks * cfg.d_codebook * D}[kind]
+    return float(n * wbytes)
+
+
+def decode_loop_bytes(cfg: synth.SamplerCfg, wbytes: int, rows: int, steps: int) -> float:
+    """sum_L [ W*b_w + 24*2*Bs*1536*b_kv*(L+1) ], fp32 KV (SURVEY.md §8d with b_kv = 4)."""
+    D, F = cfg.d_model, cfg.ffn_dim
+    W = cfg.num_layers * (3 * D * D + D * D + 3 * F * D) + cfg.num_codebooks * cfg.d_codebook * D
+    tot = 0.0
+    for Lc in range(1, steps + 1):
+        tot += W * wbytes + cfg.num_layers * 2 * rows * D * 4 * (Lc + 1)
+    return tot
+
+
+def cpu_baseline(sd, feats_cpu, cfg_scale):
+    """Oracle (CPU port of the reference path) on this box's host cores, bounded sample.
+    The reference recomputes the whole prefix every step (models/vaura_model.py:504-506): time the
+    full-prefix forward of ONE clip (2 rows with CFG) at four prefix lengths and integrate over the
+    228 steps; also time the KV-cached variant so the GPU/CPU ratio is not just the algorithmic gap."""
+    from oracle.decoder_oracle import CachedDecoder, DecoderOracle
+    cfg = synth.FULL_SAMPLER
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
+    cond = feats_cpu[:1]
+    cond = torch.cat([cond, dec.null_condition(cond)], 0) if cfg_scale > 1 else cond
+    g = torch.Generator().manual_seed(0)
+    pts = [8, 64, 128, 228]
+    ts = []
+    with torch.no_grad():
+        for Lq in pts:
+            idx = torch.randint(0, 1024, (cond.shape[0], K_CB, Lq), generator=g)
+            t0 = time.perf_counter()
+            dec.forward_full(idx, cond)
+            ts.append(time.perf_counter() - t0)
+        # piecewise-linear integral of t(L) over L = 1..228
+        total = 0.0
+        xs = [1] + pts
+        ys = [ts[0]] + ts
+        for i in range(1, len(xs)):
+            total += 0.5 * (ys[i] + ys[i - 1]) * (xs[i] - xs[i - 1])
+        faithful_tok_s = K_CB * T_FRAMES / total
+        cd = CachedDecoder(dec, cond, 64)
+        n = 24
+        tok = torch.randint(0, 1024, (cond.shape[0], K_CB), generator=g)
+        cd.step(tok)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            cd.step(tok)
+        cached_step = (time.perf_counter() - t0) / n
+    cached_tok_s = K_CB * T_FRAMES / (cached_step * 228)
+    return {
+        "value": round(faithful_tok_s, 2), "unit": "codec tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle/ fp32 torch-CPU port, 1 clip (rows={cond.shape[0]}, cfg {cfg_scale}): full-prefix forward "
+                   f"(the reference's no-cache algorithm) timed at L={pts} -> {['%.3f' % t for t in ts]} s, integrated over "
+                   f"228 steps = {total:.1f} s/clip, decode loop only (codec excluded); KV-cached variant "
+                   f"{cached_step * 1e3:.1f} ms/step"),
+        "kv_cached_value": round(cached_tok_s, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--cfg-scale", type=float, default=6.0)
+    ap.add_argument("--top-k", type=int, default=250)
+    ap.add_argument("--weights", choices=["bf16", "f32"], default="bf16", help="storage of the streamed matrices")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank, local, world = vdist.init("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    L.lib()  # fail loudly before doing anything expensive
+
+    cfg, ccfg = synth.FULL_SAMPLER, synth.FULL_CODEC
+    B = args.batch
+    first, _ = vdist.shard(B * world, rank, world)
+    sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
+    eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights)
+    codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev)
+    feats_cpu = synth.video_features(B, TV, cfg.cond_in, seed=0, first_clip=first)
+    feats = feats_cpu.to(dev)
+    kw = dict(use_sampling=True, temp=1.0, top_k=args.top_k, top_p=0.0, cfg_scale=args.cfg_scale, seed=1234,
+              clip_base=first, use_graph=not args.no_graph)
+    counts = [B] * world
+
+    def step():
+        codes = eng.generate_codes(feats, T_FRAMES, **kw)
+        wav = codec.decode(codes)
+        if world > 1:  # the single exchange of the job: final gather of tokens + waveform over RCCL
+            vdist.gather_clips(codes.to(torch.int16), counts)
+            vdist.gather_clips(wav, counts)
+        return codes, wav
+
+    for _ in range(args.warmup):
+        step()
+    vdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codes, wav = step()
+    torch.cuda.synchronize(dev)
+    vdist.barrier()
+    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+
+    assert codes.shape == (B, K_CB, T_FRAMES) and int(codes.min()) >= 0 and int(codes.max()) < 1024
+    assert wav.shape == (B, 1, T_FRAMES * HOP) and bool(torch.isfinite(wav).all())
+
+    tokens = world * B * K_CB * T_FRAMES * args.steps
+    rows = 2 * B if args.cfg_scale > 1 else B
+    wbytes = 2 if args.weights == "bf16" else 4
+    out = {
+        "metric": "audio codec tokens/sec (whole node), 2.56 s clips",
+        "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"configs[1]: batch={B}/GPU x 2.56 s clips (T=220, 9 codebooks, Tv=32 AVCLIP-shaped features), "
+                                f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
+                                "1536-d decoder + DAC-44k decode to waveform"),
+                   "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
+                   "weights": (f"{args.weights} storage of streamed matrices (synthetic checkpoint is bf16-representable: exact), "
+                               "fp32 activations / accumulate / KV cache; codec fp32"),
+                   "hipgraph": not args.no_graph},
+        "sec_audio_per_sec": round(world * B * T_FRAMES * HOP / 44100.0 * args.steps / elapsed, 2),
+    }
+
+    if rank == 0 and not args.no_extras:
+        # ---- split of one step + dominant-kernel roofline, measured live with HIP events
+        torch.cuda.synchronize(dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        reps = max(2, args.steps)
+        e0.record()
+        for _ in range(reps):
+            cd = eng.generate_codes(feats, T_FRAMES, **kw)
+        e1.record()
+        for _ in range(reps):
+            codec.decode(cd)
+        e2.record()
+        torch.cuda.synchronize(dev)
+        t_loop, t_codec = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
+        lb = decode_loop_bytes(cfg, wbytes, rows, 228)
+        out["split_ms"] = {"decode_loop": round(t_loop, 3), "codec": round(t_codec, 3)}
+        out["decode_loop_roofline"] = {"bound": "hbm", "achieved": round(lb / (t_loop * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(lb / (t_loop * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "bytes": lb}
+        out["codec_tflops"] = round(B * 353.8e9 / (t_codec * 1e-3) / 1e12, 2)
+
+        # per-kernel: event pairs around every launch of the weight-streaming kernels (eager pass, on the
+        # stream they are launched on), vaura_profile_loop
+        eng.start_sequence(None)
+        sp = eng._sampling(True, 1.0, args.top_k, 0.0, args.cfg_scale, 1234, first)
+        eng.dec.noise = 0
+        tot = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        kinds = {"qkv": 1, "attn": 2, "wo": 3, "w13": 4, "w2": 5, "heads": 6}
+        per = {}
+        for name, bit in kinds.items():   # one kind per pass so the event records do not perturb each other
+            eng.start_sequence(None)
+            L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), 228, 1 << bit, tot, cnt,
+                                               int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
+            per[name] = 1e3 * tot[bit] / max(1, cnt[bit])   # us per launch
+        dom = "w13"
+        ab = algorithmic_bytes_per_launch(dom, cfg, wbytes, rows)
+        ach = ab / (per[dom] * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_w13.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "kernel": "gemv_kernel<w1|w3 SwiGLU, K=1536, N=8192> (feed_forward.w1/w3)",
+                           "algorithmic_bytes_per_launch": ab, "avg_us_per_launch": round(per[dom], 3)}
+        out["kernel_us"] = {k: round(v, 3) for k, v in per.items()}
+
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale)
+            out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

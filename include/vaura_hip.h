@@ -101,6 +101,7 @@ typedef struct vaura_decoder {
   const float* tok_emb;      /* (K, vocab+1, codebook_dim)                         llama.py:392-404 */
   const float* tok_proj_w;   /* (K, tok_dim, codebook_dim) weight-norm folded      llama.py:405-409 */
   const float* tok_proj_b;   /* (K, tok_dim)                                                */
+  const float* tok_table;    /* (K, vocab+1, tok_dim) = vaura_build_token_table(tok_emb, tok_proj_w, tok_proj_b) */
   const float* empty_video;  /* (cond_dim)                                         llama.py:336-338 */
   const float* rope;         /* (max_len, head_dim/2, 2) cos,sin                   llama.py:593-603 */
   const float* cond_proj;    /* packed rows (rows*Tv x cond_dim): vaura_prefill_cond output */
@@ -116,6 +117,13 @@ typedef struct vaura_decoder {
   float* ws_attn;            /* packed rows (rows x d_model)                        */
   float* ws_ffn;             /* packed rows (rows x ffn_dim)                        */
   float* ws_logits;          /* row-major (rows, K*vocab)                           */
+  /* bf16-weight path only: activations as exact hi/mid/lo bf16 planes ("split rows", see
+   * vaura_amd/csrc/gemv3_kernel.h) and per-tile partial sums of squares for the fused RMSNorm  */
+  uint16_t* ws_h_split;      /* split rows (rows x d_model) of h * next_norm_gain   */
+  uint16_t* ws_attn_split;   /* split rows (rows x d_model)                         */
+  uint16_t* ws_ffn_split;    /* split rows (rows x ffn_dim)                         */
+  float*    ws_ss;           /* (row_blocks, d_model/16, 16)                        */
+  const float* first_norm;   /* layers[0].attn_norm (device), gain applied by the embed kernel */
 } vaura_decoder;
 
 /* -------------------------------------------------------------------------------------------
@@ -123,6 +131,11 @@ typedef struct vaura_decoder {
  * src: row-major fp32 (N x K) as stored in the reference checkpoint (nn.Linear.weight).          */
 int vaura_pack_weight(const float* src, void* dst, int64_t N, int64_t K, int wdtype, vaura_stream_t s);
 size_t vaura_packed_weight_bytes(int64_t N, int64_t K, int wdtype);
+
+/* a4 DacEmbeddingProjection (llama.py:60-73) evaluated once for every (codebook, token):
+ * table[k][tok][c] = sum_i w[k][c][i] * emb[k][tok][i] + b[k][c]   (K, vocab+1, tok_dim) fp32   */
+int vaura_build_token_table(const float* tok_emb, const float* proj_w, const float* proj_b, float* table, int K,
+                            int vocab1, int cdim, int tok_dim, vaura_stream_t s);
 
 /* row-major (rows x C) fp32 <-> packed rows.  `rows_padded` = ceil(rows/16)*16 rows are written.   */
 int vaura_pack_rows(const float* src, float* dst, int64_t rows, int64_t C, vaura_stream_t s);
@@ -165,12 +178,33 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
 int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s);
 void vaura_step_graph_free(void);
 
+/* Measurement aid (bench.py): runs `n_steps` sampled steps eagerly on `s` with a hipEvent pair
+ * around every launch of the kernel kinds selected by `kind_mask` (bit = vaura_kernel_kind), then
+ * synchronises `s` and reports, per kind, the summed elapsed ms and the launch count (HOST arrays of
+ * VAURA_K_COUNT entries).  The only entry point that creates events / synchronises.              */
+typedef enum vaura_kernel_kind {
+  VAURA_K_EMBED = 0, VAURA_K_QKV = 1, VAURA_K_ATTN = 2, VAURA_K_WO = 3, VAURA_K_W13 = 4, VAURA_K_W2 = 5,
+  VAURA_K_HEADS = 6, VAURA_K_SAMPLE = 7, VAURA_K_COUNT = 8
+} vaura_kernel_kind;
+int vaura_profile_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_steps, unsigned kind_mask,
+                       double* total_ms_host, int64_t* launches_host, vaura_stream_t s);
+
 /* -------------------------------------------------------------------------------------------
  * op-level entry points (parity tests call the same kernels the step uses)                      */
 /* out = epilogue( W x (x*gain) * rinv ):  epi 0 store, 1 +residual, 2 SwiGLU pairs, 3 gelu_tanh,
  * 4 row-major logits.  K must be one of the compiled depths (512, 768, 1024, 1536, 4096).        */
 int vaura_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
                int64_t rows, int64_t N, int64_t K, int epilogue, float eps, vaura_stream_t s);
+/* bf16-weight form of vaura_gemv: x as exact hi/mid/lo bf16 planes ("split rows"), products on
+ * v_mfma_f32_16x16x32_bf16.  ss_in (row_blocks, n_ss_in, 16): partial sums of squares of the raw input
+ * (fused RMSNorm) or NULL.  Optional outputs: fp32 packed rows, split rows of out*gain_out, partial
+ * sums of squares of out.  epilogue: 0 store, 1 +residual, 2 SwiGLU pairs, 4 row-major logits.       */
+int vaura_gemv_bf16(const void* w, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+                    uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
+                    float eps, vaura_stream_t s);
+/* packed rows (rows x C) fp32 [* gain] -> split rows (3 * rows_padded * C bf16) [+ partial sums of squares] */
+int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* ss, int64_t rows, int64_t C, vaura_stream_t s);
+
 /* a8/a9 for one layer at position `pos` (host value): rope(q,k), append, softmax(qK^T/sqrt(hd)) V. */
 int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
                          int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s);

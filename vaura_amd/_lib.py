@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvaura_hip.so")
 
 W_F32, W_BF16 = 0, 1
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_LOGITS = 0, 1, 2, 3, 4
+KERNEL_KINDS = ("embed", "qkv", "attn", "wo", "w13", "w2", "heads", "sample")
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
@@ -40,12 +41,14 @@ class Decoder(C.Structure):
                 ("max_len", C.c_int32), ("timesteps", C.c_int32), ("seq_len", C.c_int32),
                 ("n_cond_tokens", C.c_int32), ("_pad0", C.c_int32),
                 ("layers_host", C.POINTER(LayerWeights)), ("heads", C.c_void_p), ("final_norm", C.c_void_p),
-                ("tok_emb", C.c_void_p), ("tok_proj_w", C.c_void_p), ("tok_proj_b", C.c_void_p),
+                ("tok_emb", C.c_void_p), ("tok_proj_w", C.c_void_p), ("tok_proj_b", C.c_void_p), ("tok_table", C.c_void_p),
                 ("empty_video", C.c_void_p), ("rope", C.c_void_p), ("cond_proj", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("seq", C.c_void_p), ("state", C.c_void_p),
                 ("noise", C.c_void_p),
                 ("ws_h", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_attn", C.c_void_p), ("ws_ffn", C.c_void_p),
-                ("ws_logits", C.c_void_p)]
+                ("ws_logits", C.c_void_p),
+                ("ws_h_split", C.c_void_p), ("ws_attn_split", C.c_void_p), ("ws_ffn_split", C.c_void_p),
+                ("ws_ss", C.c_void_p), ("first_norm", C.c_void_p)]
 
 
 class Conv(C.Structure):
@@ -69,6 +72,8 @@ SIGNATURES = {
     "vaura_version": (C.c_char_p, []),
     "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "vaura_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "vaura_build_token_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p]),
     "vaura_pack_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "vaura_unpack_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "vaura_prefill_cond": (C.c_int, [C.POINTER(Dims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -81,8 +86,13 @@ SIGNATURES = {
     "vaura_generate_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vaura_step_graph_build": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_void_p]),
     "vaura_step_graph_free": (None, []),
+    "vaura_profile_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_uint, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int64), C.c_void_p]),
     "vaura_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                              C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "vaura_gemv_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    "vaura_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "vaura_attention_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vaura_dac_decode": (C.c_int, [C.POINTER(Codec), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -104,6 +114,9 @@ def lib() -> C.CDLL:
             raise VauraHipError(
                 f"{LIB_PATH} is missing: the HIP hot path is not built (run `python -m vaura_amd.csrc.build`). "
                 "There is no CPU fallback.")
+        # torch first: libvaura_hip.so must bind to the HIP runtime torch has already loaded and
+        # initialised, otherwise a second runtime without a device context answers (hipErrorNoDevice)
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

@@ -4,12 +4,14 @@
 //   Transformer.inference              models/modules/sampler/llama.py:445-504
 //   TransformerBlock.forward           llama.py:272-283
 #include "common.h"
+#include "gemv3_kernel.h"
+#include <vector>
 
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
 
 static int check_decoder(const vaura_decoder* d) {
   if (!d || !d->layers_host || !d->heads || !d->final_norm || !d->tok_emb || !d->tok_proj_w || !d->tok_proj_b ||
-      !d->empty_video || !d->rope || !d->cond_proj || !d->kcache || !d->vcache || !d->seq || !d->state || !d->ws_h ||
+      !d->tok_table || !d->empty_video || !d->rope || !d->cond_proj || !d->kcache || !d->vcache || !d->seq || !d->state || !d->ws_h ||
       !d->ws_qkv || !d->ws_attn || !d->ws_ffn || !d->ws_logits)
     return VAURA_ERR_ARG;
   const vaura_dims& m = d->dims;
@@ -20,39 +22,133 @@ static int check_decoder(const vaura_decoder* d) {
   return 0;
 }
 
-static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
+// Optional per-launch timing (vaura_profile_loop): event pairs around every launch of the selected kinds.
+struct StepProfiler {
+  unsigned mask = 0;
+  std::vector<hipEvent_t> ev[VAURA_K_COUNT];
+  void before(int kind, hipStream_t s) {
+    if (!(mask & (1u << kind))) return;
+    hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s); ev[kind].push_back(e);
+  }
+  void after(int kind, hipStream_t s) { before(kind, s); }
+};
+static StepProfiler* g_prof = nullptr;
+#define PROF_B(kind) do { if (g_prof) g_prof->before(kind, s); } while (0)
+#define PROF_A(kind) do { if (g_prof) g_prof->after(kind, s); } while (0)
+
+static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
+                    const float* gain_out, float* ss_out, const vaura_decoder* d, int N) {
+  Gemv3Args a;
+  a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
+  a.gain_out = gain_out; a.ss_out = ss_out; a.rows = d->rows; a.R = (d->rows + 15) / 16; a.N = N; a.eps = d->dims.eps;
+  a.k_total = d->dims.d_model;
+  return a;
+}
+
+// bf16-stored weights: activations travel as exact hi/mid/lo bf16 planes, products on the bf16 MFMA
+static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
   const int rows = d->rows;
+  if (!d->ws_h_split || !d->ws_attn_split || !d->ws_ffn_split || !d->ws_ss) return VAURA_ERR_ARG;
+  PROF_B(VAURA_K_EMBED);
+  int rc = va_launch_embed(d, s);   // h, split(h * attn_norm[0]), ss partials
+  PROF_A(VAURA_K_EMBED);
+  if (rc) return rc;
+  const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
+  for (int l = 0; l < m.n_layer; ++l) {
+    const vaura_layer_weights& L = d->layers_host[l];
+    const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
+    PROF_B(VAURA_K_QKV);   // qkv = rinv * Wqkv.(g*h)                                  llama.py:280, 228
+    rc = va_launch_gemv3(g3(L.wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D), 3 * D, D,
+                         E3_STORE, true, s);
+    PROF_A(VAURA_K_QKV);
+    if (rc) return rc;
+    PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
+    rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
+                             d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, s);
+    PROF_A(VAURA_K_ATTN);
+    if (rc) return rc;
+    PROF_B(VAURA_K_WO);    // h += Wo.attn ; emit split(h * ffn_norm) + ss               llama.py:259, 279
+    rc = va_launch_gemv3(g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D), D, D,
+                         E3_RESID, false, s);
+    PROF_A(VAURA_K_WO);
+    if (rc) return rc;
+    PROF_B(VAURA_K_W13);   // ffn = silu(W1 x) * (W3 x), x = rmsnorm(h)                  llama.py:282, 177
+    rc = va_launch_gemv3(g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F), 2 * F, D,
+                         E3_SWIGLU, true, s);
+    PROF_A(VAURA_K_W13);
+    if (rc) return rc;
+    PROF_B(VAURA_K_W2);    // h += W2.ffn ; emit split(h * next attention_norm) + ss     llama.py:177, 282
+    rc = va_launch_gemv3(g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D), D, F,
+                         E3_RESID, false, s);
+    PROF_A(VAURA_K_W2);
+    if (rc) return rc;
+  }
+  if (!sample) return va_launch_advance(d->state, s);
+  PROF_B(VAURA_K_HEADS);   // logits = heads . rmsnorm(h)                               llama.py:503-504
+  rc = va_launch_gemv3(g3(d->heads, d->ws_h_split, d->ws_ss, nullptr, d->ws_logits, nullptr, nullptr, nullptr, d,
+                          m.n_codebooks * m.vocab), (int64_t)m.n_codebooks * m.vocab, D, E3_LOGITS, true, s);
+  PROF_A(VAURA_K_HEADS);
+  if (rc) return rc;
+  PROF_B(VAURA_K_SAMPLE);
+  rc = va_launch_sample(d->ws_logits, d->batch, m.n_codebooks, m.vocab, sp, d->noise, d->batch * m.n_codebooks, d->state, 0,
+                        nullptr, d->seq, d->timesteps, d->seq_len, d->state, s);
+  PROF_A(VAURA_K_SAMPLE);
+  return rc;
+}
+
+static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
+  if (d->wdtype == VAURA_W_BF16) return enqueue_step_bf16(d, sp, sample, s);
+  const vaura_dims& m = d->dims;
+  const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
+  const int rows = d->rows;
+  PROF_B(VAURA_K_EMBED);
   int rc = va_launch_embed(d, s);
+  PROF_A(VAURA_K_EMBED);
   if (rc) return rc;
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     // h -> qkv  (attention_norm fused)                                   llama.py:280, 228
+    PROF_B(VAURA_K_QKV);
     rc = va_launch_gemv(L.wqkv, d->wdtype, d->ws_h, L.attn_norm, nullptr, d->ws_qkv, rows, 3 * D, D, EPI_STORE, m.eps, s);
+    PROF_A(VAURA_K_QKV);
     if (rc) return rc;
     // rope + cache append + softmax(qK^T)V                               llama.py:234-257
-    rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, rows, H, hd,
-                             d->max_len, d->state, 0, s);
+    PROF_B(VAURA_K_ATTN);
+    rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, nullptr, rows,
+                             H, hd, d->max_len, d->state, 0, s);
+    PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     // h += wo . attn                                                      llama.py:259, 279
+    PROF_B(VAURA_K_WO);
     rc = va_launch_gemv(L.wo, d->wdtype, d->ws_attn, nullptr, d->ws_h, d->ws_h, rows, D, D, EPI_RESID, 0.f, s);
+    PROF_A(VAURA_K_WO);
     if (rc) return rc;
     // ffn = silu(w1 x) * (w3 x)  (ffn_norm fused)                        llama.py:282, 177
+    PROF_B(VAURA_K_W13);
     rc = va_launch_gemv(L.w13, d->wdtype, d->ws_h, L.ffn_norm, nullptr, d->ws_ffn, rows, 2 * F, D, EPI_SWIGLU, m.eps, s);
+    PROF_A(VAURA_K_W13);
     if (rc) return rc;
     // h += w2 . ffn                                                       llama.py:177, 282
+    PROF_B(VAURA_K_W2);
     rc = va_launch_gemv(L.w2, d->wdtype, d->ws_ffn, nullptr, d->ws_h, d->ws_h, rows, D, F, EPI_RESID, 0.f, s);
+    PROF_A(VAURA_K_W2);
     if (rc) return rc;
   }
   if (!sample) return va_launch_advance(d->state, s);
   // logits = heads . norm(h)                                              llama.py:503-504
+  PROF_B(VAURA_K_HEADS);
   rc = va_launch_gemv(d->heads, d->wdtype, d->ws_h, d->final_norm, nullptr, d->ws_logits, rows, (int64_t)m.n_codebooks * m.vocab, D,
                       EPI_LOGITS, m.eps, s);
+  PROF_A(VAURA_K_HEADS);
   if (rc) return rc;
-  return va_launch_sample(d->ws_logits, d->batch, m.n_codebooks, m.vocab, sp, d->noise, d->batch * m.n_codebooks, d->state, 0,
+  PROF_B(VAURA_K_SAMPLE);
+  rc = va_launch_sample(d->ws_logits, d->batch, m.n_codebooks, m.vocab, sp, d->noise, d->batch * m.n_codebooks, d->state, 0,
                           nullptr, d->seq, d->timesteps, d->seq_len, d->state, s);
+  PROF_A(VAURA_K_SAMPLE);
+  return rc;
 }
 
 static hipGraphExec_t g_step_exec = nullptr;
@@ -114,6 +210,33 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
     if (rc) return rc;
   }
   return 0;
+}
+
+int vaura_profile_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_steps, unsigned kind_mask,
+                       double* total_ms_host, int64_t* launches_host, vaura_stream_t s) {
+  int rc = check_decoder(dec);
+  if (rc) return rc;
+  if (!sp || n_steps <= 0 || !total_ms_host || !launches_host) return VAURA_ERR_ARG;
+  StepProfiler prof;
+  prof.mask = kind_mask;
+  g_prof = &prof;
+  hipStream_t st = as_stream(s);
+  for (int i = 0; i < n_steps && !rc; ++i) rc = enqueue_step(dec, sp, 1, st);
+  g_prof = nullptr;
+  hipError_t e = hipStreamSynchronize(st);
+  for (int k = 0; k < VAURA_K_COUNT; ++k) {
+    double tot = 0.0;
+    const size_t n = prof.ev[k].size() / 2;
+    for (size_t i = 0; i < n; ++i) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, prof.ev[k][2 * i], prof.ev[k][2 * i + 1]) == hipSuccess) tot += ms;
+    }
+    for (hipEvent_t ev : prof.ev[k]) (void)hipEventDestroy(ev);
+    total_ms_host[k] = tot;
+    launches_host[k] = (int64_t)n;
+  }
+  if (rc) return rc;
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 }  // extern "C"

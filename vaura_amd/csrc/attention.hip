@@ -10,6 +10,7 @@
 // then the same mapping accumulates P.V, reduced through shuffles + LDS.  The rotated key and the
 // value of the new position are appended to the cache by this kernel.
 #include "common.h"
+#include "gemv3_kernel.h"
 
 #define ATT_THREADS 256
 
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     float* __restrict__ kcache,      // (rows, H, max_len, HD)
     float* __restrict__ vcache,
     float* __restrict__ out,         // packed rows (rows x D)
+    uint16_t* __restrict__ outp,     // optional split rows (rows x D)
     int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
   constexpr int QUADS = HD / 4;          // 24
   constexpr int QPL = QUADS / 8;         // float4 per lane per position = 3
@@ -164,22 +166,22 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     for (int i = 1; i < 4; ++i) o += reinterpret_cast<const f32x4*>(red + i * HD)[tid];
     o += reinterpret_cast<const f32x4*>(sv)[tid] * (sc[pos] * inv);
     reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
+    if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
   }
 }
 
-int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, int rows, int n_head,
-                        int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s) {
+int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, uint16_t* outp, int rows,
+                        int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
-  hipLaunchKernelGGL(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, rope, kc, vc, out,
-                     n_head, max_len, pos_dev, pos_host);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, rope, kc, vc, out, outp,
+            n_head, max_len, pos_dev, pos_host);
   return 0;
 }
 
 extern "C" int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
                                     int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s) {
   if (pos < 0 || pos >= max_len) return VAURA_ERR_ARG;
-  return va_launch_attention(qkv, rope, kcache, vcache, out, rows, n_head, head_dim, max_len, nullptr, pos, as_stream(s));
+  return va_launch_attention(qkv, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos, as_stream(s));
 }

@@ -10,8 +10,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemv.hip", "attention.hip", "step.hip", "api.hip", "dac.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "vaura_hip.h")]
+SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac.hip"]
+HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", os.path.join("..", "..", "include", "vaura_hip.h")]
 LIB = os.path.join(HERE, "libvaura_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

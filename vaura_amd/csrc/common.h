@@ -12,6 +12,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     hipError_t e__ = hipGetLastError();        \
     if (e__ != hipSuccess) return (int)e__;    \
   } while (0)
+// launch + check; the sticky per-thread error is cleared first so that a stale error left by some
+// earlier, unrelated runtime call (observed: hipErrorNoDevice from a device probe) is not reported here
+#define VA_LAUNCH(...)                         \
+  do {                                         \
+    (void)hipGetLastError();                   \
+    hipLaunchKernelGGL(__VA_ARGS__);           \
+    VA_CHECK_LAUNCH();                         \
+  } while (0)
 
 // packed-rows index (see vaura_hip.h): float index of (row, col) in a (rows x C) matrix
 __host__ __device__ __forceinline__ size_t packed_index(int row, int col, int C) {
@@ -48,8 +56,10 @@ inline hipStream_t as_stream(vaura_stream_t s) { return (hipStream_t)s; }
 // ---- launchers implemented across the .hip files (host side, internal)
 int va_launch_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
                    int64_t rows, int64_t N, int64_t K, int epilogue, float eps, hipStream_t s);
-int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, int rows, int n_head,
-                        int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s);
+int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, uint16_t* outp, int rows,
+                        int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s);
+struct Gemv3Args;
+int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 int va_launch_embed(const vaura_decoder* d, hipStream_t s);
 int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,
                      int noise_rows_per_step, const int32_t* state, int64_t step_host, int32_t* tokens_out,

@@ -199,8 +199,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
     a.ostride = 1; a.oshift0 = 0; a.Lout = Lin; a.jcount = Lin;
   }
   dim3 grid((a.jcount + BM - 1) / BM, cv.cout / BN, B * phases);
-  hipLaunchKernelGGL(conv_mfma_kernel, grid, dim3(256), 0, s, a);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(conv_mfma_kernel, grid, dim3(256), 0, s, a);
   return 0;
 }
 
@@ -228,9 +227,8 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   hipStream_t s = as_stream(s_);
   float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
 
-  hipLaunchKernelGGL(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
+  VA_LAUNCH(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
                      c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim);
-  VA_CHECK_LAUNCH();
   // conv_in: only the activated output is consumed (by the first transposed conv)
   int rc = launch_conv(c->conv_in, Y, nullptr, c->alpha_up[0], nullptr, A, B, T, s);
   if (rc) return rc;
@@ -253,8 +251,7 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   }
   const int C = c->conv_out.cin;
   if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C);
   return 0;
 }
 

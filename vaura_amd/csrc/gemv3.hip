@@ -1,0 +1,68 @@
+// Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
+#include "gemv3_kernel.h"
+
+template <int G, int NW, int T, int EPI, bool NORM, int XB = 1>
+static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
+  if (n_tiles % T) return VAURA_ERR_SHAPE;
+  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB>), dim3((unsigned)(n_tiles / T)), dim3(NW * 64), 0, s, a);
+  return 0;
+}
+
+int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
+  if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
+  if (norm && (!a.ss_in || a.n_ss_in <= 0)) return VAURA_ERR_ARG;
+  const int64_t tiles = n_weight_rows / 16;
+  if (K == 1536) {
+    if (epilogue == E3_STORE && norm) return launch3<6, 8, 2, E3_STORE, true>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<6, 8, 1, E3_STORE, false>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<6, 8, 1, E3_RESID, false>(a, tiles, s);
+    if (epilogue == E3_SWIGLU && norm) return launch3<6, 8, 2, E3_SWIGLU, true>(a, tiles, s);
+    if (epilogue == E3_LOGITS && norm) return launch3<6, 8, 2, E3_LOGITS, true>(a, tiles, s);
+  } else if (K == 4096) {
+    if (epilogue == E3_RESID && !norm) return launch3<8, 16, 1, E3_RESID, false, 2>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<8, 16, 1, E3_STORE, false, 2>(a, tiles, s);
+  }
+  return VAURA_ERR_SHAPE;
+}
+
+// ---------------------------------------------------------------------------- op-level access
+// packed rows (rows x C) fp32 [* gain] -> split rows; optional per-16-column partial sums of squares
+__global__ void split_rows_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, const float* __restrict__ gain,
+                                  float* __restrict__ ss, int rows_p, int C) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one quad
+  if (gid >= (int64_t)rows_p * (C / 4)) return;
+  const int row = (int)(gid / (C / 4)), cq = (int)(gid % (C / 4));
+  f32x4 v = reinterpret_cast<const f32x4*>(src)[packed_quad(row, cq, C)];
+  if (ss) {
+    float s = ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((cq & 3) == 0) ss[((size_t)(row >> 4) * (C / 16) + (cq >> 2)) * 16 + (row & 15)] = s;
+  }
+  if (gain) v *= *reinterpret_cast<const f32x4*>(gain + cq * 4);
+  store_split4(dst, row, cq * 4, C, v);
+}
+
+extern "C" {
+
+int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* ss, int64_t rows, int64_t C, vaura_stream_t s) {
+  if (!src || !dst || rows <= 0 || C <= 0 || (C % 16)) return VAURA_ERR_ARG;
+  const int rows_p = (int)((rows + 15) / 16 * 16);
+  const int64_t total = (int64_t)rows_p * (C / 4);
+  VA_LAUNCH(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(s), src, dst, gain, ss, rows_p, (int)C);
+  return 0;
+}
+
+int vaura_gemv_bf16(const void* w, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+                    uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
+                    float eps, vaura_stream_t s) {
+  if (!w || !x_split || rows <= 0) return VAURA_ERR_ARG;
+  Gemv3Args a;
+  a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
+  a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
+  a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K;
+  if (epilogue == E3_RESID && !residual) return VAURA_ERR_ARG;
+  return va_launch_gemv3(a, N, K, epilogue, ss_in != nullptr, as_stream(s));
+}
+
+}  // extern "C"

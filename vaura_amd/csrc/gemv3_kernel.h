@@ -1,0 +1,238 @@
+// Weight-streaming skinny GEMM, bf16-stored weights, exact-fp32 semantics on the bf16 matrix cores.
+//
+// v_mfma_f32_16x16x4_f32 (gemv_kernel.h) is exact but runs at 1/16 of the bf16 MFMA rate: at 16 rows
+// its pipe time per decode GEMV is as long as the HBM stream it should hide under.  Here the fp32
+// activation is split ONCE, by the kernel that produces it, into three bf16 planes
+//        x = hi + mid + lo      hi = trunc_bf16(x), mid = trunc_bf16(x - hi), lo = x - hi - mid
+// which is exact (8 + 8 + 8 significand bits, residuals computed exactly in fp32), and the consumer
+// issues three v_mfma_f32_16x16x32_bf16 per 32-deep k-group: bf16 x bf16 products are exact in fp32,
+// each plane accumulates in its own fp32 accumulator (lo products never align against hi ones) and
+// the three are added once at the end.  Weights stored as bf16 ARE the MFMA A operand as loaded: no
+// VALU touches them.
+//
+// "split rows" layout of a (rows x C) activation:  [row_block][plane 0..2][C/8][16 rows][8] bf16
+//   -> one wave load = the B operand (16 rows x 32 k) of one plane, contiguous 1 KiB.
+// RMSNorm: the producer multiplies by the NEXT norm's gain before splitting and writes per-tile partial
+// sums of squares; the consumer adds the partials in a fixed order and applies rsqrt(mean+eps) in its
+// epilogue (W.(g*x*rinv) == rinv * W.(g*x)).
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+enum { E3_STORE = 0, E3_RESID = 1, E3_SWIGLU = 2, E3_LOGITS = 4 };
+
+struct Gemv3Args {
+  const void* W;          // bf16 MFMA tiles
+  const uint16_t* XP;     // split rows (rows x K)
+  const float* ss_in;     // NORM: (R, n_ss_in, 16) partial sums of squares of the raw input rows
+  int n_ss_in;
+  const float* res;       // E3_RESID: fp32 packed rows (rows x N)
+  float* out;             // fp32 packed rows (rows x N) / row-major logits; may be null for E3_SWIGLU
+  uint16_t* outp;         // optional split rows of (out * gain_out)
+  const float* gain_out;  // optional (N) gain applied before splitting (next RMSNorm)
+  float* ss_out;          // optional (R, N/16, 16) partial sums of squares of `out`
+  int rows, R, N;
+  float eps;
+  int k_total;            // K of the normalised vector (mean denominator)
+};
+
+__device__ __forceinline__ size_t split_index16(int rb, int plane, int octet, int row16, int C) {
+  // index in 16-byte units
+  return (((size_t)rb * 3 + (size_t)plane) * (size_t)(C >> 3) + (size_t)octet) * 16 + (size_t)row16;
+}
+
+// NB: take scalars by value — __builtin_bit_cast applied directly to an ext-vector ELEMENT expression
+// (v[i], u.y) reads element 0 for every index on hipcc 7.2.
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// exact 3-way split of 4 fp32 values -> three 8-byte bf16 quads
+__device__ __forceinline__ void split3(const f32x4 v, uint2& hi, uint2& mid, uint2& lo) {
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = v[i];
+    const uint32_t uh = f2u(x) & 0xffff0000u;
+    const float r1 = x - u2f(uh);
+    const uint32_t um = f2u(r1) & 0xffff0000u;
+    const float r2 = r1 - u2f(um);
+    h[i] = uh; m[i] = um; l[i] = f2u(r2);
+  }
+  hi = uint2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+  mid = uint2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+  lo = uint2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+}
+
+// store 4 consecutive columns (c0 % 4 == 0) of one row as three planes
+__device__ __forceinline__ void store_split4(uint16_t* base, int row, int c0, int C, const f32x4 v) {
+  uint2 hi, mid, lo;
+  split3(v, hi, mid, lo);
+  const int rb = row >> 4, m = row & 15, oct = c0 >> 3, half = (c0 >> 2) & 1;
+  uint2* p = reinterpret_cast<uint2*>(base);
+  p[split_index16(rb, 0, oct, m, C) * 2 + half] = hi;
+  p[split_index16(rb, 1, oct, m, C) * 2 + half] = mid;
+  p[split_index16(rb, 2, oct, m, C) * 2 + half] = lo;
+}
+
+__device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a)); }
+
+// XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
+// been consumed, for depths whose three planes do not fit the register budget at once)
+template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
+  constexpr int K = 32 * G * NW;
+  constexpr int KG = K / 32;
+  constexpr int GB = G / XB;
+  static_assert(G % XB == 0, "x batches must divide the groups");
+  __shared__ f32x4 red[NW][T][64];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  // de-phase the k-slices across workgroups: every workgroup reads the SAME activation planes, and with
+  // identical slice order all CUs of an XCD hit the same L2 channel at the same time
+  const int w = (ABL & 8) ? wid : (int)((wid + blockIdx.x) % NW);
+  const int m = lane & 15;
+  const int q = lane >> 4;
+  const int tile0 = blockIdx.x * T;
+  const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
+
+  auto row_block = [&](const int rb, const bool first) {
+    const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
+    u32x4 xb[GB][3];
+    u32x4 wb[T][G];
+    auto load_x = [&](int b) {
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
+                               : Xp[split_index16(rb, p, (w * G + b * GB + g) * 4 + q, m, K)];
+    };
+    if constexpr (ABL & 16) {
+      // activation planes first, as their own phase: L2 hits queued behind HBM misses in the CU's
+      // memory pipe return at HBM latency (head-of-line), so the two streams are kept apart
+      load_x(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+          wb[t][g] = __builtin_nontemporal_load(Wp + kg * 64 + lane);
+        }
+    } else {
+    // interleave the issue so that k-group g is complete once W[g] and x[g] have landed
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g < GB) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+        wb[t][g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
+      }
+    }
+    }
+    // rinv inputs (wave 0 only; issued early)
+    float ssp = 0.f;
+    if constexpr (NORM) {
+      if (wid == 0) {
+        const float* sp = a.ss_in + (size_t)rb * a.n_ss_in * 16;
+        for (int i = q; i < a.n_ss_in; i += 4) ssp += sp[i * 16 + m];
+      }
+    }
+
+    f32x4 acc[T][3];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int b = 0; b < XB; ++b) {
+      if (b > 0) load_x(b);
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const bf16x8 wf = __builtin_bit_cast(bf16x8, wb[t][b * GB + g]);
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            if constexpr (ABL & 1) {
+              asm volatile("" ::"v"(wb[t][b * GB + g]), "v"(xb[g][p]));
+            } else {
+              acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xb[g][p]), acc[t][p], 0, 0, 0);
+            }
+          }
+        }
+        if (first) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[wid][t][lane] = (acc[t][2] + acc[t][1]) + acc[t][0];
+    __syncthreads();
+    if (wid == 0) {
+      float rinv = 1.f;
+      if constexpr (NORM) {
+        ssp += __shfl_xor(ssp, 16, 64);
+        ssp += __shfl_xor(ssp, 32, 64);
+        rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+      }
+      f32x4 v[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f32x4 sacc = red[0][t][lane];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) sacc += red[i][t][lane];
+        v[t] = sacc * rinv;
+      }
+      const int row = rb * 16 + m;
+      if constexpr (EPI == E3_SWIGLU) {
+        static_assert(T == 2 || EPI != E3_SWIGLU, "SwiGLU needs a (w1, w3) tile pair");
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[0][r]) * v[T - 1][r];
+        const int tile = blockIdx.x;
+        if (a.out) reinterpret_cast<f32x4*>(a.out)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane] = o;
+        if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
+      } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int tile = tile0 + t;
+          const int c0 = tile * 16 + 4 * q;
+          if constexpr (EPI == E3_LOGITS) {
+            if (row < a.rows) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + c0) = v[t];
+          } else {
+            const size_t idx = ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane;
+            f32x4 o = v[t];
+            if constexpr (EPI == E3_RESID) o += reinterpret_cast<const f32x4*>(a.res)[idx];
+            if (a.out) reinterpret_cast<f32x4*>(a.out)[idx] = o;
+            if (a.ss_out) {
+              float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
+              s += __shfl_xor(s, 16, 64);
+              s += __shfl_xor(s, 32, 64);
+              if (q == 0) a.ss_out[((size_t)rb * (a.N / 16) + tile) * 16 + m] = s;
+            }
+            if (a.outp) {
+              f32x4 u = o;
+              if (a.gain_out) u *= *reinterpret_cast<const f32x4*>(a.gain_out + c0);
+              store_split4(a.outp, row, c0, a.N, u);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  row_block(0, true);
+  for (int rb = 1; rb < a.R; ++rb) {
+    __syncthreads();
+    row_block(rb, false);
+  }
+}

@@ -5,58 +5,83 @@
 //   sample   models/vaura_model.py:807-825, 536-544; utils/utils.py:139-196
 //   pattern  models/modules/misc/codebook_patterns.py:137-285, 390-406 (delayed pattern, closed form)
 #include "common.h"
+#include "gemv3_kernel.h"
 
 // ------------------------------------------------------------------------------------ embed
-// h0[row] = [ cond(row, pos // tpf) | sum_k ( W_k . emb_k[tok(row % B, k, pos)] + b_k ) ]  -> packed rows
-__global__ __launch_bounds__(256) void embed_kernel(
+// Token projection table, built once per weight set with the arithmetic of the reference's
+// DacEmbeddingProjection (llama.py:70-73): table[k][tok][c] = sum_i W_k[c][i] * emb_k[tok][i] + b_k[c]
+__global__ void token_table_kernel(const float* __restrict__ tok_emb, const float* __restrict__ proj_w,
+                                   const float* __restrict__ proj_b, float* __restrict__ table, int K, int vocab1,
+                                   int cdim, int tok_dim) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)K * vocab1 * tok_dim;
+  if (i >= total) return;
+  const int c = (int)(i % tok_dim);
+  const int tok = (int)((i / tok_dim) % vocab1);
+  const int k = (int)(i / ((int64_t)tok_dim * vocab1));
+  const float* e = tok_emb + ((size_t)k * vocab1 + tok) * cdim;
+  const float* wr = proj_w + ((size_t)k * tok_dim + c) * cdim;
+  float z = 0.f;
+  for (int j = 0; j < cdim; ++j) z = fmaf(wr[j], e[j], z);
+  table[i] = z + proj_b[(size_t)k * tok_dim + c];
+}
+
+// h0[row] = [ cond(row, pos // tpf) | sum_k table_k[tok(row % B, k, pos)] ]  -> packed rows (+ split rows
+// of h0 * gain and per-16-column partial sums of squares for the first fused RMSNorm)
+__global__ __launch_bounds__(64) void embed_kernel(
     const int32_t* __restrict__ seq, const int32_t* __restrict__ state, const float* __restrict__ cond_proj,
-    const float* __restrict__ empty_video, const float* __restrict__ tok_emb, const float* __restrict__ proj_w,
-    const float* __restrict__ proj_b, float* __restrict__ h, int B, int K, int S, int Tv, int tpf, int vocab1,
-    int cdim, int cond_dim, int tok_dim) {
-  __shared__ float e[16][8];  // K <= 16 codebooks, codebook_dim <= 8
+    const float* __restrict__ empty_video, const float* __restrict__ table, float* __restrict__ h,
+    uint16_t* __restrict__ hsplit, const float* __restrict__ gain, float* __restrict__ ss, int B, int K, int S, int Tv,
+    int tpf, int vocab1, int cond_dim, int tok_dim) {
   const int row = blockIdx.x;
+  const int cq = blockIdx.y * 64 + threadIdx.x;   // 4-column quad
   const int b = row % B;
   const int pos = state[0];
   const int D = cond_dim + tok_dim;
-  if (threadIdx.x < K * cdim) {
-    const int k = threadIdx.x / cdim, i = threadIdx.x % cdim;
-    const int tok = seq[((size_t)b * K + k) * S + pos];
-    e[k][i] = tok_emb[((size_t)k * vocab1 + tok) * cdim + i];
-  }
-  __syncthreads();
   const int frame = pos / tpf;
-  for (int cq = threadIdx.x; cq < D / 4; cq += blockDim.x) {
-    f32x4 o;
-    if (cq < cond_dim / 4) {
-      if (frame < Tv)
-        o = reinterpret_cast<const f32x4*>(cond_proj)[packed_quad(row * Tv + frame, cq, cond_dim)];
-      else
-        o = reinterpret_cast<const f32x4*>(empty_video)[cq];
-    } else {
-      const int c0 = (cq - cond_dim / 4) * 4;
-      o = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < K; ++k) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float* wr = proj_w + ((size_t)k * tok_dim + c0 + j) * cdim;
-          float z = 0.f;
-          for (int i = 0; i < cdim; ++i) z = fmaf(wr[i], e[k][i], z);
-          z += proj_b[(size_t)k * tok_dim + c0 + j];
-          o[j] += z;
-        }
-      }
+  f32x4 o;
+  if (cq < cond_dim / 4) {
+    if (frame < Tv)
+      o = reinterpret_cast<const f32x4*>(cond_proj)[packed_quad(row * Tv + frame, cq, cond_dim)];
+    else
+      o = reinterpret_cast<const f32x4*>(empty_video)[cq];
+  } else {
+    const int c0 = (cq - cond_dim / 4) * 4;
+    o = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {   // same left-to-right order as the reference's sum([...]) (llama.py:455-460)
+      const int tok = seq[((size_t)b * K + k) * S + pos];
+      o += *reinterpret_cast<const f32x4*>(table + ((size_t)k * vocab1 + tok) * tok_dim + c0);
     }
-    reinterpret_cast<f32x4*>(h)[packed_quad(row, cq, D)] = o;
+  }
+  reinterpret_cast<f32x4*>(h)[packed_quad(row, cq, D)] = o;
+  if (hsplit) {
+    float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((threadIdx.x & 3) == 0) ss[((size_t)(row >> 4) * (D / 16) + (cq >> 2)) * 16 + (row & 15)] = s;
+    const f32x4 u = o * *reinterpret_cast<const f32x4*>(gain + cq * 4);
+    store_split4(hsplit, row, cq * 4, D, u);
   }
 }
 
 int va_launch_embed(const vaura_decoder* d, hipStream_t s) {
   const vaura_dims& m = d->dims;
-  if (m.n_codebooks > 16 || m.codebook_dim > 8 || m.n_codebooks * m.codebook_dim > 256) return VAURA_ERR_SHAPE;
-  hipLaunchKernelGGL(embed_kernel, dim3(d->rows), dim3(256), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
-                     d->tok_emb, d->tok_proj_w, d->tok_proj_b, d->ws_h, d->batch, m.n_codebooks, d->seq_len,
-                     d->n_cond_tokens, m.tokens_per_frame, m.vocab + 1, m.codebook_dim, m.cond_dim, m.tok_dim);
-  VA_CHECK_LAUNCH();
+  const int D = m.cond_dim + m.tok_dim;
+  if (!d->tok_table || (D % 256)) return VAURA_ERR_SHAPE;
+  const bool split = d->wdtype == VAURA_W_BF16;
+  if (split && (!d->ws_h_split || !d->ws_ss || !d->first_norm)) return VAURA_ERR_ARG;
+  VA_LAUNCH(embed_kernel, dim3(d->rows, D / 256), dim3(64), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
+            d->tok_table, d->ws_h, split ? d->ws_h_split : nullptr, d->first_norm, d->ws_ss, d->batch, m.n_codebooks,
+            d->seq_len, d->n_cond_tokens, m.tokens_per_frame, m.vocab + 1, m.cond_dim, m.tok_dim);
+  return 0;
+}
+
+extern "C" int vaura_build_token_table(const float* tok_emb, const float* proj_w, const float* proj_b, float* table, int K,
+                                       int vocab1, int cdim, int tok_dim, vaura_stream_t s) {
+  if (!tok_emb || !proj_w || !proj_b || !table || K <= 0) return VAURA_ERR_ARG;
+  const int64_t total = (int64_t)K * vocab1 * tok_dim;
+  VA_LAUNCH(token_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(s), tok_emb, proj_w, proj_b,
+            table, K, vocab1, cdim, tok_dim);
   return 0;
 }
 
@@ -291,8 +316,7 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
   a.B = B; a.K = K; a.V = vocab; a.T = T; a.S = S;
   a.use_sampling = sp->use_sampling; a.top_k = sp->top_k; a.temp = sp->temp; a.top_p = sp->top_p;
   a.cfg_scale = sp->cfg_scale; a.seed = sp->seed; a.clip_base = sp->clip_base; a.step_host = step_host;
-  hipLaunchKernelGGL(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a);
   return 0;
 }
 
@@ -300,8 +324,7 @@ __global__ void advance_kernel(int32_t* state) {
   if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1;
 }
 int va_launch_advance(int32_t* state, hipStream_t s) {
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, s, state);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(advance_kernel, dim3(1), dim3(64), 0, s, state);
   return 0;
 }
 
@@ -330,16 +353,14 @@ extern "C" {
 int vaura_pattern_build(const int32_t* codes, int32_t* seq, int B, int K, int T, int special, vaura_stream_t s) {
   if (!codes || !seq || B <= 0 || K <= 0 || T <= 0) return VAURA_ERR_ARG;
   const int64_t n = (int64_t)B * K * (T + K);
-  hipLaunchKernelGGL(pattern_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), codes, seq, B, K, T, special);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(pattern_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), codes, seq, B, K, T, special);
   return 0;
 }
 
 int vaura_pattern_revert(const int32_t* seq, int32_t* codes, int B, int K, int T, int S, int fill, vaura_stream_t s) {
   if (!codes || !seq || B <= 0 || K <= 0 || T <= 0 || S <= 0) return VAURA_ERR_ARG;
   const int64_t n = (int64_t)B * K * T;
-  hipLaunchKernelGGL(pattern_revert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), seq, codes, B, K, T, S, fill);
-  VA_CHECK_LAUNCH();
+  VA_LAUNCH(pattern_revert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s), seq, codes, B, K, T, S, fill);
   return 0;
 }
 

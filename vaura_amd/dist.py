@@ -1,0 +1,67 @@
+"""Batch-parallel sharding of independent clips over the GPUs of one node.
+
+The reference has no inference-time parallelism (single device, sequential batches:
+configs/generate_vgg.yaml:18, scripts/generate.py:264).  Clips are independent
+(SURVEY.md §8e), so each rank owns a contiguous slice of the global batch, keeps a full weight
+replica, and the only exchange is ONE all_gather of the results at the end (tokens and
+waveform).  Sampling noise is keyed by global clip index (``clip_base``) so the result does
+not depend on the world size.  No collective sits on the data path.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str = "nccl") -> Tuple[int, int, int]:
+    rank, local, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of `total` clips: returns (first_clip, count) of `rank`; remainders go to
+    the lowest ranks."""
+    base, rem = divmod(total, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def gather_clips(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
+    """All-gather per-rank results (clip dim 0, possibly ragged) into global clip order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    mx = max(counts)
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad.contiguous())
+    return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -71,6 +71,11 @@ class DecoderEngine:
                 fold_weight_norm(sd[f"tok_embeddings.{k}.out_proj.weight_g"].float(),
                                  sd[f"tok_embeddings.{k}.out_proj.weight_v"].float())[:, :, 0] for k in range(K)]))
             self.tok_b = self._dev(torch.stack([sd[f"tok_embeddings.{k}.out_proj.bias"].float() for k in range(K)]))
+            self.tok_table = torch.empty(K, cfg.d_codebook + 1, cfg.tok_dim, dtype=torch.float32, device=self.dev)
+            self._keep.append(self.tok_table)
+            L.check(self.lib.vaura_build_token_table(L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b),
+                                                     L.ptr(self.tok_table), K, cfg.d_codebook + 1, cfg.codebook_dim,
+                                                     cfg.tok_dim, L.current_stream()), "vaura_build_token_table")
             torch.cuda.synchronize(self.dev)
         self.dims = L.Dims(cfg.num_layers, D, cfg.nhead, F, K, cfg.d_codebook, cfg.cond_dim, cfg.tok_dim, cfg.cond_in,
                            cfg.codebook_dim, 7, cfg.layer_norm_eps)
@@ -122,6 +127,11 @@ class DecoderEngine:
             self.ws_attn = torch.zeros(rp * c.d_model, **f32)
             self.ws_ffn = torch.zeros(rp * c.ffn_dim, **f32)
             self.ws_logits = torch.zeros(rows, K * c.d_codebook, **f32)
+            i16 = dict(dtype=torch.int16, device=self.dev)
+            self.ws_h_split = torch.zeros(rp * 3 * c.d_model, **i16)
+            self.ws_attn_split = torch.zeros(rp * 3 * c.d_model, **i16)
+            self.ws_ffn_split = torch.zeros(rp * 3 * c.ffn_dim, **i16)
+            self.ws_ss = torch.zeros((rp // 16) * (c.d_model // 16) * 16, **f32)
             crp = self._rows_padded(rows * n_cond_tokens)
             self.cond_in = torch.zeros(crp * c.cond_in, **f32)
             self.cond_tmp = torch.zeros(crp * c.cond_dim, **f32)
@@ -135,11 +145,15 @@ class DecoderEngine:
         d.layers_host = C.cast(self.layers, C.POINTER(L.LayerWeights))
         d.heads, d.final_norm = L.ptr(self.heads), L.ptr(self.final_norm)
         d.tok_emb, d.tok_proj_w, d.tok_proj_b = L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b)
+        d.tok_table = L.ptr(self.tok_table)
         d.empty_video, d.rope, d.cond_proj = L.ptr(self.empty_video), L.ptr(self.rope), L.ptr(self.cond_proj)
         d.kcache, d.vcache, d.seq, d.state = L.ptr(self.kcache), L.ptr(self.vcache), L.ptr(self.seq), L.ptr(self.state)
         d.noise = 0
         d.ws_h, d.ws_qkv, d.ws_attn = L.ptr(self.ws_h), L.ptr(self.ws_qkv), L.ptr(self.ws_attn)
         d.ws_ffn, d.ws_logits = L.ptr(self.ws_ffn), L.ptr(self.ws_logits)
+        d.ws_h_split, d.ws_attn_split = L.ptr(self.ws_h_split), L.ptr(self.ws_attn_split)
+        d.ws_ffn_split, d.ws_ss = L.ptr(self.ws_ffn_split), L.ptr(self.ws_ss)
+        d.first_norm = self.layers[0].attn_norm
         self.dec = d
         self._shape = key
         self._graph_key = None
