@@ -3,6 +3,7 @@
 // Each timed launch streams a DIFFERENT weight set (cycling through > 256 MiB) so the Infinity Cache
 // cannot serve it, like the real decode step where every matrix is read once per step.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 #include "gemv_kernel.h"
@@ -32,7 +33,7 @@ struct Case { const char* name; double bytes; };
 // time per launch inside a replayed hipGraph of `nsets` back-to-back launches (how the product runs them)
 static hipStream_t g_stream;
 template <typename F>
-static double time_launches(F&& launch, int nsets, int iters) {
+static double time_launches_impl(F&& launch, int nsets, int iters) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   hipGraph_t graph; hipGraphExec_t exec;
@@ -53,7 +54,12 @@ static double time_launches(F&& launch, int nsets, int iters) {
   return 1e3 * ms / (reps * nsets);  // us per launch
 }
 
-int main() {
+static const char* g_filter = nullptr;
+static const char* g_current = "";
+#define REPORT(name, us, bytes) do { g_current = name; report(name, us, bytes); } while (0)
+#define time_launches(...) (g_filter && !strstr(g_current, g_filter) ? -1.0 : time_launches_impl(__VA_ARGS__))
+int main(int argc, char** argv) {
+  if (argc > 1) g_filter = argv[1];
   const int rows = 16;
   CK(hipStreamCreate(&g_stream));
   const int NSETS = 24;
@@ -78,68 +84,69 @@ int main() {
     return a;
   };
   auto report = [&](const char* what, double us, double bytes) {
+    if (us < 0) return;
     printf("%-44s %8.2f us  %7.2f TB/s\n", what, us, bytes / us * 1e-6);
   };
 
   // ---- floor: pure streaming with the GEMV's own access pattern
   {
     double b = 8192.0 * 1536 * 2;
-    report("stream w13 G6 NW8 T2 nt (256 WG x 512)", time_launches([&](int s) {
+    REPORT("stream w13 G6 NW8 T2 nt (256 WG x 512)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<6, 8, 2, true>), dim3(256), dim3(512), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b);
-    report("stream w13 G6 NW8 T2 plain", time_launches([&](int s) {
+    REPORT("stream w13 G6 NW8 T2 plain", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<6, 8, 2, false>), dim3(256), dim3(512), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b);
-    report("stream w13 G6 NW8 T1 nt (512 WG x 512)", time_launches([&](int s) {
+    REPORT("stream w13 G6 NW8 T1 nt (512 WG x 512)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<6, 8, 1, true>), dim3(512), dim3(512), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b);
-    report("stream w13 G12 NW4 T1 nt (512 WG x 256)", time_launches([&](int s) {
+    REPORT("stream w13 G12 NW4 T1 nt (512 WG x 256)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<12, 4, 1, true>), dim3(512), dim3(256), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b);
-    report("stream w13 G3 NW16 T1 nt (512 WG x 1024)", time_launches([&](int s) {
+    REPORT("stream w13 G3 NW16 T1 nt (512 WG x 1024)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<3, 16, 1, true>), dim3(512), dim3(1024), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b);
-    report("stream w13 G3 NW16 T4 nt (128 WG x 1024)", time_launches([&](int s) {
+    REPORT("stream w13 G3 NW16 T4 nt (128 WG x 1024)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<3, 16, 4, true>), dim3(128), dim3(1024), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b);
     double bq = 4608.0 * 1536 * 2;
-    report("stream qkv G6 NW8 T1 nt (288 WG x 512)", time_launches([&](int s) {
+    REPORT("stream qkv G6 NW8 T1 nt (288 WG x 512)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<6, 8, 1, true>), dim3(288), dim3(512), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), bq);
     double bo = 1536.0 * 1536 * 2;
-    report("stream wo G6 NW8 T1 nt (96 WG x 512)", time_launches([&](int s) {
+    REPORT("stream wo G6 NW8 T1 nt (96 WG x 512)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<6, 8, 1, true>), dim3(96), dim3(512), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), bo);
-    report("stream wo G3 NW16 T1 nt (96 WG x 1024)", time_launches([&](int s) {
+    REPORT("stream wo G3 NW16 T1 nt (96 WG x 1024)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<3, 16, 1, true>), dim3(96), dim3(1024), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), bo);
     double b2 = 1536.0 * 4096 * 2;
-    report("stream w2 G16 NW8 T1 nt (96 WG x 512)", time_launches([&](int s) {
+    REPORT("stream w2 G16 NW8 T1 nt (96 WG x 512)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<16, 8, 1, true>), dim3(96), dim3(512), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b2);
-    report("stream w2 G8 NW16 T1 nt (96 WG x 1024)", time_launches([&](int s) {
+    REPORT("stream w2 G8 NW16 T1 nt (96 WG x 1024)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<8, 16, 1, true>), dim3(96), dim3(1024), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), b2);
-    report("empty-ish launch (1 WG)", time_launches([&](int s) {
+    REPORT("empty-ish launch (1 WG)", time_launches([&](int s) {
       hipLaunchKernelGGL((stream_only<1, 1, 1, true>), dim3(1), dim3(64), 0, g_stream, (const u32x4*)(Wbuf + (size_t)s * maxW), out); }, NSETS, iters), 1.0);
   }
   // ---- the real kernels
-  report("gemv qkv  <6,8,1,STORE,norm>", time_launches([&](int s) {
+  REPORT("gemv qkv  <6,8,1,STORE,norm>", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, true>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv ablate: no MFMA", time_launches([&](int s) {
+  REPORT("  qkv ablate: no MFMA", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, true, 1>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv ablate: no x loads", time_launches([&](int s) {
+  REPORT("  qkv ablate: no x loads", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, true, 2>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv ablate: no MFMA, no x", time_launches([&](int s) {
+  REPORT("  qkv ablate: no MFMA, no x", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, true, 3>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv ablate: no W loads", time_launches([&](int s) {
+  REPORT("  qkv ablate: no W loads", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, true, 4>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv ablate: no W, no x (MFMA only)", time_launches([&](int s) {
+  REPORT("  qkv ablate: no W, no x (MFMA only)", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, true, 6>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv no-norm", time_launches([&](int s) {
+  REPORT("  qkv no-norm", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_STORE, false>), dim3(288), dim3(512), 0, g_stream, args(s, 4608, 1536, false, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv <12,4,1> (256 thr)", time_launches([&](int s) {
+  REPORT("  qkv <12,4,1> (256 thr)", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 12, 4, 1, EPI_STORE, true>), dim3(288), dim3(256), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv <3,16,1> (1024 thr)", time_launches([&](int s) {
+  REPORT("  qkv <3,16,1> (1024 thr)", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 3, 16, 1, EPI_STORE, true>), dim3(288), dim3(1024), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("  qkv <6,8,2> (144 WG)", time_launches([&](int s) {
+  REPORT("  qkv <6,8,2> (144 WG)", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 2, EPI_STORE, true>), dim3(144), dim3(512), 0, g_stream, args(s, 4608, 1536, true, false)); }, NSETS, iters), 4608.0 * 1536 * 2);
-  report("gemv wo   <6,8,1,RESID>", time_launches([&](int s) {
+  REPORT("gemv wo   <6,8,1,RESID>", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 1, EPI_RESID, false>), dim3(96), dim3(512), 0, g_stream, args(s, 1536, 1536, false, true)); }, NSETS, iters), 1536.0 * 1536 * 2);
-  report("gemv w13  <6,8,2,SWIGLU,norm>", time_launches([&](int s) {
+  REPORT("gemv w13  <6,8,2,SWIGLU,norm>", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 2, EPI_SWIGLU, true>), dim3(256), dim3(512), 0, g_stream, args(s, 4096, 1536, true, false)); }, NSETS, iters), 8192.0 * 1536 * 2);
-  report("gemv w2   <16,8,1,RESID>", time_launches([&](int s) {
+  REPORT("gemv w2   <16,8,1,RESID>", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 16, 8, 1, EPI_RESID, false>), dim3(96), dim3(512), 0, g_stream, args(s, 1536, 4096, false, true)); }, NSETS, iters), 1536.0 * 4096 * 2);
-  report("gemv heads<6,8,2,LOGITS,norm>", time_launches([&](int s) {
+  REPORT("gemv heads<6,8,2,LOGITS,norm>", time_launches([&](int s) {
     hipLaunchKernelGGL((gemv_kernel<true, 6, 8, 2, EPI_LOGITS, true>), dim3(288), dim3(512), 0, g_stream, args(s, 9216, 1536, true, false)); }, NSETS, iters), 9216.0 * 1536 * 2);
   // ---- bf16-MFMA kernels on split rows
   uint16_t* xs; float* ssb; uint16_t* osp;
@@ -154,7 +161,7 @@ int main() {
     return a;
   };
 #define G3(name, G, NW, T, EPI, NORM, XB, ABL, grid, N, resid, split, bytes) \
-  report(name, time_launches([&](int s) { hipLaunchKernelGGL((gemv3_kernel<G, NW, T, EPI, NORM, XB, ABL>), dim3(grid), dim3(NW * 64), 0, g_stream, a3(s, N, NORM, resid, split)); }, NSETS, iters), bytes)
+  REPORT(name, time_launches([&](int s) { hipLaunchKernelGGL((gemv3_kernel<G, NW, T, EPI, NORM, XB, ABL>), dim3(grid), dim3(NW * 64), 0, g_stream, a3(s, N, NORM, resid, split)); }, NSETS, iters), bytes)
   const double bq = 4608.0 * 1536 * 2, bo = 1536.0 * 1536 * 2, b13 = 8192.0 * 1536 * 2, b2 = 1536.0 * 4096 * 2, bh = 9216.0 * 1536 * 2;
   G3("g3 qkv <6,8,1> norm", 6, 8, 1, E3_STORE, true, 1, 0, 288, 4608, false, false, bq);
   G3("   qkv same-phase slices (old)", 6, 8, 1, E3_STORE, true, 1, 8, 288, 4608, false, false, bq);
@@ -181,5 +188,22 @@ int main() {
   G3("   w2  ablate no x", 8, 16, 1, E3_RESID, false, 2, 2, 96, 1536, true, true, b2);
   G3("g3 heads <6,8,2>", 6, 8, 2, E3_LOGITS, true, 1, 0, 288, 9216, false, false, bh);
   G3("   heads <3,16,2>", 3, 16, 2, E3_LOGITS, true, 1, 0, 288, 9216, false, false, bh);
+  // ---- tile-count sweep after the rinv fix
+  G3("sw qkv <6,8,2> 144", 6, 8, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
+  G3("sw qkv <6,8,3> 96", 6, 8, 3, E3_STORE, true, 1, 0, 96, 4608, false, false, bq);
+  G3("sw qkv <12,4,2> 144", 12, 4, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
+  G3("sw qkv <3,16,2> 144", 3, 16, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
+  G3("sw w13 <6,8,4> 128", 6, 8, 4, E3_SWIGLU, true, 1, 0, 128, 4096, false, true, b13);
+  G3("sw w13 <3,16,2> 256", 3, 16, 2, E3_SWIGLU, true, 1, 0, 256, 4096, false, true, b13);
+  G3("sw w13 <3,16,4> 128", 3, 16, 4, E3_SWIGLU, true, 1, 0, 128, 4096, false, true, b13);
+  G3("sw heads <6,8,4> 144", 6, 8, 4, E3_LOGITS, true, 1, 0, 144, 9216, false, false, bh);
+  G3("sw heads <6,8,3> 192", 6, 8, 3, E3_LOGITS, true, 1, 0, 192, 9216, false, false, bh);
+  G3("sw heads <3,16,4> 144", 3, 16, 4, E3_LOGITS, true, 1, 0, 144, 9216, false, false, bh);
+  G3("sw wo <12,4,1> 96x256", 12, 4, 1, E3_RESID, false, 1, 0, 96, 1536, true, true, bo);
+  G3("sw wo <3,16,1> 96x1024", 3, 16, 1, E3_RESID, false, 1, 0, 96, 1536, true, true, bo);
+  G3("sw w2 <8,16,1> xb4 96", 8, 16, 1, E3_RESID, false, 4, 0, 96, 1536, true, true, b2);
+  G3("sw w2 <8,16,1> xb1 96", 8, 16, 1, E3_RESID, false, 1, 0, 96, 1536, true, true, b2);
+  G3("sw w2 <16,8,1> xb2 96x512", 16, 8, 1, E3_RESID, false, 2, 0, 96, 1536, true, true, b2);
+  G3("sw w2 <16,8,1> xb4 96x512", 16, 8, 1, E3_RESID, false, 4, 0, 96, 1536, true, true, b2);
   return 0;
 }

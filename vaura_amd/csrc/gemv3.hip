@@ -10,17 +10,17 @@ static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
 
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
-  if (norm && (!a.ss_in || a.n_ss_in <= 0)) return VAURA_ERR_ARG;
+  if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
   const int64_t tiles = n_weight_rows / 16;
   if (K == 1536) {
     if (epilogue == E3_STORE && norm) return launch3<6, 8, 2, E3_STORE, true>(a, tiles, s);
     if (epilogue == E3_STORE && !norm) return launch3<6, 8, 1, E3_STORE, false>(a, tiles, s);
     if (epilogue == E3_RESID && !norm) return launch3<6, 8, 1, E3_RESID, false>(a, tiles, s);
     if (epilogue == E3_SWIGLU && norm) return launch3<6, 8, 2, E3_SWIGLU, true>(a, tiles, s);
-    if (epilogue == E3_LOGITS && norm) return launch3<6, 8, 2, E3_LOGITS, true>(a, tiles, s);
+    if (epilogue == E3_LOGITS && norm) return launch3<6, 8, 3, E3_LOGITS, true>(a, tiles, s);
   } else if (K == 4096) {
-    if (epilogue == E3_RESID && !norm) return launch3<8, 16, 1, E3_RESID, false, 2>(a, tiles, s);
-    if (epilogue == E3_STORE && !norm) return launch3<8, 16, 1, E3_STORE, false, 2>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<16, 8, 1, E3_RESID, false, 4>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<16, 8, 1, E3_STORE, false, 4>(a, tiles, s);
   }
   return VAURA_ERR_SHAPE;
 }

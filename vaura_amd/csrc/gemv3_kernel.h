@@ -86,6 +86,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   constexpr int GB = G / XB;
   static_assert(G % XB == 0, "x batches must divide the groups");
   __shared__ f32x4 red[NW][T][64];
+  constexpr int SSL = NORM ? 2048 : 4;   // n_ss_in * 16 <= 2048 floats
+  __shared__ float ssl[SSL];
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -134,16 +136,23 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
-        wb[t][g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
+        if constexpr (ABL & 32) wb[t][g] = Wp[kg * 64 + lane];
+        else if constexpr (ABL & 64) wb[t][g] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, 0x7fffffff, 0x00020000), (uint32_t)((kg * 64 + lane) * 16), 0, 2 | 16);
+        else if constexpr (ABL & 128) wb[t][g] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, 0x7fffffff, 0x00020000), (uint32_t)((kg * 64 + lane) * 16), 0, 16);
+        else wb[t][g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
       }
     }
     }
-    // rinv inputs (wave 0 only; issued early)
-    float ssp = 0.f;
+    // rinv inputs: the producer's per-tile partial sums of squares, fetched by the whole workgroup in one
+    // go and parked in LDS (a load->add loop in one wave pays an L2 round trip per partial: 2.4 us)
+    constexpr int SSN = NORM ? 2048 / (NW * 64) : 1;
+    float ssr[SSN];
     if constexpr (NORM) {
-      if (wid == 0) {
-        const float* sp = a.ss_in + (size_t)rb * a.n_ss_in * 16;
-        for (int i = q; i < a.n_ss_in; i += 4) ssp += sp[i * 16 + m];
+      const float* sp = a.ss_in + (size_t)rb * a.n_ss_in * 16;
+#pragma unroll
+      for (int j = 0; j < SSN; ++j) {
+        const int i = threadIdx.x + j * NW * 64;
+        ssr[j] = (i < a.n_ss_in * 16) ? sp[i] : 0.f;
       }
     }
 
@@ -176,10 +185,19 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 
 #pragma unroll
     for (int t = 0; t < T; ++t) red[wid][t][lane] = (acc[t][2] + acc[t][1]) + acc[t][0];
+    if constexpr (NORM) {
+#pragma unroll
+      for (int j = 0; j < SSN; ++j) {
+        const int i = threadIdx.x + j * NW * 64;
+        if (i < SSL) ssl[i] = ssr[j];
+      }
+    }
     __syncthreads();
     if (wid == 0) {
       float rinv = 1.f;
       if constexpr (NORM) {
+        float ssp = 0.f;
+        for (int i = q; i < a.n_ss_in; i += 4) ssp += ssl[i * 16 + m];
         ssp += __shfl_xor(ssp, 16, 64);
         ssp += __shfl_xor(ssp, 32, 64);
         rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
@@ -194,13 +212,16 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
       }
       const int row = rb * 16 + m;
       if constexpr (EPI == E3_SWIGLU) {
-        static_assert(T == 2 || EPI != E3_SWIGLU, "SwiGLU needs a (w1, w3) tile pair");
-        f32x4 o;
+        static_assert(T % 2 == 0 || EPI != E3_SWIGLU, "SwiGLU needs (w1, w3) tile pairs");
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[0][r]) * v[T - 1][r];
-        const int tile = blockIdx.x;
-        if (a.out) reinterpret_cast<f32x4*>(a.out)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane] = o;
-        if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
+        for (int pr = 0; pr < T / 2; ++pr) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[2 * pr][r]) * v[2 * pr + 1][r];
+          const int tile = blockIdx.x * (T / 2) + pr;   // tile of the ffn dimension
+          if (a.out) reinterpret_cast<f32x4*>(a.out)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane] = o;
+          if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
+        }
       } else {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
