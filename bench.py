@@ -133,7 +133,7 @@ def main():
         codes = eng.generate_codes(feats, T_FRAMES, **kw)
         wav = codec.decode(codes)
         if world > 1:  # the single exchange of the job: final gather of tokens + waveform over RCCL
-            vdist.gather_clips(codes.to(torch.int16), counts)
+            vdist.gather_clips(codes.to(torch.int32), counts)
             vdist.gather_clips(wav, counts)
         return codes, wav
 
@@ -190,20 +190,18 @@ def main():
                                        "bytes": lb}
         out["codec_tflops"] = round(B * 353.8e9 / (t_codec * 1e-3) / 1e12, 2)
 
-        # per-kernel: event pairs around every launch of the weight-streaming kernels (eager pass, on the
-        # stream they are launched on), vaura_profile_loop
+        # per-kernel: every launch of one eager 228-step pass carries its own start/stop events on the stream
+        # it is launched on (hipExtLaunchKernelGGL via vaura_profile_loop) = the interval rocprofv3 reports
         eng.start_sequence(None)
         sp = eng._sampling(True, 1.0, args.top_k, 0.0, args.cfg_scale, 1234, first)
         eng.dec.noise = 0
         tot = (C.c_double * 8)()
         cnt = (C.c_int64 * 8)()
-        kinds = {"qkv": 1, "attn": 2, "wo": 3, "w13": 4, "w2": 5, "heads": 6}
-        per = {}
-        for name, bit in kinds.items():   # one kind per pass so the event records do not perturb each other
-            eng.start_sequence(None)
-            L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), 228, 1 << bit, tot, cnt,
-                                               int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
-            per[name] = 1e3 * tot[bit] / max(1, cnt[bit])   # us per launch
+        kinds = {"embed": 0, "qkv": 1, "attn": 2, "wo": 3, "w13": 4, "w2": 5, "heads": 6, "sample": 7}
+        eng.start_sequence(None)
+        L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), 228, 0xFF, tot, cnt,
+                                           int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
+        per = {name: 1e3 * tot[bit] / max(1, cnt[bit]) for name, bit in kinds.items()}   # us per launch
         dom = "w13"
         ab = algorithmic_bytes_per_launch(dom, cfg, wbytes, rows)
         ach = ab / (per[dom] * 1e-6) / 1e9

@@ -1,0 +1,126 @@
+"""The drop-in surface on the GPU: plugin classes built from reference-style config dicts, driven
+like scripts/generate.py drives the reference, compared with goldens the reference
+produced and with the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from vaura_amd import synth
+
+DEV = "cuda:0"
+
+
+def _model(sd, noise_mode="torch_cpu"):
+    from vaura_amd.model import VAURAModel
+    cfg = synth.tiny_sampler(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VAURAModel(
+            feature_extractor_config={"target": "vaura_amd.feature_extractor.MotionFormer"},
+            audio_encoder_config={"target": "vaura_amd.codec.DacModelWrapper", "params": {"model_sr": 44100}},
+            sampler_config={"target": "vaura_amd.sampler.Transformer", "params": cfg.yaml_params()},
+            visual_bridge_config={"target": "torch.nn.Identity"},
+            pattern_provider_config={"target": "vaura_amd.patterns.DelayedPatternProvider", "params": {"n_q": 9}},
+            flatten_vis_feats=True, freeze_feature_extractor=True, noise_mode=noise_mode)
+    m.sampler.load_state_dict(sd, strict=True)
+    m.sampler.audio_tokens_per_video_frame = 7   # scripts/generate.py:216
+    return m.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def model(tiny_sampler_sd):
+    return _model(tiny_sampler_sd)
+
+
+def _ref(g, k):
+    return torch.from_numpy(g[k].astype(np.int64))
+
+
+def test_generate_greedy_and_cfg_like_the_reference_caller(model, golden):
+    g = golden("tiny_model.npz")
+    frames = synth.video_features(2, seed=int(g["feat_seed"])).reshape(2, 4, 8, 768).to(DEV)
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
+                       prompt_is_encoded=True, cfg_scale=1.0)
+    assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "greedy_T20"))
+    assert r["generated_audio"].shape == (2, 1, 20 * 512) and r["s_attn_weights"] is None
+    r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
+                       prompt_is_encoded=True, cfg_scale=6.0)
+    assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "greedy_cfg6_T20"))
+
+
+def test_generate_sampling_reproduces_reference_cpu_stream(model, golden):
+    """noise_mode='torch_cpu': seeding torch like the reference run did gives the reference's tokens."""
+    g = golden("tiny_model.npz")
+    frames = synth.video_features(2, seed=int(g["feat_seed"])).reshape(2, 4, 8, 768).to(DEV)
+    torch.manual_seed(99)
+    r = model.generate(frames=frames, max_new_tokens=20, return_sampled_indices=True, use_sampling=True, temp=1.0,
+                       top_k=250, top_p=0.0, prompt_is_encoded=True, cfg_scale=6.0)
+    assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "topk250_cfg6_seed99_T20"))
+    torch.manual_seed(98)
+    r = model.generate(frames=frames, max_new_tokens=20, return_sampled_indices=True, use_sampling=True, temp=0.9,
+                       top_k=250, top_p=0.8, prompt_is_encoded=True, cfg_scale=1.0)
+    assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "topp80_t09_seed98_T20"))
+
+
+def test_generate_with_prompt_and_remove_prompts(model, golden):
+    g = golden("tiny_model.npz")
+    frames = synth.video_features(2, seed=int(g["feat_seed"])).reshape(2, 4, 8, 768).to(DEV)
+    prompt = _ref(g, "greedy_T20")[:, :, 5:13].to(DEV)
+    r = model.generate(frames=frames, audio=prompt, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
+                       prompt_is_encoded=True, remove_prompts=False)
+    assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "prompt8_greedy_T20"))
+    r2 = model.generate(frames=frames, audio=prompt, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
+                        prompt_is_encoded=True, remove_prompts=True)
+    assert torch.equal(r2["sampled_indices"].cpu(), _ref(g, "prompt8_greedy_T20")[:, :, 8:])
+    assert r2["generated_audio"].shape[-1] == 12 * 512
+
+
+def test_sample_next_token_signature_and_value(model, golden):
+    """_sample_next_token(sequence, condition, ...) -> (B, K, 1): equals the oracle on the same prefix."""
+    from oracle import sampling_oracle as so
+    from oracle.decoder_oracle import DecoderOracle
+    g = golden("tiny_model.npz")
+    feats = synth.video_features(2, seed=int(g["feat_seed"]))
+    idx = _ref(g, "fwd_idx")[:, :, :7]
+    sd = {k: v.cpu() for k, v in model.sampler.state_dict().items()}
+    dec = DecoderOracle(sd, 2, 16)
+    cond = torch.cat([feats, dec.null_condition(feats)], 0)
+    ref_logits = so.cfg_mix(dec.forward_full(idx.repeat(2, 1, 1), cond)[:, :, -1], 6.0)
+    ref = so.next_token(ref_logits, use_sampling=False, temp=1.0, top_k=0, top_p=0.0, noise=None)
+    tok, a, b = model._sample_next_token(idx.to(DEV), feats.to(DEV), use_sampling=False, cfg_scale=6.0)
+    assert a is None and b is None and tok.shape == (2, 9, 1)
+    assert torch.equal(tok.cpu(), ref)
+
+
+def test_sampler_forward_returns_all_positions(model, golden):
+    g = golden("tiny_model.npz")
+    feats = synth.video_features(2, seed=int(g["feat_seed"])).to(DEV)
+    logits, a, b = model.sampler(tgt=_ref(g, "fwd_idx").to(DEV), memory=feats, tgt_is_causal=True)
+    assert logits.shape == (2, 9, 12, 1024) and a is None and b is None
+    ref = torch.from_numpy(g["fwd_logits"])
+    assert (logits.cpu()[:, :, list(g["fwd_logits_pos"])] - ref).abs().max() < 3e-5
+
+
+def test_codec_plugin_decodes_encodec_style_frames(model):
+    from oracle import dac_oracle
+    codes = torch.randint(0, 1024, (1, 9, 6), generator=torch.Generator().manual_seed(4))
+    wav = model.audio_encoder.decode([(codes.to(DEV), None)])
+    sd = {k: v.cpu().float() for k, v in model.audio_encoder.model.state_dict().items()}
+    ref = dac_oracle.decode(sd, codes)
+    assert wav.shape == (1, 1, 6 * 512)
+    assert float(((wav.cpu() - ref) ** 2).mean().sqrt()) <= 1e-4
+
+
+def test_pattern_plugin_on_device(golden):
+    from vaura_amd.patterns import DelayedPatternProvider
+    g = golden("patterns.npz")
+    pat = DelayedPatternProvider(n_q=9).get_pattern(20)
+    codes = torch.from_numpy(g["T20_p8_codes"].astype(np.int64)).to(DEV)
+    seq, idx, mask = pat.build_pattern_sequence(codes, 1024)
+    assert np.array_equal(seq.cpu().numpy(), g["T20_p8_seq"]) and np.array_equal(mask.cpu().numpy(), g["T20_p8_mask"])
+    rev, ridx, rmask = pat.revert_pattern_sequence(torch.from_numpy(g["T20_p8_filled"].astype(np.int64)).to(DEV), -1)
+    assert np.array_equal(rev.cpu().numpy(), g["T20_p8_rev"]) and bool(rmask.all())

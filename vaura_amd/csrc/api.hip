@@ -22,19 +22,24 @@ static int check_decoder(const vaura_decoder* d) {
   return 0;
 }
 
-// Optional per-launch timing (vaura_profile_loop): event pairs around every launch of the selected kinds.
+// Optional per-launch timing (vaura_profile_loop): every launch of the selected kinds carries its own
+// start/stop events (see VA_LAUNCH), i.e. the interval rocprofv3's kernel trace reports.
+hipEvent_t va_prof_start = nullptr, va_prof_stop = nullptr;
 struct StepProfiler {
   unsigned mask = 0;
   std::vector<hipEvent_t> ev[VAURA_K_COUNT];
-  void before(int kind, hipStream_t s) {
+  void before(int kind) {
     if (!(mask & (1u << kind))) return;
-    hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, s); ev[kind].push_back(e);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    ev[kind].push_back(a); ev[kind].push_back(b);
+    va_prof_start = a; va_prof_stop = b;
   }
-  void after(int kind, hipStream_t s) { before(kind, s); }
+  void after(int) { va_prof_start = nullptr; va_prof_stop = nullptr; }
 };
 static StepProfiler* g_prof = nullptr;
-#define PROF_B(kind) do { if (g_prof) g_prof->before(kind, s); } while (0)
-#define PROF_A(kind) do { if (g_prof) g_prof->after(kind, s); } while (0)
+#define PROF_B(kind) do { if (g_prof) g_prof->before(kind); } while (0)
+#define PROF_A(kind) do { if (g_prof) g_prof->after(kind); } while (0)
 
 static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
                     const float* gain_out, float* ss_out, const vaura_decoder* d, int N) {

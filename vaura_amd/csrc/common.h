@@ -1,6 +1,7 @@
 // Shared device helpers for libvaura_hip (gfx950 / CDNA4 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/vaura_hip.h"
 
@@ -13,12 +14,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     if (e__ != hipSuccess) return (int)e__;    \
   } while (0)
 // launch + check; the sticky per-thread error is cleared first so that a stale error left by some
-// earlier, unrelated runtime call (observed: hipErrorNoDevice from a device probe) is not reported here
-#define VA_LAUNCH(...)                         \
-  do {                                         \
-    (void)hipGetLastError();                   \
-    hipLaunchKernelGGL(__VA_ARGS__);           \
-    VA_CHECK_LAUNCH();                         \
+// earlier, unrelated runtime call (observed: hipErrorNoDevice from a device probe) is not reported here.
+// When vaura_profile_loop arms va_prof_start/stop the launch carries its own start/stop events
+// (hipExtLaunchKernelGGL): they time exactly the kernel, like rocprofv3's kernel trace does.
+extern hipEvent_t va_prof_start, va_prof_stop;
+#define VA_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
+  do {                                                                                               \
+    (void)hipGetLastError();                                                                         \
+    if (va_prof_start) {                                                                             \
+      hipExtLaunchKernelGGL(kern, grid, block, smem, stream, va_prof_start, va_prof_stop, 0, __VA_ARGS__); \
+    } else {                                                                                         \
+      hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);                              \
+    }                                                                                                \
+    VA_CHECK_LAUNCH();                                                                               \
   } while (0)
 
 // packed-rows index (see vaura_hip.h): float index of (row, col) in a (rows x C) matrix

@@ -1,0 +1,160 @@
+"""Generation-path mirror of the reference's ``VAURAModel`` (/root/reference/models/vaura_model.py).
+
+Same plugin slots and constructor keywords (:28-120), same ``generate()`` keywords and result dict
+(:410-597) and same ``_sample_next_token()`` signature (:775-827), so ``scripts/generate.py``-style
+callers and ``configs/generate_*.yaml`` work once the ``target:`` strings point at ``vaura_amd``.
+It is a plain ``nn.Module`` (inference only — the Lightning training half is out of scope) and it
+does no arithmetic itself: conditioning, the 228-step decode loop, sampling, pattern bookkeeping and
+codec decode all run in libvaura_hip.so.
+
+What differs from the reference, on purpose:
+  * the hot loop uses a K/V cache and runs entirely on the device (the reference re-feeds the whole
+    prefix every step, :504-506); results are identical under causal masking;
+  * ``noise_mode``: "philox" (default; device RNG keyed by (seed, clip index): invariant to batch
+    sharding) or "torch_cpu" (Exp(1) draws taken from torch's global CPU generator in the
+    reference's own order, which reproduces the reference CPU path token for token);
+  * the codec decodes in fp32 (the reference casts DAC to fp16, :92).
+"""
+from __future__ import annotations
+
+from typing import Any, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .patterns import DelayedPatternProvider
+from .utils import instantiate_from_config, sample_from_logits
+
+
+def _disabled_train(self, mode: bool = True):
+    return self
+
+
+class VAURAModel(nn.Module):
+    def __init__(self, learning_rate: float = 5e-6, lr_scheduler: dict = None, weight_decay: float = 0.01,
+                 betas: tuple = (0.9, 0.95), batch_size: int = 1, use_visual_conditioning: bool = True,
+                 feature_extractor_config: dict = None, audio_encoder_config: dict = None, sampler_config: dict = None,
+                 visual_bridge_config: dict = None, pattern_provider_config: dict = None,
+                 predict_at_val_start: bool = False, return_attention_weights: bool = False,
+                 plot_distr_of_pred_indices: bool = False, freeze_feature_extractor: bool = False,
+                 files_to_track_during_training: List[str] = None, flatten_vis_feats: bool = False,
+                 apply_per_video_frame_mask: bool = False, noise_mode: str = "philox", seed: int = 0):
+        super().__init__()
+        self.use_visual_conditioning = use_visual_conditioning
+        self.visual_feature_extractor = instantiate_from_config(feature_extractor_config) if use_visual_conditioning else None
+        if freeze_feature_extractor and self.visual_feature_extractor is not None:
+            self.visual_feature_extractor.eval().requires_grad_(False)
+        self.using_avclip = self.visual_feature_extractor.__class__.__name__ == "MotionFormer"
+        self.flatten_vis_feats = self.using_avclip and flatten_vis_feats
+        sampler_config = dict(sampler_config)
+        sampler_config["params"] = dict(sampler_config.get("params", {}), use_visual_conditioning=use_visual_conditioning)
+        self.sampler = instantiate_from_config(sampler_config)
+        self.visual_bridge = instantiate_from_config(visual_bridge_config) if use_visual_conditioning else None
+        self.audio_encoder = instantiate_from_config(audio_encoder_config)
+        if hasattr(self.sampler, "initialize_embeddings") and self.audio_encoder.__class__.__name__ == "DacModelWrapper":
+            self.sampler.initialize_embeddings(self.audio_encoder.model)
+        self.audio_encoder.eval().requires_grad_(False)
+        self.num_codebooks = self.sampler.num_codebooks
+        if pattern_provider_config is not None:
+            cfg = dict(pattern_provider_config)
+            cfg["params"] = dict(cfg.get("params", {}), n_q=self.num_codebooks)  # :699-714
+            self.pattern_provider = instantiate_from_config(cfg)
+        else:
+            self.pattern_provider = DelayedPatternProvider(n_q=self.num_codebooks)
+        if hasattr(self.sampler, "codebook_pattern"):
+            self.sampler.codebook_pattern = self.pattern_provider.__class__.__name__
+        self.apply_per_video_frame_mask = apply_per_video_frame_mask
+        self.return_attention_weights = return_attention_weights
+        self.noise_mode = noise_mode
+        self.seed = seed
+        self.clip_base = 0  # global index of this rank's first clip (vaura_amd.dist)
+        self.eval()
+
+    # ------------------------------------------------------------------ small surface
+    @property
+    def special_token_id(self) -> int:
+        return self.sampler.d_codebook
+
+    @property
+    def device(self):
+        return next(self.sampler.parameters()).device
+
+    def _handle_visual_conditioning(self, frames: torch.Tensor, clip_indices=None, B: int = None):
+        if not self.use_visual_conditioning:
+            return None
+        assert frames is not None
+        if self.using_avclip:
+            vis_feats, _ = self.visual_feature_extractor(frames)
+            if self.flatten_vis_feats:
+                Bf, S, Tv, D = vis_feats.shape
+                vis_feats = vis_feats.reshape(Bf, S * Tv, D)
+        else:
+            vis_feats = self.visual_feature_extractor(frames)
+        return self.visual_bridge(vis_feats.detach())
+
+    def _exp_noise(self, steps: int, rows: int, vocab: int) -> Optional[torch.Tensor]:
+        if self.noise_mode == "philox":
+            return None
+        if self.noise_mode != "torch_cpu":
+            raise ValueError(f"unknown noise_mode {self.noise_mode!r}")
+        # one (rows, vocab) exponential draw per step from the global CPU generator: the stream the
+        # reference's utils.multinomial -> torch.multinomial consumes on its CPU path
+        return torch.stack([torch.empty(rows, vocab).exponential_(1) for _ in range(steps)])
+
+    # ------------------------------------------------------------------ generate
+    @torch.no_grad()
+    def generate(self, frames=None, audio: Union[torch.Tensor, None] = None, clip_indices=None, max_new_tokens: int = 512,
+                 return_attention_weights: bool = False, return_sampled_indices: bool = False, check: bool = False,
+                 use_sampling: bool = True, temp: float = 1.0, top_k: int = 256, top_p: float = 0.0,
+                 remove_prompts: bool = False, prompt_is_encoded: bool = False, cfg_scale: float = 1.0) -> dict:
+        assert not self.training, "do not use generation in training mode"
+        if return_attention_weights:
+            raise NotImplementedError("attention-weight dumps are not produced by the fused decode path")
+        if audio is not None and not prompt_is_encoded:
+            raise NotImplementedError("raw-audio prompts need DAC encode (out of scope); pass encoded tokens")
+        vis = self._handle_visual_conditioning(frames, clip_indices)
+        if vis is None:
+            raise NotImplementedError("unconditional generation is not built (every config conditions on video)")
+        B = vis.shape[0]
+        K = self.num_codebooks
+        Tp = 0 if audio is None else int(audio.shape[-1])
+        assert Tp < max_new_tokens, "gt audio prompt can not be longer than max_new_tokens"
+        use_cfg = cfg_scale > 1.0 and self.sampler.__class__.__name__ == "Transformer"
+        eng = self.sampler.engine()
+        if self.sampler.audio_tokens_per_video_frame is None:
+            raise L.VauraHipError("sampler.audio_tokens_per_video_frame must be set (scripts/generate.py:216 sets 7)")
+        S = max_new_tokens + K
+        start = Tp + 1  # Pattern.get_first_step_with_timesteps(Tp), delayed pattern
+        greedy = not (use_sampling and temp > 0.0)
+        noise = None if greedy else self._exp_noise(S - start, B * K, self.sampler.d_codebook)
+        codes = eng.generate_codes(
+            vis.float(), max_new_tokens, prompt=audio if Tp else None, use_sampling=use_sampling, temp=temp, top_k=top_k,
+            top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed, clip_base=self.clip_base,
+            tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
+        # the reference's post-conditions (:550-572), checked once on the finished tensor
+        bad = (codes < 0) | (codes > self.sampler.d_codebook)
+        assert not bool(bad.any()), "generated sequence is incomplete or out of range"
+        out_codes = codes[..., (Tp if remove_prompts else 0):max_new_tokens]
+        generated_audio = self.audio_encoder.decode([(out_codes[..., :K, :], None)])
+        return {"generated_audio": generated_audio, "s_attn_weights": None, "mha_attn_weights": None,
+                "sampled_indices": out_codes if return_sampled_indices else None}
+
+    # ------------------------------------------------------------------ one step, reference signature
+    @torch.no_grad()
+    def _sample_next_token(self, sequence: torch.Tensor, condition: torch.Tensor, use_sampling: bool = False,
+                           temp: float = 1.0, top_k: int = 0, top_p: float = 0.0, return_attention_weights: bool = False,
+                           cfg_scale: float = 1.0) -> Tuple[torch.Tensor, Any, Any]:
+        """sequence (B, K, L) int64, condition (B, Tv, 768) -> (next_token (B, K, 1), None, None).
+        Stateless like the reference (the whole prefix is given), so it teacher-forces the prefix through
+        the decode kernels; ``generate()`` does not go through here."""
+        use_cfg = cfg_scale > 1.0 and self.sampler.__class__.__name__ == "Transformer"
+        if use_cfg:
+            null = torch.zeros_like(condition) + self.sampler.cls_embeddings.uncond_embedding.to(condition.device)
+            condition = torch.cat([condition, null], dim=0)
+            sequence = sequence.repeat(2, 1, 1)
+        logits, _, _ = self.sampler(tgt=sequence, memory=condition, tgt_is_causal=True)
+        last = logits[:, :, -1, :].contiguous()
+        tok = sample_from_logits(last, use_sampling=use_sampling, temp=temp, top_k=top_k, top_p=top_p,
+                                 cfg_scale=cfg_scale if use_cfg else 1.0)
+        return tok, None, None
