@@ -48,10 +48,16 @@ __global__ __launch_bounds__(64) void embed_kernel(
   } else {
     const int c0 = (cq - cond_dim / 4) * 4;
     o = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < K; ++k) {   // same left-to-right order as the reference's sum([...]) (llama.py:455-460)
-      const int tok = seq[((size_t)b * K + k) * S + pos];
-      o += *reinterpret_cast<const f32x4*>(table + ((size_t)k * vocab1 + tok) * tok_dim + c0);
-    }
+    int tok[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tok[k] = (k < K) ? seq[((size_t)b * K + k) * S + pos] : 0;
+    f32x4 e[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < K) e[k] = *reinterpret_cast<const f32x4*>(table + ((size_t)k * vocab1 + tok[k]) * tok_dim + c0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)    // same left-to-right order as the reference's sum([...]) (llama.py:455-460)
+      if (k < K) o += e[k];
   }
   reinterpret_cast<f32x4*>(h)[packed_quad(row, cq, D)] = o;
   if (hsplit) {
@@ -162,6 +168,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
   __shared__ float sp[1024];   // top-p: sorted probabilities
   __shared__ int sidx[1024];   // top-p: their token ids
   __shared__ float skeep[1024];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t s_sel[2];
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int pos = a.state ? a.state[0] : 0;
   const long long step = a.state ? (long long)a.state[2] : a.step_host;
@@ -258,11 +266,36 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
         uint32_t key[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) key[j] = __builtin_bit_cast(uint32_t, p[j]);
+        // k-th largest key by radix-256 select: 4 passes of {LDS histogram of the next byte among the keys
+        // that still match the chosen prefix, suffix-sum over the 256 bins, pick the byte holding rank `need`}
         uint32_t thr = 0;
-        for (int bit = 30; bit >= 0; --bit) {
-          const uint32_t cand = thr | (1u << bit);
-          const int c = (key[0] >= cand) + (key[1] >= cand) + (key[2] >= cand) + (key[3] >= cand);
-          if (block_count(c, si) >= kk) thr = cand;
+        int need = kk;
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+          const int shift = 24 - 8 * pass;
+          hist[tid] = 0;
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (pass == 0 || (key[j] >> (shift + 8)) == (thr >> (shift + 8))) atomicAdd(&hist[(key[j] >> shift) & 255u], 1u);
+          __syncthreads();
+          const int mine = (int)hist[255 - tid];       // reversed: an inclusive prefix scan gives suffix sums
+          int scan = mine;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(scan, o, 64);
+            if ((tid & 63) >= o) scan += up;
+          }
+          if ((tid & 63) == 63) si[tid >> 6] = scan;
+          __syncthreads();
+          for (int w2 = 0; w2 < (tid >> 6); ++w2) scan += si[w2];
+          if (scan >= need && scan - mine < need) {    // exactly one bin holds the rank
+            s_sel[0] = thr | ((uint32_t)(255 - tid) << shift);
+            s_sel[1] = (uint32_t)(need - (scan - mine));
+          }
+          __syncthreads();
+          thr = s_sel[0];
+          need = (int)s_sel[1];
         }
         const float thrf = __builtin_bit_cast(float, thr);
 #pragma unroll
