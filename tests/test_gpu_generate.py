@@ -142,3 +142,36 @@ def test_dac_decode_matches_oracle():
     rms = float(((got - ref) ** 2).mean().sqrt())
     assert rms <= 1e-4, rms
     assert float(ref.abs().max()) > 0.05  # the fixture is not a silent waveform
+
+
+def test_two_row_blocks_with_cfg_against_live_oracle():
+    """B=10 with CFG -> 20 decoder rows = two 16-row blocks (the second one ragged): every GEMV loops
+    row blocks, attention / sampler grids grow.  Token-exact vs the oracle."""
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    cfg = synth.tiny_sampler(2)
+    sd = synth.sampler_state_dict(cfg, seed=31)
+    feats = synth.video_features(10, seed=32)
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
+    ref = go.generate(dec, feats, 14, mode="cached", cfg_scale=6.0)
+    for wd in WDTYPES:
+        eng = DecoderEngine(cfg, sd, DEV, wdtype=wd)
+        got = eng.generate_codes(feats.to(DEV), 14, cfg_scale=6.0).cpu()
+        assert torch.equal(got, ref), wd
+
+
+def test_long_context_single_pass_against_live_oracle():
+    """BASELINE configs[3] shape at reduced depth: block_size_audio=1024 (rope table beyond 256 rows),
+    Tv=128 video tokens, T=300 (> 256 cached positions: the generic attention loop), B=2, cfg 1.0
+    (the reference's CFG null embedding is fixed at 32 tokens, vaura_model.py:790-793)."""
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    cfg = synth.tiny_sampler(2, block_size_audio=1024)
+    sd = synth.sampler_state_dict(cfg, seed=41)
+    feats = synth.video_features(2, tokens=128, seed=42)
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead, block_size=1024)
+    ref = go.generate(dec, feats, 300, mode="cached")
+    eng = DecoderEngine(cfg, sd, DEV, wdtype="bf16")
+    got = eng.generate_codes(feats.to(DEV), 300).cpu()
+    assert eng.max_len >= 1024
+    assert torch.equal(got, ref), float((got == ref).float().mean())
