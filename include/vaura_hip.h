@@ -232,8 +232,13 @@ typedef struct vaura_codec {
   vaura_conv res[4][3][2];          /* {k7 dilated, k1}                          ...block.{u+2}.block.{1,3} */
   const float* alpha_out;           /* final Snake                               decoder.model.{n+1}        */
   vaura_conv conv_out;              /* C_last -> 1, k7, w as [7][C_last]; tanh   decoder.model.{n+2}        */
-  float* ws[4];                     /* activation buffers, channels-last (B, L, C) fp32, ws_elems floats each */
+  float* ws[4];                     /* activation buffers, channels-last (B, L, C), ws_elems x 4 bytes each */
   size_t ws_elems;
+  int32_t precision;                /* 0: fp32 activations/weights, exact v_mfma_f32_16x16x4_f32;
+                                       1: (hi, lo) fp16 pairs, 3 x v_mfma_f32_16x16x32_f16 per product: conv weights
+                                          (not conv_out) must then be given in pair layout
+                                          [.. Cout][Cin/8][hi|lo][8] halves instead of [.. Cout][Cin] floats */
+  int32_t _pad1;
 } vaura_codec;
 
 /* codes (B, K, T) int32 -> wav (B, 1, T*prod(rates)) fp32 */

@@ -30,6 +30,15 @@ __global__ __launch_bounds__(NW * 64) void stream_only(const u32x4* __restrict__
 
 struct Case { const char* name; double bytes; };
 
+// touch one dword per `stride` bytes of [p, p+bytes): pulls the lines into the memory-side Infinity Cache
+__global__ void prefetch_kernel(const char* p, size_t bytes, int stride, float* sink) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)stride;
+  const size_t step = (size_t)gridDim.x * blockDim.x * (size_t)stride;
+  uint32_t acc = 0;
+  for (; i < bytes; i += step) acc ^= *reinterpret_cast<const uint32_t*>(p + i);
+  if (acc == 0x12345678u) sink[threadIdx.x] = 1.f;
+}
+
 // time per launch inside a replayed hipGraph of `nsets` back-to-back launches (how the product runs them)
 static hipStream_t g_stream;
 template <typename F>
@@ -188,6 +197,48 @@ int main(int argc, char** argv) {
   G3("   w2  ablate no x", 8, 16, 1, E3_RESID, false, 2, 2, 96, 1536, true, true, b2);
   G3("g3 heads <6,8,2>", 6, 8, 2, E3_LOGITS, true, 1, 0, 288, 9216, false, false, bh);
   G3("   heads <3,16,2>", 3, 16, 2, E3_LOGITS, true, 1, 0, 288, 9216, false, false, bh);
+  // ---- next-layer prefetch into the Infinity Cache on a second stream (fork/join inside the graph)
+  {
+    hipStream_t s2; CK(hipStreamCreate(&s2));
+    auto timed_pair = [&](const char* name, int stride, int pf_blocks, bool do_prefetch) {
+      if (g_filter && !strstr(name, g_filter)) return;
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      std::vector<hipEvent_t> fork(NSETS), join(NSETS);
+      for (int i = 0; i < NSETS; ++i) { CK(hipEventCreate(&fork[i])); CK(hipEventCreate(&join[i])); }
+      hipGraph_t graph; hipGraphExec_t exec;
+      CK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < NSETS; ++i) {
+        if (do_prefetch) {
+          CK(hipEventRecord(fork[i], g_stream));
+          CK(hipStreamWaitEvent(s2, fork[i], 0));
+          hipLaunchKernelGGL(prefetch_kernel, dim3(pf_blocks), dim3(256), 0, s2, Wbuf + (size_t)((i + 1) % NSETS) * maxW,
+                             (size_t)(8192.0 * 1536 * 2), stride, out);
+          CK(hipEventRecord(join[i], s2));
+        }
+        hipLaunchKernelGGL((gemv3_kernel<6, 8, 2, E3_SWIGLU, true, 1, 0>), dim3(256), dim3(512), 0, g_stream, a3(i, 4096, true, false, true));
+        hipLaunchKernelGGL((gemv3_kernel<6, 8, 1, E3_RESID, false, 1, 0>), dim3(96), dim3(512), 0, g_stream, a3(i, 1536, false, true, true));
+        if (do_prefetch) CK(hipStreamWaitEvent(g_stream, join[i], 0));
+      }
+      CK(hipStreamEndCapture(g_stream, &graph));
+      CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(exec, g_stream)); CK(hipStreamSynchronize(g_stream));
+      CK(hipEventRecord(e0, g_stream));
+      for (int i = 0; i < 10; ++i) CK(hipGraphLaunch(exec, g_stream));
+      CK(hipEventRecord(e1, g_stream)); CK(hipEventSynchronize(e1));
+      float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-44s %8.2f us per (w13 + wo) pair\n", name, 1e3 * ms / (10 * NSETS));
+    };
+    timed_pair("pf none", 0, 0, false);
+    timed_pair("pf stride128 256 blocks", 128, 256, true);
+    timed_pair("pf stride64 256 blocks", 64, 256, true);
+    timed_pair("pf stride128 64 blocks", 128, 64, true);
+    timed_pair("pf stride16 256 blocks (all bytes)", 16, 256, true);
+  }
+  G3("nt w13 <6,8,2> x plain", 6, 8, 2, E3_SWIGLU, true, 1, 0, 256, 4096, false, true, b13);
+  G3("nt w13 <6,8,2> x nontemporal", 6, 8, 2, E3_SWIGLU, true, 1, 256, 256, 4096, false, true, b13);
+  G3("nt qkv <6,8,2> x plain", 6, 8, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
+  G3("nt qkv <6,8,2> x nontemporal", 6, 8, 2, E3_STORE, true, 1, 256, 144, 4608, false, false, bq);
+  G3("nt w13 <6,8,2> W plain x plain", 6, 8, 2, E3_SWIGLU, true, 1, 32, 256, 4096, false, true, b13);
   // ---- tile-count sweep after the rinv fix
   G3("sw qkv <6,8,2> 144", 6, 8, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
   G3("sw qkv <6,8,3> 96", 6, 8, 3, E3_STORE, true, 1, 0, 96, 4608, false, false, bq);

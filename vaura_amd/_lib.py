@@ -64,7 +64,7 @@ class Codec(C.Structure):
                 ("conv_in", Conv), ("alpha_up", C.c_void_p * 4), ("up", Conv * 4),
                 ("alpha_res", ((C.c_void_p * 2) * 3) * 4), ("res", ((Conv * 2) * 3) * 4),
                 ("alpha_out", C.c_void_p), ("conv_out", Conv),
-                ("ws", C.c_void_p * 4), ("ws_elems", C.c_size_t)]
+                ("ws", C.c_void_p * 4), ("ws_elems", C.c_size_t), ("precision", C.c_int32), ("_pad1", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/vaura_hip.h

@@ -135,10 +135,148 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp16-pair variant (codec precision 1): activations and weights travel as (hi, lo) fp16 pairs,
+//   x = fp16(x) + fp16(x - fp16(x))   (22 significand bits; |rel err| <= 2^-22),
+// and a product is three v_mfma_f32_16x16x32_f16: lo_w*hi_x + hi_w*lo_x + hi_w*hi_x (fp16 x fp16 products
+// are exact in fp32; the dropped lo*lo term is < 2^-22).  5.3x fewer matrix-pipe cycles than the exact
+// fp32 MFMA above at an error far inside the codec's 1e-4 RMS budget (measured).
+// "pair layout" of an activated (L x C) buffer / a weight tap (Cout x Cin): per row, C/8 octets of
+// [plane hi|lo][8] halves = 32 B -> one row of 32 channels is still one 128-B line, same bytes as fp32.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvPArgs {
+  const uint16_t* in;    // pair layout (B, Lin, Cin)
+  const uint16_t* w;     // pair layout [phase][tap][Cout][Cin]
+  const float* bias;
+  const float* res;      // fp32 (B, Lout, Cout)
+  const float* alpha;
+  float* out_raw;        // fp32
+  uint16_t* out_act;     // pair layout, Snake applied
+  int Lin, Lout, Cin, Cout, NT;
+  int off_base, off_step, ostride, oshift0, jcount;
+};
+
+__device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, int C, const f32x4 v) {
+  // 4 consecutive channels c0..c0+3 (c0 % 4 == 0) of one row
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = v[i];
+    h[i] = (_Float16)x;
+    l[i] = (_Float16)(x - (float)h[i]);
+  }
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4* p = reinterpret_cast<f16x4*>(base + ((row * (size_t)(C >> 3) + (size_t)(c0 >> 3)) * 2) * 8 + (c0 & 7));
+  p[0] = f16x4{h[0], h[1], h[2], h[3]};
+  p[2] = f16x4{l[0], l[1], l[2], l[3]};   // +8 halves = the lo plane of the same octet
+}
+
+__global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
+  __shared__ u32x4 Ws[2][BK / 4][BN + 1];
+  __shared__ u32x4 Xs[2][BK / 4][BM + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wn = wv & 1, wm = wv >> 1;
+  const int j0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int phases = a.ostride;
+  const int b = blockIdx.z / phases, ph = blockIdx.z % phases;
+  const int cq = a.Cin / 4;                 // 16-B quads per row (C/8 octets x 2 planes)
+  const u32x4* in = reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.Lin * cq;
+  const u32x4* wbase = reinterpret_cast<const u32x4*>(a.w) + (size_t)ph * a.NT * a.Cout * cq;
+  const int kc = a.Cin / BK;
+  const int nk = a.NT * kc;
+
+  u32x4 wreg[3], xreg[4];
+  auto load_tile = [&](int kt) {
+    const int t = kt / kc, q0 = (kt % kc) * (BK / 4);
+    const u32x4* wt = wbase + (size_t)t * a.Cout * cq;
+    const int off = a.off_base + t * a.off_step;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      wreg[i] = wt[(size_t)(n0 + row) * cq + q0 + kq];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      const int jr = j0 + row + off;
+      xreg[i] = (jr >= 0 && jr < a.Lin) ? in[(size_t)jr * cq + q0 + kq] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; Ws[buf][qd & 7][qd >> 3] = wreg[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs[buf][qd & 7][qd >> 3] = xreg[i]; }
+  };
+
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int g = lane >> 4, r16 = lane & 15;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    f16x8 wh[3], wl[3], xh[4], xl[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      wh[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g][wn * 48 + i * 16 + r16]);
+      wl[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g + 1][wn * 48 + i * 16 + r16]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = __builtin_bit_cast(f16x8, Xs[buf][2 * g][wm * 64 + j * 16 + r16]);
+      xl[j] = __builtin_bit_cast(f16x8, Xs[buf][2 * g + 1][wm * 64 + j * 16 + r16]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  const size_t obase = (size_t)b * a.Lout;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int jr = j0 + wm * 64 + j * 16 + r16;
+    if (jr >= a.jcount) continue;
+    const int orow = jr * a.ostride + a.oshift0 + ph;
+    if (orow < 0 || orow >= a.Lout) continue;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int co = n0 + wn * 48 + i * 16 + 4 * g;
+      const size_t o = (obase + (size_t)orow) * a.Cout + co;
+      f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + co);
+      if (a.res) v = *reinterpret_cast<const f32x4*>(a.res + o) + v;
+      if (a.out_raw) *reinterpret_cast<f32x4*>(a.out_raw + o) = v;
+      if (a.out_act) {
+        const f32x4 al = *reinterpret_cast<const f32x4*>(a.alpha + co);
+        f32x4 sn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sn[r] = snake_f(v[r], al[r]);
+        store_pair4(a.out_act, obase + (size_t)orow, co, a.Cout, sn);
+      }
+    }
+  }
+}
+
 // z[b][t][c] = sum_k ( W_k[c][:] . codebook_k[code] + b_k[c] )   — quantizer.from_codes
 __global__ __launch_bounds__(256) void from_codes_kernel(const int32_t* __restrict__ codes, const float* __restrict__ cb,
                                                           const float* __restrict__ pw, const float* __restrict__ pb,
-                                                          float* __restrict__ z, int K, int T, int size, int dim, int latent) {
+                                                          float* __restrict__ z, int K, int T, int size, int dim, int latent,
+                                                          int pairs) {
   __shared__ float e[16][8];
   const int t = blockIdx.x, b = blockIdx.y;
   if (threadIdx.x < K * dim) {
@@ -155,13 +293,21 @@ __global__ __launch_bounds__(256) void from_codes_kernel(const int32_t* __restri
       for (int i = 0; i < dim; ++i) zk = fmaf(wr[i], e[k][i], zk);
       o += zk + pb[(size_t)k * latent + c];
     }
-    z[((size_t)b * T + t) * latent + c] = o;
+    if (pairs) {
+      const _Float16 h = (_Float16)o, l = (_Float16)(o - (float)h);
+      _Float16* zp = reinterpret_cast<_Float16*>(z) + ((((size_t)b * T + t) * (latent >> 3) + (c >> 3)) * 2) * 8 + (c & 7);
+      zp[0] = h;
+      zp[8] = l;
+    } else {
+      z[((size_t)b * T + t) * latent + c] = o;
+    }
   }
 }
 
 // wav[b][l] = tanh( bias + sum_t sum_c act[l + t - 3][c] * w[t][c] )   — last conv (C -> 1, k = 7)
 __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__ act, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ wav, int L, int C) {
+                                                        const float* __restrict__ bias, float* __restrict__ wav, int L, int C,
+                                                        int pairs) {
   const int b = blockIdx.y;
   const int sub = threadIdx.x & 7;
   const int l = blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -171,7 +317,17 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
     const int r = l + t - 3;
     if (r < 0 || r >= L || l >= L) continue;
     for (int cq = sub; cq < C / 4; cq += 8) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)r * C + 4 * cq);
+      f32x4 x;
+      if (pairs) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const f16x4* pp = reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(in) +
+                                                          (((size_t)r * (C >> 3) + (cq >> 1)) * 2) * 8 + (cq & 1) * 4);
+        const f16x4 h = pp[0], l = pp[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = (float)h[e] + (float)l[e];
+      } else {
+        x = *reinterpret_cast<const f32x4*>(in + (size_t)r * C + 4 * cq);
+      }
       const f32x4 ww = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + 4 * cq);
       d = fmaf(x[0], ww[0], d); d = fmaf(x[1], ww[1], d); d = fmaf(x[2], ww[2], d); d = fmaf(x[3], ww[3], d);
     }
@@ -183,9 +339,27 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
 }
 
 static int launch_conv(const vaura_conv& cv, const float* in, const float* res, const float* alpha, float* out_raw,
-                       float* out_act, int B, int Lin, hipStream_t s) {
+                       float* out_act, int B, int Lin, int pairs, hipStream_t s) {
   if (!cv.w || !cv.bias || (cv.cin % BK) || (cv.cout % BN)) return VAURA_ERR_SHAPE;
   if (out_act && !alpha) return VAURA_ERR_ARG;
+  if (pairs) {
+    ConvPArgs p;
+    p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(cv.w); p.bias = cv.bias; p.res = res;
+    p.alpha = alpha; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
+    p.Lin = Lin; p.Cin = cv.cin; p.Cout = cv.cout;
+    int ph = 1;
+    if (cv.stride > 1) {
+      if (cv.stride % 2) return VAURA_ERR_SHAPE;
+      p.NT = 2; p.off_base = 0; p.off_step = -1; p.ostride = cv.stride; p.oshift0 = -(cv.stride / 2);
+      p.Lout = Lin * cv.stride; p.jcount = Lin + 1; ph = cv.stride;
+    } else {
+      p.NT = cv.taps; p.off_base = -((cv.taps - 1) / 2) * cv.dilation; p.off_step = cv.dilation;
+      p.ostride = 1; p.oshift0 = 0; p.Lout = Lin; p.jcount = Lin;
+    }
+    dim3 grid((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph);
+    VA_LAUNCH(conv_pair_kernel, grid, dim3(256), 0, s, p);
+    return 0;
+  }
   ConvArgs a;
   a.in = in; a.w = cv.w; a.bias = cv.bias; a.res = res; a.alpha = alpha; a.out_raw = out_raw; a.out_act = out_act;
   a.Lin = Lin; a.Cin = cv.cin; a.Cout = cv.cout;
@@ -225,33 +399,35 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   if (c->ws_elems < vaura_dac_workspace_elems(c, B, T)) return VAURA_ERR_ARG;
   for (int i = 0; i < 4; ++i) if (!c->ws[i]) return VAURA_ERR_ARG;
   hipStream_t s = as_stream(s_);
+  const int pr = c->precision;
+  if (pr != 0 && pr != 1) return VAURA_ERR_DTYPE;
   float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
 
   VA_LAUNCH(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
-                     c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim);
+                     c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim, pr);
   // conv_in: only the activated output is consumed (by the first transposed conv)
-  int rc = launch_conv(c->conv_in, Y, nullptr, c->alpha_up[0], nullptr, A, B, T, s);
+  int rc = launch_conv(c->conv_in, Y, nullptr, c->alpha_up[0], nullptr, A, B, T, pr, s);
   if (rc) return rc;
   int L = T;
   for (int b = 0; b < c->n_blocks; ++b) {
     // Snake (already applied by the producer) -> transposed conv; raw kept for the first residual
-    rc = launch_conv(c->up[b], A, nullptr, c->alpha_res[b][0][0], Y, Z, B, L, s);
+    rc = launch_conv(c->up[b], A, nullptr, c->alpha_res[b][0][0], Y, Z, B, L, pr, s);
     if (rc) return rc;
     L *= c->rates[b];
     { float* t = R; R = Y; Y = t; t = A; A = Z; Z = t; }
     for (int u = 0; u < 3; ++u) {
       // y = Snake2(conv7(Snake1(x)))  (Snake1 applied by the producer)
-      rc = launch_conv(c->res[b][u][0], A, nullptr, c->alpha_res[b][u][1], nullptr, Y, B, L, s);
+      rc = launch_conv(c->res[b][u][0], A, nullptr, c->alpha_res[b][u][1], nullptr, Y, B, L, pr, s);
       if (rc) return rc;
       // x = x + conv1(y); emit Snake_next(x)
       const float* next_alpha = (u < 2) ? c->alpha_res[b][u + 1][0] : (b + 1 < c->n_blocks ? c->alpha_up[b + 1] : c->alpha_out);
-      rc = launch_conv(c->res[b][u][1], Y, R, next_alpha, (u < 2) ? R : nullptr, A, B, L, s);
+      rc = launch_conv(c->res[b][u][1], Y, R, next_alpha, (u < 2) ? R : nullptr, A, B, L, pr, s);
       if (rc) return rc;
     }
   }
   const int C = c->conv_out.cin;
   if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
-  VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C);
+  VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
   return 0;
 }
 

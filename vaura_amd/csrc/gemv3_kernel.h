@@ -131,7 +131,9 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
       if (g < GB) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
+          xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
+                     : (ABL & 256) ? __builtin_nontemporal_load(Xp + split_index16(rb, p, (w * G + g) * 4 + q, m, K))
+                                   : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {

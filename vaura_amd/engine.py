@@ -287,11 +287,15 @@ class DecoderEngine:
 class CodecEngine:
     """DAC decode (codes -> waveform) on the HIP path; weights from a DAC-1.0.0-keyed state dict."""
 
-    def __init__(self, cfg: CodecCfg, sd: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, cfg: CodecCfg, sd: Dict[str, torch.Tensor], device="cuda:0", precision: str = "f16pair"):
+        """precision: "f16pair" (default; activations/weights as (hi, lo) fp16 pairs on the fp16 MFMA, error
+        ~1e-6 RMS) or "f32" (exact fp32 MFMA)."""
         _require_cuda(device)
         self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
         self._keep = []
+        self.pairs = {"f32": 0, "f16pair": 1}[precision]
         c = L.Codec()
+        c.precision = self.pairs
         c.n_codebooks, c.codebook_size, c.codebook_dim, c.latent_dim = (cfg.n_codebooks, cfg.codebook_size,
                                                                         cfg.codebook_dim, cfg.latent_dim)
         nb = len(cfg.decoder_rates)
@@ -337,7 +341,16 @@ class CodecEngine:
             cout, cin, k = w.shape
             wl = w.permute(2, 0, 1)
             taps = k
-        cv.w = L.ptr(self._dev(wl))
+        if self.pairs and cout > 1:   # (hi, lo) fp16 pair layout [.., Cout][Cin/8][plane][8]
+            wl = wl.contiguous()
+            hi = wl.half()
+            lo = (wl - hi.float()).half()
+            pr = torch.stack([hi.reshape(*wl.shape[:-1], cin // 8, 8), lo.reshape(*wl.shape[:-1], cin // 8, 8)], dim=-2)
+            keep = pr.contiguous().to(self.dev)
+            self._keep.append(keep)
+            cv.w = L.ptr(keep)
+        else:
+            cv.w = L.ptr(self._dev(wl))
         cv.bias = L.ptr(self._dev(sd[prefix + "bias"]))
         cv.cin, cv.cout, cv.taps, cv.dilation, cv.stride = cin, cout, taps, dilation, stride
 
