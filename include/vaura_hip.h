@@ -93,7 +93,8 @@ typedef struct vaura_decoder {
   int32_t timesteps;       /* T  = max_new_tokens                                  */
   int32_t seq_len;         /* S  = T + n_codebooks                                 */
   int32_t n_cond_tokens;   /* Tv                                                   */
-  int32_t _pad0;
+  int32_t prefill_positions; /* > 0: every ws_* buffer holds this many positions' worth of row blocks, so a
+                                prompt is teacher-forced in chunks of that many positions per pass (bf16 path) */
 
   const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
   const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles           llama.py:356-361 */

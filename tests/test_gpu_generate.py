@@ -177,3 +177,22 @@ def test_long_context_single_pass_against_live_oracle():
     got = eng.generate_codes(feats.to(DEV), 300).cpu()
     assert eng.max_len >= 1024
     assert torch.equal(got, ref), float((got == ref).float().mean())
+
+
+@pytest.mark.parametrize("B,cfg_scale", [(2, 1.0), (3, 6.0), (10, 6.0)])
+def test_batched_prompt_prefill_against_live_oracle(B, cfg_scale):
+    """Sliding-window shape (scripts/generate.py:327-365): a 40-token prompt of a 60-token chunk is
+    teacher-forced in two passes of <= 32 positions (one weight stream per pass, not one per position),
+    then 28 positions are generated.  Rows = B or 2B (incl. two ragged row blocks).  Token-exact."""
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    cfg = synth.tiny_sampler(2)
+    sd = synth.sampler_state_dict(cfg, seed=51)
+    feats = synth.video_features(B, seed=52)
+    prompt = torch.randint(0, 1024, (B, 9, 40), generator=torch.Generator().manual_seed(53))
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
+    ref = go.generate(dec, feats, 60, prompt=prompt, mode="cached", cfg_scale=cfg_scale)
+    eng = DecoderEngine(cfg, sd, DEV, wdtype="bf16")
+    got = eng.generate_codes(feats.to(DEV), 60, prompt=prompt.to(DEV), cfg_scale=cfg_scale).cpu()
+    assert torch.equal(got[:, :, :40], prompt)
+    assert torch.equal(got, ref), float((got == ref).float().mean())

@@ -174,10 +174,6 @@ int main(int argc, char** argv) {
   const double bq = 4608.0 * 1536 * 2, bo = 1536.0 * 1536 * 2, b13 = 8192.0 * 1536 * 2, b2 = 1536.0 * 4096 * 2, bh = 9216.0 * 1536 * 2;
   G3("g3 qkv <6,8,1> norm", 6, 8, 1, E3_STORE, true, 1, 0, 288, 4608, false, false, bq);
   G3("   qkv same-phase slices (old)", 6, 8, 1, E3_STORE, true, 1, 8, 288, 4608, false, false, bq);
-  G3("   qkv x-phase then W-phase", 6, 8, 1, E3_STORE, true, 1, 16, 288, 4608, false, false, bq);
-  G3("   qkv T2 x-phase then W-phase", 6, 8, 2, E3_STORE, true, 1, 16, 144, 4608, false, false, bq);
-  G3("   w13 x-phase then W-phase", 6, 8, 2, E3_SWIGLU, true, 1, 16, 256, 4096, false, true, b13);
-  G3("   wo x-phase then W-phase", 6, 8, 1, E3_RESID, false, 1, 16, 96, 1536, true, true, bo);
   G3("   qkv ablate no MFMA", 6, 8, 1, E3_STORE, true, 1, 1, 288, 4608, false, false, bq);
   G3("   qkv ablate no x", 6, 8, 1, E3_STORE, true, 1, 2, 288, 4608, false, false, bq);
   G3("   qkv ablate no W", 6, 8, 1, E3_STORE, true, 1, 4, 288, 4608, false, false, bq);
@@ -235,10 +231,7 @@ int main(int argc, char** argv) {
     timed_pair("pf stride16 256 blocks (all bytes)", 16, 256, true);
   }
   G3("nt w13 <6,8,2> x plain", 6, 8, 2, E3_SWIGLU, true, 1, 0, 256, 4096, false, true, b13);
-  G3("nt w13 <6,8,2> x nontemporal", 6, 8, 2, E3_SWIGLU, true, 1, 256, 256, 4096, false, true, b13);
   G3("nt qkv <6,8,2> x plain", 6, 8, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
-  G3("nt qkv <6,8,2> x nontemporal", 6, 8, 2, E3_STORE, true, 1, 256, 144, 4608, false, false, bq);
-  G3("nt w13 <6,8,2> W plain x plain", 6, 8, 2, E3_SWIGLU, true, 1, 32, 256, 4096, false, true, b13);
   // ---- tile-count sweep after the rinv fix
   G3("sw qkv <6,8,2> 144", 6, 8, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
   G3("sw qkv <6,8,3> 96", 6, 8, 3, E3_STORE, true, 1, 0, 96, 4608, false, false, bq);

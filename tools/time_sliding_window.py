@@ -1,0 +1,33 @@
+"""Time one later chunk of the sliding-window caller (scripts/generate.py:327-365): Tp = 166 prompt tokens,
+T = 221, i.e. 166 teacher-forced positions + 63 generated ones, B = 8, cfg 6.0 — batched prefill vs
+per-position teacher forcing."""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from vaura_amd import synth
+from vaura_amd.engine import DecoderEngine
+
+dev = "cuda:0"
+cfg = synth.FULL_SAMPLER
+sd = synth.sampler_state_dict(cfg, seed=0)
+feats = synth.video_features(8, seed=0).to(dev)
+prompt = torch.randint(0, 1024, (8, 9, 166), generator=torch.Generator().manual_seed(1)).to(dev)
+res = {}
+for pp in (32, 0):
+    DecoderEngine.PREFILL_POSITIONS = pp if pp else 1
+    eng = DecoderEngine(cfg, sd, dev, wdtype="bf16")
+    kw = dict(prompt=prompt, use_sampling=True, top_k=250, cfg_scale=6.0, seed=3)
+    out = eng.generate_codes(feats, 221, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = eng.generate_codes(feats, 221, **kw)
+    torch.cuda.synchronize()
+    res[pp] = (time.perf_counter() - t0) / 3
+    print(f"prefill_positions={pp}: {res[pp] * 1e3:.1f} ms per chunk (166 prompt + 63 generated positions)")
+    if pp == 32:
+        ref = out.clone()
+    else:
+        print("tokens identical between the two prefill paths:", bool(torch.equal(ref, out)))
+    del eng
+    torch.cuda.empty_cache()

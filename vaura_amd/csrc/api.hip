@@ -42,12 +42,47 @@ static StepProfiler* g_prof = nullptr;
 #define PROF_A(kind) do { if (g_prof) g_prof->after(kind); } while (0)
 
 static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
-                    const float* gain_out, float* ss_out, const vaura_decoder* d, int N) {
+                    const float* gain_out, float* ss_out, const vaura_decoder* d, int N, int n_pos = 1) {
   Gemv3Args a;
   a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
-  a.gain_out = gain_out; a.ss_out = ss_out; a.rows = d->rows; a.R = (d->rows + 15) / 16; a.N = N; a.eps = d->dims.eps;
+  a.gain_out = gain_out; a.ss_out = ss_out;
+  a.R = n_pos * ((d->rows + 15) / 16);           // prefill: one group of row blocks per position
+  a.rows = n_pos == 1 ? d->rows : a.R * 16;
+  a.N = N; a.eps = d->dims.eps;
   a.k_total = d->dims.d_model;
   return a;
+}
+
+// Teacher-forced positions [p0, p0 + n) of the pattern sequence in ONE pass per layer (the prompt of the
+// sliding-window caller, scripts/generate.py:327-365): every GEMV keeps its weight slice in registers and
+// loops over the positions' row blocks, K/V of the whole chunk are rotated/appended first, then each
+// (row, head, position) attends causally over the cache.  No heads, no sampling.
+static int enqueue_prefill_chunk_bf16(const vaura_decoder* d, int p0, int n, hipStream_t s) {
+  const vaura_dims& m = d->dims;
+  const int D = m.d_model, F = m.ffn_dim;
+  int rc = va_launch_embed(d, p0, n, s);
+  if (rc) return rc;
+  for (int l = 0; l < m.n_layer; ++l) {
+    const vaura_layer_weights& L = d->layers_host[l];
+    const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
+    rc = va_launch_gemv3(g3(L.wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D, n), 3 * D, D,
+                         E3_STORE, true, s);
+    if (rc) return rc;
+    rc = va_launch_rope_append(d, l, p0, n, s);
+    if (rc) return rc;
+    rc = va_launch_attention_prefill(d, l, p0, n, s);
+    if (rc) return rc;
+    rc = va_launch_gemv3(g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D, n), D, D,
+                         E3_RESID, false, s);
+    if (rc) return rc;
+    rc = va_launch_gemv3(g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F, n), 2 * F, D,
+                         E3_SWIGLU, true, s);
+    if (rc) return rc;
+    rc = va_launch_gemv3(g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D, n), D, F,
+                         E3_RESID, false, s);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 // bf16-stored weights: activations travel as exact hi/mid/lo bf16 planes, products on the bf16 MFMA
@@ -57,7 +92,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   const int rows = d->rows;
   if (!d->ws_h_split || !d->ws_attn_split || !d->ws_ffn_split || !d->ws_ss) return VAURA_ERR_ARG;
   PROF_B(VAURA_K_EMBED);
-  int rc = va_launch_embed(d, s);   // h, split(h * attn_norm[0]), ss partials
+  int rc = va_launch_embed(d, -1, 1, s);   // h, split(h * attn_norm[0]), ss partials
   PROF_A(VAURA_K_EMBED);
   if (rc) return rc;
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
@@ -90,7 +125,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     PROF_A(VAURA_K_W2);
     if (rc) return rc;
   }
-  if (!sample) return va_launch_advance(d->state, s);
+  if (!sample) return va_launch_advance(d->state, -1, s);
   PROF_B(VAURA_K_HEADS);   // logits = heads . rmsnorm(h)                               llama.py:503-504
   rc = va_launch_gemv3(g3(d->heads, d->ws_h_split, d->ws_ss, nullptr, d->ws_logits, nullptr, nullptr, nullptr, d,
                           m.n_codebooks * m.vocab), (int64_t)m.n_codebooks * m.vocab, D, E3_LOGITS, true, s);
@@ -109,7 +144,7 @@ static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sa
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
   const int rows = d->rows;
   PROF_B(VAURA_K_EMBED);
-  int rc = va_launch_embed(d, s);
+  int rc = va_launch_embed(d, -1, 1, s);
   PROF_A(VAURA_K_EMBED);
   if (rc) return rc;
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
@@ -142,7 +177,7 @@ static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sa
     PROF_A(VAURA_K_W2);
     if (rc) return rc;
   }
-  if (!sample) return va_launch_advance(d->state, s);
+  if (!sample) return va_launch_advance(d->state, -1, s);
   // logits = heads . norm(h)                                              llama.py:503-504
   PROF_B(VAURA_K_HEADS);
   rc = va_launch_gemv(d->heads, d->wdtype, d->ws_h, d->final_norm, nullptr, d->ws_logits, rows, (int64_t)m.n_codebooks * m.vocab, D,
@@ -198,9 +233,20 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
   if (rc) return rc;
   if (!sp || n_prefill < 0 || n_steps < 0) return VAURA_ERR_ARG;
   hipStream_t st = as_stream(s);
-  for (int i = 0; i < n_prefill; ++i) {
-    rc = enqueue_step(dec, sp, 0, st);
+  if (n_prefill > 0 && dec->wdtype == VAURA_W_BF16 && dec->prefill_positions > 0) {
+    // the caller guarantees state[0] == 0 at entry (vaura_pattern_build + zeroed state)
+    for (int p0 = 0; p0 < n_prefill; p0 += dec->prefill_positions) {
+      const int n = (n_prefill - p0 < dec->prefill_positions) ? n_prefill - p0 : dec->prefill_positions;
+      rc = enqueue_prefill_chunk_bf16(dec, p0, n, st);
+      if (rc) return rc;
+    }
+    rc = va_launch_advance(dec->state, n_prefill, st);
     if (rc) return rc;
+  } else {
+    for (int i = 0; i < n_prefill; ++i) {
+      rc = enqueue_step(dec, sp, 0, st);
+      if (rc) return rc;
+    }
   }
   if (use_graph) {
     if (!g_step_exec) return VAURA_ERR_STATE;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     float* __restrict__ vcache,
     float* __restrict__ out,         // packed rows (rows x D)
     uint16_t* __restrict__ outp,     // optional split rows (rows x D)
-    int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
+    int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host, int prefill_rows16) {
   constexpr int QUADS = HD / 4;          // 24
   constexpr int QPL = QUADS / 8;         // float4 per lane per position = 3
   static_assert(QUADS % 8 == 0, "head_dim must be a multiple of 32");
@@ -37,7 +37,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
   const int h = blockIdx.x, row = blockIdx.y;
   const int tid = threadIdx.x;
   const int D = n_head * HD;
-  const int pos = pos_dev ? pos_dev[0] : pos_host;
+  // decode (prefill_rows16 == 0): one new position `pos`, rotated/appended here, cache holds [0, pos).
+  // prefill (prefill_rows16 > 0): workgroup z handles position pos_host + z of a teacher-forced chunk whose
+  // rotated q and cache rows [0, pos] were written by rope_append_kernel; row block z holds its q / output.
+  const bool prefill = prefill_rows16 > 0;
+  const int pos = prefill ? pos_host + (int)blockIdx.z : (pos_dev ? pos_dev[0] : pos_host);
+  const int vrow = prefill ? (int)blockIdx.z * prefill_rows16 + row : row;
+  const int ncache = prefill ? pos + 1 : pos;   // positions read from the cache
   const int L = pos + 1;
   const float scale = 1.0f / sqrtf((float)HD);
 
@@ -45,11 +51,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
   float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
 
   // ---- 1. gather q, k, v of this head; rotate q and k; append k, v
-  if (tid < 3 * QUADS) {
+  if (tid < (prefill ? QUADS : 3 * QUADS)) {
     const int which = tid / QUADS, cq = tid % QUADS;
     const int col = which * D + h * HD + cq * 4;
-    f32x4 x = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, col >> 2, 3 * D)];
-    if (which < 2) {
+    f32x4 x = reinterpret_cast<const f32x4*>(qkv)[packed_quad(vrow, col >> 2, 3 * D)];
+    if (which < 2 && !prefill) {
       const f32x4 cs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
       f32x4 y;
       y[0] = x[0] * cs[0] - x[1] * cs[1];
@@ -59,8 +65,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
       x = y;
     }
     reinterpret_cast<f32x4*>(which == 0 ? sq : (which == 1 ? sk : sv))[cq] = x;
-    if (which == 1) reinterpret_cast<f32x4*>(kc + (size_t)pos * HD)[cq] = x;
-    if (which == 2) reinterpret_cast<f32x4*>(vc + (size_t)pos * HD)[cq] = x;
+    if (which == 1 && !prefill) reinterpret_cast<f32x4*>(kc + (size_t)pos * HD)[cq] = x;
+    if (which == 2 && !prefill) reinterpret_cast<f32x4*>(vc + (size_t)pos * HD)[cq] = x;
   }
   __syncthreads();
 
@@ -71,14 +77,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
 #pragma unroll
   for (int i = 0; i < QPL; ++i) qf[i] = reinterpret_cast<const f32x4*>(sq)[sub + 8 * i];
 
-  for (int p0 = 0; p0 < pos; p0 += 32 * 4) {
+  for (int p0 = 0; p0 < ncache; p0 += 32 * 4) {
     f32x4 kf[4][QPL];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = p0 + u * 32 + prow;
 #pragma unroll
       for (int i = 0; i < QPL; ++i)
-        kf[u][i] = (p < pos) ? reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        kf[u][i] = (p < ncache) ? reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -91,10 +97,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
       d += __shfl_xor(d, 2, 64);
       d += __shfl_xor(d, 4, 64);
       const int p = p0 + u * 32 + prow;
-      if (sub == 0 && p < pos) sc[p] = d * scale;
+      if (sub == 0 && p < ncache) sc[p] = d * scale;
     }
   }
-  if (tid < 64) {  // new position: one wave, lanes 0..23 hold a quad each
+  if (tid < 64 && !prefill) {  // new position: one wave, lanes 0..23 hold a quad each
     float d = 0.f;
     if (tid < QUADS) {
       const f32x4 a = reinterpret_cast<const f32x4*>(sq)[tid], b = reinterpret_cast<const f32x4*>(sk)[tid];
@@ -127,16 +133,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
   f32x4 av[QPL];
 #pragma unroll
   for (int i = 0; i < QPL; ++i) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int p0 = 0; p0 < pos; p0 += 32 * 4) {
+  for (int p0 = 0; p0 < ncache; p0 += 32 * 4) {
     f32x4 vf[4][QPL];
     float pw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = p0 + u * 32 + prow;
-      pw[u] = (p < pos) ? sc[p] * inv : 0.f;
+      pw[u] = (p < ncache) ? sc[p] * inv : 0.f;
 #pragma unroll
       for (int i = 0; i < QPL; ++i)
-        vf[u][i] = (p < pos) ? reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        vf[u][i] = (p < ncache) ? reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -164,10 +170,39 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     f32x4 o = reinterpret_cast<const f32x4*>(red)[tid];
 #pragma unroll
     for (int i = 1; i < 4; ++i) o += reinterpret_cast<const f32x4*>(red + i * HD)[tid];
-    o += reinterpret_cast<const f32x4*>(sv)[tid] * (sc[pos] * inv);
-    reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
-    if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
+    if (!prefill) o += reinterpret_cast<const f32x4*>(sv)[tid] * (sc[pos] * inv);
+    reinterpret_cast<f32x4*>(out)[packed_quad(vrow, (h * HD) / 4 + tid, D)] = o;
+    if (outp) store_split4(outp, vrow, h * HD + 4 * tid, D, o);
   }
+}
+
+// rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
+template <int HD>
+__global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qkv, const float* __restrict__ rope,
+                                                          float* __restrict__ kcache, float* __restrict__ vcache, int n_head,
+                                                          int max_len, int p0, int rows16) {
+  constexpr int QUADS = HD / 4;
+  const int h = blockIdx.x, row = blockIdx.y, pos = p0 + (int)blockIdx.z, tid = threadIdx.x;
+  if (tid >= 3 * QUADS) return;
+  const int D = n_head * HD;
+  const int vrow = (int)blockIdx.z * rows16 + row;
+  const int which = tid / QUADS, cq = tid % QUADS;
+  const int col = which * D + h * HD + cq * 4;
+  f32x4* src = reinterpret_cast<f32x4*>(qkv) + packed_quad(vrow, col >> 2, 3 * D);
+  f32x4 x = *src;
+  if (which < 2) {
+    const f32x4 cs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);
+    f32x4 y;
+    y[0] = x[0] * cs[0] - x[1] * cs[1];
+    y[1] = x[1] * cs[0] + x[0] * cs[1];
+    y[2] = x[2] * cs[2] - x[3] * cs[3];
+    y[3] = x[3] * cs[2] + x[2] * cs[3];
+    x = y;
+  }
+  const size_t cbase = (((size_t)row * n_head + h) * (size_t)max_len + pos) * HD;
+  if (which == 0) *src = x;
+  if (which == 1) reinterpret_cast<f32x4*>(kcache + cbase)[cq] = x;
+  if (which == 2) reinterpret_cast<f32x4*>(vcache + cbase)[cq] = x;
 }
 
 int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, uint16_t* outp, int rows,
@@ -176,7 +211,27 @@ int va_launch_attention(const float* qkv, const float* rope, float* kc, float* v
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
   VA_LAUNCH(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, rope, kc, vc, out, outp,
-            n_head, max_len, pos_dev, pos_host);
+            n_head, max_len, pos_dev, pos_host, 0);
+  return 0;
+}
+
+int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s) {
+  const int H = d->dims.n_head, hd = d->dims.d_model / H;
+  if (hd != 96) return VAURA_ERR_SHAPE;
+  const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
+  VA_LAUNCH(rope_append_kernel<96>, dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, d->kcache + layer * kv_layer,
+            d->vcache + layer * kv_layer, H, d->max_len, p0, (d->rows + 15) / 16 * 16);
+  return 0;
+}
+
+int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s) {
+  const int H = d->dims.n_head, hd = d->dims.d_model / H;
+  if (hd != 96) return VAURA_ERR_SHAPE;
+  const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
+  const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + d->max_len + 4);
+  VA_LAUNCH(attention_step_kernel<96>, dim3(H, d->rows, n_pos), dim3(ATT_THREADS), smem, s, d->ws_qkv, d->rope,
+            d->kcache + layer * kv_layer, d->vcache + layer * kv_layer, d->ws_attn, d->ws_attn_split, H, d->max_len, nullptr,
+            p0, (d->rows + 15) / 16 * 16);
   return 0;
 }
 

@@ -68,8 +68,10 @@ int va_launch_attention(const float* qkv, const float* rope, float* kc, float* v
                         int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s);
 struct Gemv3Args;
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
-int va_launch_embed(const vaura_decoder* d, hipStream_t s);
+int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t s);
 int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,
                      int noise_rows_per_step, const int32_t* state, int64_t step_host, int32_t* tokens_out,
                      int32_t* seq, int T, int S, int32_t* state_rw, hipStream_t s);
-int va_launch_advance(int32_t* state, hipStream_t s);
+int va_launch_advance(int32_t* state, int set_to, hipStream_t s);
+int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);
+int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);

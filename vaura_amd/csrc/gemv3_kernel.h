@@ -77,6 +77,8 @@ __device__ __forceinline__ void store_split4(uint16_t* base, int row, int c0, in
 
 __device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a)); }
 
+// ABL: ablation bits for tools/microbench only (0 in the product): 1 = no MFMA, 2 = no x loads, 4 = no weight
+// loads, 8 = same k-slice order in every workgroup.
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
 // been consumed, for depths whose three planes do not fit the register budget at once)
 template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0>
@@ -99,10 +101,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   const int tile0 = blockIdx.x * T;
   const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
 
+  // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
+  // block; a prefill pass loops row blocks (one per prompt position) over the same registers
+  u32x4 wb[T][G];
+
   auto row_block = [&](const int rb, const bool first) {
     const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
     u32x4 xb[GB][3];
-    u32x4 wb[T][G];
     auto load_x = [&](int b) {
 #pragma unroll
       for (int g = 0; g < GB; ++g)
@@ -111,39 +116,23 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
           xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
                                : Xp[split_index16(rb, p, (w * G + b * GB + g) * 4 + q, m, K)];
     };
-    if constexpr (ABL & 16) {
-      // activation planes first, as their own phase: L2 hits queued behind HBM misses in the CU's
-      // memory pipe return at HBM latency (head-of-line), so the two streams are kept apart
-      load_x(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+    if (first) {
+      // interleave the issue so that k-group g is complete once W[g] and x[g] have landed
 #pragma unroll
-      for (int g = 0; g < G; ++g)
+      for (int g = 0; g < G; ++g) {
+        if (g < GB) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
+        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
-          wb[t][g] = __builtin_nontemporal_load(Wp + kg * 64 + lane);
+          wb[t][g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
         }
+      }
     } else {
-    // interleave the issue so that k-group g is complete once W[g] and x[g] have landed
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (g < GB) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
-                     : (ABL & 256) ? __builtin_nontemporal_load(Xp + split_index16(rb, p, (w * G + g) * 4 + q, m, K))
-                                   : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
-      }
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
-        if constexpr (ABL & 32) wb[t][g] = Wp[kg * 64 + lane];
-        else if constexpr (ABL & 64) wb[t][g] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, 0x7fffffff, 0x00020000), (uint32_t)((kg * 64 + lane) * 16), 0, 2 | 16);
-        else if constexpr (ABL & 128) wb[t][g] = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, 0x7fffffff, 0x00020000), (uint32_t)((kg * 64 + lane) * 16), 0, 16);
-        else wb[t][g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
-      }
-    }
+      load_x(0);
     }
     // rinv inputs: the producer's per-tile partial sums of squares, fetched by the whole workgroup in one
     // go and parked in LDS (a load->add loop in one wave pays an L2 round trip per partial: 2.4 us)

@@ -32,11 +32,14 @@ __global__ __launch_bounds__(64) void embed_kernel(
     const int32_t* __restrict__ seq, const int32_t* __restrict__ state, const float* __restrict__ cond_proj,
     const float* __restrict__ empty_video, const float* __restrict__ table, float* __restrict__ h,
     uint16_t* __restrict__ hsplit, const float* __restrict__ gain, float* __restrict__ ss, int B, int K, int S, int Tv,
-    int tpf, int vocab1, int cond_dim, int tok_dim) {
+    int tpf, int vocab1, int cond_dim, int tok_dim, int pos_host, int rows16) {
   const int row = blockIdx.x;
   const int cq = blockIdx.y * 64 + threadIdx.x;   // 4-column quad
   const int b = row % B;
-  const int pos = state[0];
+  // decode: the position lives on the device; prefill: positions pos_host + blockIdx.z, one row block
+  // (rows16 = padded row count) per position
+  const int pos = pos_host >= 0 ? pos_host + (int)blockIdx.z : state[0];
+  const int vrow = (int)blockIdx.z * rows16 + row;
   const int D = cond_dim + tok_dim;
   const int frame = pos / tpf;
   f32x4 o;
@@ -59,26 +62,27 @@ __global__ __launch_bounds__(64) void embed_kernel(
     for (int k = 0; k < 16; ++k)    // same left-to-right order as the reference's sum([...]) (llama.py:455-460)
       if (k < K) o += e[k];
   }
-  reinterpret_cast<f32x4*>(h)[packed_quad(row, cq, D)] = o;
+  reinterpret_cast<f32x4*>(h)[packed_quad(vrow, cq, D)] = o;
   if (hsplit) {
     float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if ((threadIdx.x & 3) == 0) ss[((size_t)(row >> 4) * (D / 16) + (cq >> 2)) * 16 + (row & 15)] = s;
+    if ((threadIdx.x & 3) == 0) ss[((size_t)(vrow >> 4) * (D / 16) + (cq >> 2)) * 16 + (vrow & 15)] = s;
     const f32x4 u = o * *reinterpret_cast<const f32x4*>(gain + cq * 4);
-    store_split4(hsplit, row, cq * 4, D, u);
+    store_split4(hsplit, vrow, cq * 4, D, u);
   }
 }
 
-int va_launch_embed(const vaura_decoder* d, hipStream_t s) {
+int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t s) {
   const vaura_dims& m = d->dims;
   const int D = m.cond_dim + m.tok_dim;
   if (!d->tok_table || (D % 256)) return VAURA_ERR_SHAPE;
   const bool split = d->wdtype == VAURA_W_BF16;
   if (split && (!d->ws_h_split || !d->ws_ss || !d->first_norm)) return VAURA_ERR_ARG;
-  VA_LAUNCH(embed_kernel, dim3(d->rows, D / 256), dim3(64), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
+  VA_LAUNCH(embed_kernel, dim3(d->rows, D / 256, n_pos), dim3(64), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
             d->tok_table, d->ws_h, split ? d->ws_h_split : nullptr, d->first_norm, d->ws_ss, d->batch, m.n_codebooks,
-            d->seq_len, d->n_cond_tokens, m.tokens_per_frame, m.vocab + 1, m.cond_dim, m.tok_dim);
+            d->seq_len, d->n_cond_tokens, m.tokens_per_frame, m.vocab + 1, m.cond_dim, m.tok_dim, pos_host,
+            (d->rows + 15) / 16 * 16);
   return 0;
 }
 
@@ -353,11 +357,11 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
   return 0;
 }
 
-__global__ void advance_kernel(int32_t* state) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) state[0] += 1;
+__global__ void advance_kernel(int32_t* state, int set_to) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) state[0] = set_to >= 0 ? set_to : state[0] + 1;
 }
-int va_launch_advance(int32_t* state, hipStream_t s) {
-  VA_LAUNCH(advance_kernel, dim3(1), dim3(64), 0, s, state);
+int va_launch_advance(int32_t* state, int set_to, hipStream_t s) {
+  VA_LAUNCH(advance_kernel, dim3(1), dim3(64), 0, s, state, set_to);
   return 0;
 }
 

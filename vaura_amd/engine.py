@@ -104,6 +104,8 @@ class DecoderEngine:
         return (r + 15) // 16 * 16
 
     # ------------------------------------------------------------------ per-call state
+    PREFILL_POSITIONS = 32   # prompt positions teacher-forced per pass (bf16 path); workspaces scale with it
+
     def prepare(self, batch: int, timesteps: int, n_cond_tokens: int, cfg_on: bool, tokens_per_frame: int = 7,
                 block_size: Optional[int] = None):
         c = self.cfg
@@ -115,7 +117,8 @@ class DecoderEngine:
         if self._shape == key:
             return
         with torch.cuda.device(self.dev):
-            rp = self._rows_padded(rows)
+            pp = self.PREFILL_POSITIONS if self.wdtype == "bf16" else 1
+            rp = self._rows_padded(rows) * pp     # decode uses the first position's worth of row blocks
             f32 = dict(dtype=torch.float32, device=self.dev)
             self.rope = rope_table(max_len, c.head_dim, c.rope_base).to(self.dev)
             self.kcache = torch.zeros(c.num_layers, rows, c.nhead, max_len, c.head_dim, **f32)
@@ -127,6 +130,7 @@ class DecoderEngine:
             self.ws_attn = torch.zeros(rp * c.d_model, **f32)
             self.ws_ffn = torch.zeros(rp * c.ffn_dim, **f32)
             self.ws_logits = torch.zeros(rows, K * c.d_codebook, **f32)
+            self._prefill_positions = pp if pp > 1 else 0
             i16 = dict(dtype=torch.int16, device=self.dev)
             self.ws_h_split = torch.zeros(rp * 3 * c.d_model, **i16)
             self.ws_attn_split = torch.zeros(rp * 3 * c.d_model, **i16)
@@ -142,6 +146,7 @@ class DecoderEngine:
         d.dims.tokens_per_frame = tokens_per_frame
         d.wdtype, d.batch, d.rows, d.max_len = self.wd, batch, rows, max_len
         d.timesteps, d.seq_len, d.n_cond_tokens = timesteps, S, n_cond_tokens
+        d.prefill_positions = self._prefill_positions
         d.layers_host = C.cast(self.layers, C.POINTER(L.LayerWeights))
         d.heads, d.final_norm = L.ptr(self.heads), L.ptr(self.final_norm)
         d.tok_emb, d.tok_proj_w, d.tok_proj_b = L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b)
