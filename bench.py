@@ -101,8 +101,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
-    ap.add_argument("--cfg-scale", type=float, default=6.0)
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 = BASELINE configs[1] (2.56 s clips, batch 8, cfg 6); c4 = configs[3] (10.24 s single pass, "
+                         "batch 4, cfg 1, block_size_audio 1024, 128 video tokens)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 8 for c2, 4 for c4)")
+    ap.add_argument("--cfg-scale", type=float, default=None)
     ap.add_argument("--top-k", type=int, default=250)
     ap.add_argument("--weights", choices=["bf16", "f32"], default="bf16", help="storage of the streamed matrices")
     ap.add_argument("--no-graph", action="store_true")
@@ -110,14 +113,27 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
-    rank, local, world = vdist.init("nccl")
+    # VAURA_BENCH_BACKEND=gloo + VAURA_BENCH_SHARE_GPU=1: exercise the multi-rank control flow on a 1-GPU box
+    # (all ranks on cuda:0, collectives on host copies).  Never used for reported numbers.
+    rank, local, world = vdist.init(os.environ.get("VAURA_BENCH_BACKEND", "nccl"))
+    if os.environ.get("VAURA_BENCH_SHARE_GPU") == "1":
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     L.lib()  # fail loudly before doing anything expensive
 
-    cfg, ccfg = synth.FULL_SAMPLER, synth.FULL_CODEC
+    long_ctx = args.workload == "c4"
+    global T_FRAMES, TV
+    if long_ctx:
+        T_FRAMES, TV = 880, 128
+    if args.batch is None:
+        args.batch = 4 if long_ctx else 8
+    if args.cfg_scale is None:
+        args.cfg_scale = 1.0 if long_ctx else 6.0   # the CFG null embedding is fixed at 32 tokens (vaura_model.py:790-793)
+    cfg = synth.SamplerCfg(block_size_audio=1024) if long_ctx else synth.FULL_SAMPLER
+    ccfg = synth.FULL_CODEC
     B = args.batch
     first, _ = vdist.shard(B * world, rank, world)
     sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
@@ -155,11 +171,11 @@ def main():
     rows = 2 * B if args.cfg_scale > 1 else B
     wbytes = 2 if args.weights == "bf16" else 4
     out = {
-        "metric": "audio codec tokens/sec (whole node), 2.56 s clips",
+        "metric": f"audio codec tokens/sec (whole node), {'10.24' if long_ctx else '2.56'} s clips",
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (f"configs[1]: batch={B}/GPU x 2.56 s clips (T=220, 9 codebooks, Tv=32 AVCLIP-shaped features), "
+        "config": {"workload": (f"configs[{3 if long_ctx else 1}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
                    "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
@@ -183,12 +199,13 @@ def main():
         e2.record()
         torch.cuda.synchronize(dev)
         t_loop, t_codec = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
-        lb = decode_loop_bytes(cfg, wbytes, rows, 228)
+        n_steps = T_FRAMES + K_CB - 1
+        lb = decode_loop_bytes(cfg, wbytes, rows, n_steps)
         out["split_ms"] = {"decode_loop": round(t_loop, 3), "codec": round(t_codec, 3)}
         out["decode_loop_roofline"] = {"bound": "hbm", "achieved": round(lb / (t_loop * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": round(lb / (t_loop * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "bytes": lb}
-        out["codec_tflops"] = round(B * 353.8e9 / (t_codec * 1e-3) / 1e12, 2)
+        out["codec_tflops"] = round(B * 1.608e9 * T_FRAMES / (t_codec * 1e-3) / 1e12, 2)   # 1.608 GFLOP per codec frame
 
         # per-kernel: every launch of one eager 228-step pass carries its own start/stop events on the stream
         # it is launched on (hipExtLaunchKernelGGL via vaura_profile_loop) = the interval rocprofv3 reports
@@ -199,7 +216,7 @@ def main():
         cnt = (C.c_int64 * 8)()
         kinds = {"embed": 0, "qkv": 1, "attn": 2, "wo": 3, "w13": 4, "w2": 5, "heads": 6, "sample": 7}
         eng.start_sequence(None)
-        L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), 228, 0xFF, tot, cnt,
+        L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), n_steps, 0xFF, tot, cnt,
                                            int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
         per = {name: 1e3 * tot[bit] / max(1, cnt[bit]) for name, bit in kinds.items()}   # us per launch
         dom = "w13"
@@ -218,7 +235,7 @@ def main():
                            "algorithmic_bytes_per_launch": ab, "avg_us_per_launch": round(per[dom], 3)}
         out["kernel_us"] = {k: round(v, 3) for k, v in per.items()}
 
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not long_ctx:
             out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
 

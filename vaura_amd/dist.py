@@ -49,8 +49,15 @@ def gather_clips(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad.contiguous())
+    src = pad.contiguous()
+    if dist.get_backend() == "gloo" and src.is_cuda:   # debugging aid: gloo collectives on host copies
+        host = src.cpu()
+        outs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(outs, host)
+        out = [o.to(src.device) for o in outs]
+    else:
+        out = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(out, src)
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
@@ -62,6 +69,6 @@ def barrier():
 def max_over_ranks(x: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
