@@ -38,16 +38,17 @@ def algorithmic_bytes_per_launch(kind: str, cfg: synth.SamplerCfg, wbytes: int, 
     """Weight bytes a launch of each GEMV kind must stream."""
     D, F = cfg.d_model, cfg.ffn_dim
     n = {"qkv": 3 * D * D, "wo": D * D, "w13": 2 * F * D, "w2": D * F, "heads": cfg.num_codebooks * cfg.d_codebook * D}[kind]
-    return float(n * wbytes)
+    return float(n * (2 if kind == "heads" and wbytes == 1 else wbytes))   # fp8 keeps the heads in bf16
 
 
 def decode_loop_bytes(cfg: synth.SamplerCfg, wbytes: int, rows: int, steps: int) -> float:
     """sum_L [ W*b_w + 24*2*Bs*1536*b_kv*(L+1) ], fp32 KV (SURVEY.md §8d with b_kv = 4)."""
     D, F = cfg.d_model, cfg.ffn_dim
-    W = cfg.num_layers * (3 * D * D + D * D + 3 * F * D) + cfg.num_codebooks * cfg.d_codebook * D
+    Wb = cfg.num_layers * (3 * D * D + D * D + 3 * F * D) * wbytes + \
+        cfg.num_codebooks * cfg.d_codebook * D * (2 if wbytes == 1 else wbytes)
     tot = 0.0
     for Lc in range(1, steps + 1):
-        tot += W * wbytes + cfg.num_layers * 2 * rows * D * 4 * (Lc + 1)
+        tot += Wb + cfg.num_layers * 2 * rows * D * 4 * (Lc + 1)
     return tot
 
 
@@ -107,7 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 8 for c2, 4 for c4)")
     ap.add_argument("--cfg-scale", type=float, default=None)
     ap.add_argument("--top-k", type=int, default=250)
-    ap.add_argument("--weights", choices=["bf16", "f32"], default="bf16", help="storage of the streamed matrices")
+    ap.add_argument("--weights", choices=["bf16", "f32", "fp8"], default="bf16", help="storage of the streamed matrices")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -169,7 +170,7 @@ def main():
 
     tokens = world * B * K_CB * T_FRAMES * args.steps
     rows = 2 * B if args.cfg_scale > 1 else B
-    wbytes = 2 if args.weights == "bf16" else 4
+    wbytes = {"bf16": 2, "f32": 4, "fp8": 1}[args.weights]
     out = {
         "metric": f"audio codec tokens/sec (whole node), {'10.24' if long_ctx else '2.56'} s clips",
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,

@@ -22,7 +22,10 @@
  *
  * Streamed-weight layout ("MFMA tiles"): an (N x K) matrix, N%16==0, K%32==0, is stored as
  *     [N/16][K/32][64 lanes][8]  with lane = (n%16) + 16*((k%32)/8), element j = k%8
- *   (fp32: [N/16][K/32][2 halves][64 lanes][4]); see vaura_pack_weight().
+ *   (fp32: [N/16][K/32][2 halves][64 lanes][4];
+ *    fp8:  [N/16][K/64][64 lanes][16 bytes] = the lane's 8 values of the even then of the odd k-group, K%64==0,
+ *          followed by float scale[N], scale[n] = smallest power of two with max|W[n,:]| <= 448*scale[n]);
+ *   see vaura_pack_weight().
  */
 #ifndef VAURA_HIP_H
 #define VAURA_HIP_H
@@ -44,7 +47,9 @@ typedef enum vaura_status {
   VAURA_ERR_STATE = -4      /* e.g. step graph not built                   */
 } vaura_status;
 
-typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1 } vaura_wdtype;
+/* storage of the streamed matrices.  VAURA_W_FP8 (BASELINE configs[4]; no reference counterpart): OCP e4m3 with
+ * one power-of-two scale per output row, for the four per-layer matrices; heads / conditioning stay bf16.   */
+typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1, VAURA_W_FP8 = 2 } vaura_wdtype;
 
 /* ---- model geometry: configs/modules/samplers/llama_9cbs.yaml:3-17 + sampler/llama.py:308-361 */
 typedef struct vaura_dims {
@@ -97,7 +102,7 @@ typedef struct vaura_decoder {
                                 prompt is teacher-forced in chunks of that many positions per pass (bf16 path) */
 
   const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
-  const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles           llama.py:356-361 */
+  const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles (bf16 when wdtype is FP8) llama.py:356-361 */
   const float* final_norm;   /* (d_model)                                          llama.py:355 */
   const float* tok_emb;      /* (K, vocab+1, codebook_dim)                         llama.py:392-404 */
   const float* tok_proj_w;   /* (K, tok_dim, codebook_dim) weight-norm folded      llama.py:405-409 */
@@ -200,7 +205,7 @@ int vaura_gemv(const void* w, int wdtype, const float* x, const float* gain, con
  * v_mfma_f32_16x16x32_bf16.  ss_in (row_blocks, n_ss_in, 16): partial sums of squares of the raw input
  * (fused RMSNorm) or NULL.  Optional outputs: fp32 packed rows, split rows of out*gain_out, partial
  * sums of squares of out.  epilogue: 0 store, 1 +residual, 2 SwiGLU pairs, 4 row-major logits.       */
-int vaura_gemv_bf16(const void* w, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+int vaura_gemv_bf16(const void* w, int wdtype /* BF16 | FP8 */, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
                     uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s);
 /* packed rows (rows x C) fp32 [* gain] -> split rows (3 * rows_padded * C bf16) [+ partial sums of squares] */

@@ -92,6 +92,89 @@ def test_gemv_variants(K, N, epi, norm, rows, wdtype):
     assert rel_err(got, ref) < 2e-5, rel_err(got, ref)
 
 
+SPLIT_GEMV_CASES = [
+    # K, N, epilogue, norm, rows
+    (1536, 4608, L.EPI_STORE, True, 16),
+    (1536, 1536, L.EPI_RESID, False, 5),
+    (1536, 8192, L.EPI_SWIGLU, True, 16),
+    (4096, 1536, L.EPI_RESID, False, 16),
+    (1536, 9216, L.EPI_LOGITS, True, 7),
+    (1536, 4608, L.EPI_STORE, True, 40),
+]
+
+
+@pytest.mark.parametrize("wdtype", [L.W_BF16, L.W_FP8])
+@pytest.mark.parametrize("K,N,epi,norm,rows", SPLIT_GEMV_CASES)
+def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
+    """vaura_gemv_bf16: activations as exact hi/mid/lo bf16 planes, bf16 or fp8 weights, fused RMSNorm via
+    partial sums of squares, optional split / sum-of-squares outputs for the next kernel.  The fp8 case is
+    checked against the SAME fp64 product on the dequantised matrix (quant.fp8_effective_weight)."""
+    from vaura_amd import quant
+    g = torch.Generator().manual_seed(K + N + epi + rows + 1)
+    w = torch.randn(N, K, generator=g) * 0.02
+    x = torch.randn(rows, K, generator=g)
+    gain = torch.rand(K, generator=g) + 0.5 if norm else None
+    gain_out = torch.rand(N // 2 if epi == L.EPI_SWIGLU else N, generator=g) + 0.5
+    eps = 1e-5
+    n_out = N // 2 if epi == L.EPI_SWIGLU else N
+    res = torch.randn(rows, n_out, generator=g) if epi == L.EPI_RESID else None
+    if epi == L.EPI_SWIGLU:
+        F_ = N // 2
+        w = torch.stack([w[:F_].view(F_ // 16, 16, K), w[F_:].view(F_ // 16, 16, K)], dim=1).reshape(N, K)
+    w_eff = quant.fp8_effective_weight(w) if wdtype == L.W_FP8 else synth.to_bf16_exact(w)
+    # the producer's side of the fused norm: x*gain travels as planes, sum(x^2) as per-tile partials
+    xd = x.to(DEV)
+    xs, ss = ops.split_rows(ops.pack_rows(xd), rows, K, gain.to(DEV) if norm else None, want_ss=norm)
+    x64 = x.double()
+    xn = x64 if gain is None else (x64 * gain.double()) * torch.rsqrt(torch.mean(x64 * x64, dim=-1, keepdim=True) + eps)
+    y = xn @ w_eff.double().t()
+    if epi == L.EPI_SWIGLU:
+        yv = y.view(rows, N // 32, 2, 16)
+        ref = (F.silu(yv[:, :, 0]) * yv[:, :, 1]).reshape(rows, n_out)
+    elif epi == L.EPI_RESID:
+        ref = res.double() + y
+    else:
+        ref = y
+    wp = ops.pack_weight(w.to(DEV) if wdtype == L.W_FP8 else w_eff.to(DEV), wdtype)
+    resp = ops.pack_rows(res.to(DEV)) if res is not None else None
+    want = epi != L.EPI_LOGITS
+    if epi == L.EPI_SWIGLU:
+        gain_out = torch.ones(n_out)     # the SwiGLU output feeds w2 directly: no norm gain in between
+    out, osp, oss = ops.gemv_bf16(wp, xs, rows, N, K, epi, ss_in=ss if norm else None, residual=resp,
+                                  gain_out=gain_out.to(DEV) if want and epi != L.EPI_SWIGLU else None, want_split=want,
+                                  want_ss=want and epi != L.EPI_SWIGLU, eps=eps, wdtype=wdtype)
+    got = out.cpu() if epi == L.EPI_LOGITS else ops.unpack_rows(out, rows, n_out).cpu()
+    assert rel_err(got.double(), ref) < 3e-6, rel_err(got.double(), ref)
+    if want:
+        planes = ops.unsplit_rows(osp, rows, n_out).cpu()
+        # the planes add up to out*gain_out exactly (fp32 sums of 8-bit pieces are exact)
+        assert torch.equal((planes[0] + planes[1]) + planes[2], got * gain_out)
+        if oss is not None:
+            ssum = oss.view(-1, n_out // 16, 16).sum(1).reshape(-1)[:rows].cpu()
+            assert rel_err(ssum, (got * got).sum(-1)) < 1e-5
+
+
+def test_fp8_pack_matches_host_quantiser():
+    """Device quantiser (vaura_pack_weight, VAURA_W_FP8) == the torch statement of the format: same
+    power-of-two row scales, same round-to-nearest-even e4m3 codes, laid out as fp8 tile pairs."""
+    from vaura_amd import quant
+    g = torch.Generator().manual_seed(21)
+    N, K = 48, 128
+    w = torch.randn(N, K, generator=g) * torch.logspace(-4, 1, N)[:, None]
+    w[5] = 0.0
+    w[6, 3] = 448.0 * 2.0 ** -7      # exactly on a scale boundary
+    w[6, 4:] *= 1e-3
+    packed = ops.pack_weight(w.to(DEV), L.W_FP8).cpu()
+    assert packed.numel() == N * K + 4 * N
+    scales = packed[N * K:].view(torch.float32)
+    ref_s = quant.fp8_row_scales(w)
+    assert torch.equal(scales, ref_s)
+    codes = (w / ref_s[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)          # (N, K)
+    # tile pairs: [N/16][K/64][lane = n%16 + 16*q][h*8 + j]  <-  k = kg2*64 + 32*h + 8*q + j
+    ref_tiles = codes.view(N // 16, 16, K // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).reshape(-1)
+    assert torch.equal(packed[:N * K], ref_tiles)
+
+
 def test_gemv_rejects_unsupported_shapes():
     w = torch.zeros(16 * 40 * 4, dtype=torch.uint8, device=DEV)
     x = torch.zeros(16 * 40, device=DEV)

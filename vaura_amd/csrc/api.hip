@@ -44,6 +44,8 @@ static StepProfiler* g_prof = nullptr;
 static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
                     const float* gain_out, float* ss_out, const vaura_decoder* d, int N, int n_pos = 1) {
   Gemv3Args a;
+  // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay bf16
+  a.wq = (d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0; a.wscale = nullptr;
   a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
   a.gain_out = gain_out; a.ss_out = ss_out;
   a.R = n_pos * ((d->rows + 15) / 16);           // prefill: one group of row blocks per position
@@ -139,7 +141,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
 }
 
 static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
-  if (d->wdtype == VAURA_W_BF16) return enqueue_step_bf16(d, sp, sample, s);
+  if (d->wdtype == VAURA_W_BF16 || d->wdtype == VAURA_W_FP8) return enqueue_step_bf16(d, sp, sample, s);
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
   const int rows = d->rows;
@@ -233,7 +235,7 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
   if (rc) return rc;
   if (!sp || n_prefill < 0 || n_steps < 0) return VAURA_ERR_ARG;
   hipStream_t st = as_stream(s);
-  if (n_prefill > 0 && dec->wdtype == VAURA_W_BF16 && dec->prefill_positions > 0) {
+  if (n_prefill > 0 && dec->wdtype != VAURA_W_F32 && dec->prefill_positions > 0) {
     // the caller guarantees state[0] == 0 at entry (vaura_pattern_build + zeroed state)
     for (int p0 = 0; p0 < n_prefill; p0 += dec->prefill_positions) {
       const int n = (n_prefill - p0 < dec->prefill_positions) ? n_prefill - p0 : dec->prefill_positions;

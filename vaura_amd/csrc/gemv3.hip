@@ -1,28 +1,95 @@
 // Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
 #include "gemv3_kernel.h"
 
-template <int G, int NW, int T, int EPI, bool NORM, int XB = 1>
+template <bool FP8, int G, int NW, int T, int EPI, bool NORM, int XB = 1>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   if (n_tiles % T) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB>), dim3((unsigned)(n_tiles / T)), dim3(NW * 64), 0, s, a);
+  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, FP8>), dim3((unsigned)(n_tiles / T)), dim3(NW * 64), 0, s, a);
   return 0;
 }
 
-int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
+template <bool FP8>
+static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
+  if (K == 1536) {
+    if (epilogue == E3_STORE && norm) return launch3<FP8, 6, 8, 2, E3_STORE, true>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<FP8, 6, 8, 1, E3_STORE, false>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<FP8, 6, 8, 1, E3_RESID, false>(a, tiles, s);
+    if (epilogue == E3_SWIGLU && norm) return launch3<FP8, 6, 8, 2, E3_SWIGLU, true>(a, tiles, s);
+    if (epilogue == E3_LOGITS && norm) return launch3<FP8, 6, 8, 3, E3_LOGITS, true>(a, tiles, s);
+  } else if (K == 4096) {
+    if (epilogue == E3_RESID && !norm) return launch3<FP8, 16, 8, 1, E3_RESID, false, 4>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<FP8, 16, 8, 1, E3_STORE, false, 4>(a, tiles, s);
+  }
+  return VAURA_ERR_SHAPE;
+}
+
+int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
+  Gemv3Args a = a0;
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
   if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
   const int64_t tiles = n_weight_rows / 16;
-  if (K == 1536) {
-    if (epilogue == E3_STORE && norm) return launch3<6, 8, 2, E3_STORE, true>(a, tiles, s);
-    if (epilogue == E3_STORE && !norm) return launch3<6, 8, 1, E3_STORE, false>(a, tiles, s);
-    if (epilogue == E3_RESID && !norm) return launch3<6, 8, 1, E3_RESID, false>(a, tiles, s);
-    if (epilogue == E3_SWIGLU && norm) return launch3<6, 8, 2, E3_SWIGLU, true>(a, tiles, s);
-    if (epilogue == E3_LOGITS && norm) return launch3<6, 8, 3, E3_LOGITS, true>(a, tiles, s);
-  } else if (K == 4096) {
-    if (epilogue == E3_RESID && !norm) return launch3<16, 8, 1, E3_RESID, false, 4>(a, tiles, s);
-    if (epilogue == E3_STORE && !norm) return launch3<16, 8, 1, E3_STORE, false, 4>(a, tiles, s);
+  if (a.wq) {
+    a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
+    return dispatch3<true>(a, tiles, K, epilogue, norm, s);
   }
-  return VAURA_ERR_SHAPE;
+  a.wscale = nullptr;
+  return dispatch3<false>(a, tiles, K, epilogue, norm, s);
+}
+
+// ---------------------------------------------------------------------------- fp8 weight ingress
+// power-of-two row scale: the smallest 2^E with amax <= 448 * 2^E (448 = largest e4m3 value)
+__global__ void fp8_row_scale_kernel(const float* __restrict__ src, float* __restrict__ scale, int K) {
+  const float* row = src + (size_t)blockIdx.x * K;
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, fabsf(row[k]));
+  mx = wave_max(mx);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    float sc = 1.f;
+    if (mx > 0.f) {
+      int e;
+      const float m = frexpf(mx, &e);           // mx = m * 2^e, m in [0.5, 1);  448 = 0.875 * 2^9
+      sc = ldexpf(1.f, m <= 0.875f ? e - 9 : e - 8);
+    }
+    scale[blockIdx.x] = sc;
+  }
+}
+
+__global__ void fp8_pack_kernel(const float* __restrict__ src, const float* __restrict__ scale, u32x4* __restrict__ dst,
+                                int64_t N, int K) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one lane's 16 bytes
+  if (gid >= N * (K / 64) * 4) return;
+  const int lane = (int)(gid & 63);
+  const int64_t pair = gid >> 6;
+  const int kg2 = (int)(pair % (K / 64));
+  const int64_t tile = pair / (K / 64);
+  const int64_t n = tile * 16 + (lane & 15);
+  const float inv = 1.0f / scale[n];            // exact: power of two
+  const float* p = src + n * K + (int64_t)kg2 * 64 + 8 * (lane >> 4);
+  uint32_t w[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float* e = p + 32 * h + 4 * j;
+      int v = __builtin_amdgcn_cvt_pk_fp8_f32(e[0] * inv, e[1] * inv, 0, false);
+      v = __builtin_amdgcn_cvt_pk_fp8_f32(e[2] * inv, e[3] * inv, v, true);
+      w[2 * h + j] = (uint32_t)v;
+    }
+  dst[gid] = u32x4{w[0], w[1], w[2], w[3]};
+}
+
+int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s) {
+  if ((N % 16) || (K % 64)) return VAURA_ERR_SHAPE;
+  float* scale = reinterpret_cast<float*>(static_cast<char*>(dst) + (size_t)N * (size_t)K);
+  VA_LAUNCH(fp8_row_scale_kernel, dim3((unsigned)N), dim3(256), 0, s, src, scale, (int)K);
+  const int64_t total = N * (K / 64) * 4;
+  VA_LAUNCH(fp8_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, (const float*)scale,
+            reinterpret_cast<u32x4*>(dst), N, (int)K);
+  return 0;
 }
 
 // ---------------------------------------------------------------------------- op-level access
@@ -53,11 +120,13 @@ int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* 
   return 0;
 }
 
-int vaura_gemv_bf16(const void* w, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+int vaura_gemv_bf16(const void* w, int wdtype, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
                     uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s) {
   if (!w || !x_split || rows <= 0) return VAURA_ERR_ARG;
+  if (wdtype != VAURA_W_BF16 && wdtype != VAURA_W_FP8) return VAURA_ERR_DTYPE;
   Gemv3Args a;
+  a.wq = wdtype == VAURA_W_FP8; a.wscale = nullptr;
   a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
   a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
   a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K;

@@ -23,7 +23,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 enum { E3_STORE = 0, E3_RESID = 1, E3_SWIGLU = 2, E3_LOGITS = 4 };
 
 struct Gemv3Args {
-  const void* W;          // bf16 MFMA tiles
+  const void* W;          // bf16 MFMA tiles, or fp8 tile pairs + per-row scales (wq = 1)
+  int wq;                 // 0: bf16 weights, 1: fp8 e4m3 weights with power-of-two row scales
+  const float* wscale;    // wq = 1: (weight rows) power-of-two scales (set by the launcher: they follow the tiles)
   const uint16_t* XP;     // split rows (rows x K)
   const float* ss_in;     // NORM: (R, n_ss_in, 16) partial sums of squares of the raw input rows
   int n_ss_in;
@@ -75,14 +77,31 @@ __device__ __forceinline__ void store_split4(uint16_t* base, int row, int c0, in
   p[split_index16(rb, 2, oct, m, C) * 2 + half] = lo;
 }
 
+// fp8 weights ("fp8 tile pairs"): [N/16][K/64][64 lanes][16 bytes]; bytes 0..7 of a lane are its 8 e4m3
+// values of the even 32-deep k-group, bytes 8..15 those of the odd one (same lane->(n, k) map as the bf16
+// tiles), followed by float scale[N].  e4m3 -> bf16 is exact (3 significand bits), the row scale is a power
+// of two applied to the fp32 sum, so the kernel computes exactly what the bf16 path computes on the
+// dequantised matrix  W_eff = fp8 * scale.
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
+  const f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
+  const float e0 = p0[0], e1 = p0[1], e2 = p1[0], e3 = p1[1], e4 = p2[0], e5 = p2[1], e6 = p3[0], e7 = p3[1];
+  const u32x4 r = {(f2u(e0) >> 16) | (f2u(e1) & 0xffff0000u), (f2u(e2) >> 16) | (f2u(e3) & 0xffff0000u),
+                   (f2u(e4) >> 16) | (f2u(e5) & 0xffff0000u), (f2u(e6) >> 16) | (f2u(e7) & 0xffff0000u)};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 __device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a)); }
 
 // ABL: ablation bits for tools/microbench only (0 in the product): 1 = no MFMA, 2 = no x loads, 4 = no weight
 // loads, 8 = same k-slice order in every workgroup.
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
 // been consumed, for depths whose three planes do not fit the register budget at once)
-template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0>
+template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, bool FP8 = false>
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
+  static_assert(!FP8 || (G % 2 == 0 && (G / XB) % 2 == 0), "fp8 tile pairs hold two k-groups per lane");
+  constexpr int GW = FP8 ? G / 2 : G;   // weight registers (u32x4) per tile
   constexpr int K = 32 * G * NW;
   constexpr int KG = K / 32;
   constexpr int GB = G / XB;
@@ -103,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 
   // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
   // block; a prefill pass loops row blocks (one per prompt position) over the same registers
-  u32x4 wb[T][G];
+  u32x4 wb[T][GW];
 
   auto row_block = [&](const int rb, const bool first) {
     const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
@@ -125,10 +144,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
           for (int p = 0; p < 3; ++p)
             xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
         }
+        if (!FP8 || (g & 1) == 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
-          wb[t][g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
+          for (int t = 0; t < T; ++t) {
+            const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((w * G + g) >> 1)
+                                  : (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+            wb[t][FP8 ? g / 2 : g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
+          }
         }
       }
     } else {
@@ -160,11 +182,17 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
       for (int g = 0; g < GB; ++g) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const bf16x8 wf = __builtin_bit_cast(bf16x8, wb[t][b * GB + g]);
+          bf16x8 wf;
+          if constexpr (FP8) {
+            const u32x4 pr = wb[t][(b * GB + g) / 2];
+            wf = (g & 1) ? fp8x8_to_bf16(pr.z, pr.w) : fp8x8_to_bf16(pr.x, pr.y);
+          } else {
+            wf = __builtin_bit_cast(bf16x8, wb[t][b * GB + g]);
+          }
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
             if constexpr (ABL & 1) {
-              asm volatile("" ::"v"(wb[t][b * GB + g]), "v"(xb[g][p]));
+              asm volatile("" ::"v"(wf), "v"(xb[g][p]));
             } else {
               acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xb[g][p]), acc[t][p], 0, 0, 0);
             }
@@ -199,6 +227,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
         f32x4 sacc = red[0][t][lane];
 #pragma unroll
         for (int i = 1; i < NW; ++i) sacc += red[i][t][lane];
+        if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
         v[t] = sacc * rinv;
       }
       const int row = rb * 16 + m;

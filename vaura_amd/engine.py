@@ -40,7 +40,11 @@ class DecoderEngine:
         _require_cuda(device)
         self.cfg = cfg
         self.dev = torch.device(device)
-        self.wd = {"f32": L.W_F32, "bf16": L.W_BF16}[wdtype]
+        # "fp8": e4m3 + power-of-two row scales for the four per-layer matrices (BASELINE configs[4]); the codebook
+        # heads stay bf16.  The model then IS the one with weights quant.fp8_effective_weight(W): same kernels,
+        # same exact-fp32 activation arithmetic.
+        self.wd = {"f32": L.W_F32, "bf16": L.W_BF16, "fp8": L.W_FP8}[wdtype]
+        head_wd = L.W_BF16 if wdtype == "fp8" else self.wd
         self.wdtype = wdtype
         self.lib = L.lib()
         D, F, K = cfg.d_model, cfg.ffn_dim, cfg.num_codebooks
@@ -60,7 +64,7 @@ class DecoderEngine:
                 lw[l].ffn_norm = L.ptr(self._dev(sd[p + "ffn_norm.weight"]))
             self.layers = lw
             heads = torch.cat([sd[f"lm_heads.{k}.weight"].float() for k in range(K)], dim=0)
-            self.heads = self._pack(heads, self.wd)
+            self.heads = self._pack(heads, head_wd)
             self.final_norm = self._dev(sd["norm.weight"])
             self.fc1 = self._pack(sd["cls_embeddings.projection.fc1.weight"], L.W_F32)
             self.fc2 = self._pack(sd["cls_embeddings.projection.fc2.weight"], L.W_F32)
@@ -117,7 +121,7 @@ class DecoderEngine:
         if self._shape == key:
             return
         with torch.cuda.device(self.dev):
-            pp = self.PREFILL_POSITIONS if self.wdtype == "bf16" else 1
+            pp = self.PREFILL_POSITIONS if self.wdtype != "f32" else 1
             rp = self._rows_padded(rows) * pp     # decode uses the first position's worth of row blocks
             f32 = dict(dtype=torch.float32, device=self.dev)
             self.rope = rope_table(max_len, c.head_dim, c.rope_base).to(self.dev)

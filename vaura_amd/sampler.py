@@ -73,7 +73,7 @@ class Transformer(nn.Module):
                                       norm_eps=layer_norm_eps, rope_base=c.rope_base, initializer_range=0.02)
         self.audio_tokens_per_video_frame: Optional[int] = None
         self.codebook_pattern = None
-        self.weight_dtype = weight_dtype  # storage of the streamed matrices on the device: "bf16" | "f32"
+        self.weight_dtype = weight_dtype  # storage of the streamed matrices on the device: "bf16" | "f32" | "fp8"
 
         D, F = c.d_model, c.ffn_dim
         shapes = {
