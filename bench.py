@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--top-k", type=int, default=250)
     ap.add_argument("--weights", choices=["bf16", "f32", "fp8"], default="bf16", help="storage of the streamed matrices")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="experiment: codec + gather of batch i on a second stream (slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -146,12 +147,24 @@ def main():
               clip_base=first, use_graph=not args.no_graph)
     counts = [B] * world
 
+    # Everything runs on one non-null HIP stream.  --overlap (experiment, measured SLOWER: 268 vs 255 ms per batch —
+    # the codec's full-chip grids delay the latency-bound GEMVs of the next batch's decode loop) puts codec + gather
+    # of batch i on a second stream next to the decode loop of batch i+1.
+    s_loop = torch.cuda.Stream(dev)
+    s_post = torch.cuda.Stream(dev) if args.overlap else s_loop
+
     def step():
-        codes = eng.generate_codes(feats, T_FRAMES, **kw)
-        wav = codec.decode(codes)
-        if world > 1:  # the single exchange of the job: final gather of tokens + waveform over RCCL
-            vdist.gather_clips(codes.to(torch.int32), counts)
-            vdist.gather_clips(wav, counts)
+        with torch.cuda.stream(s_loop):
+            codes = eng.generate_codes(feats, T_FRAMES, **kw)
+            done = torch.cuda.Event()
+            done.record(s_loop)
+        with torch.cuda.stream(s_post):
+            s_post.wait_event(done)
+            codes.record_stream(s_post)
+            wav = codec.decode(codes)
+            if world > 1:  # the single exchange of the job: final gather of tokens + waveform over RCCL
+                vdist.gather_clips(codes.to(torch.int32), counts)
+                vdist.gather_clips(wav, counts)
         return codes, wav
 
     for _ in range(args.warmup):
@@ -180,15 +193,21 @@ def main():
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
                    "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
-                   "weights": (f"{args.weights} storage of streamed matrices (synthetic checkpoint is bf16-representable: exact), "
-                               "fp32 activations / accumulate / KV cache; codec fp32"),
-                   "hipgraph": not args.no_graph},
+                   "weights": ({"bf16": "bf16 storage of the streamed matrices (synthetic checkpoint is bf16-representable: exact)",
+                                "f32": "fp32 storage of the streamed matrices",
+                                "fp8": "fp8 e4m3 + power-of-two row scales for the per-layer matrices, bf16 heads (a different "
+                                       "model than the bf16 one: not the headline configuration)"}[args.weights]
+                               + "; fp32 activations / accumulate / KV cache; codec on (hi, lo) fp16 pairs, fp32 accumulate"),
+                   "hipgraph": not args.no_graph,
+                   "streams": "decode loop of batch i+1 overlaps codec+gather of batch i (two HIP streams)" if args.overlap
+                              else "one non-null HIP stream"},
         "sec_audio_per_sec": round(world * B * T_FRAMES * HOP / 44100.0 * args.steps / elapsed, 2),
     }
 
     if rank == 0 and not args.no_extras:
         # ---- split of one step + dominant-kernel roofline, measured live with HIP events
         torch.cuda.synchronize(dev)
+        torch.cuda.set_stream(s_loop)    # same stream as the timed region; the events below are recorded on it
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         reps = max(2, args.steps)
         e0.record()

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from .engine import off_null_stream
 from .patterns import DelayedPatternProvider
 from .utils import instantiate_from_config, sample_from_logits
 
@@ -128,15 +129,19 @@ class VAURAModel(nn.Module):
         start = Tp + 1  # Pattern.get_first_step_with_timesteps(Tp), delayed pattern
         greedy = not (use_sampling and temp > 0.0)
         noise = None if greedy else self._exp_noise(S - start, B * K, self.sampler.d_codebook)
-        codes = eng.generate_codes(
-            vis.float(), max_new_tokens, prompt=audio if Tp else None, use_sampling=use_sampling, temp=temp, top_k=top_k,
-            top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed, clip_base=self.clip_base,
-            tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
+        with off_null_stream(eng.dev) as caller:   # decode loop + codec leave HIP's null stream together
+            codes = eng.generate_codes(
+                vis.float(), max_new_tokens, prompt=audio if Tp else None, use_sampling=use_sampling, temp=temp,
+                top_k=top_k, top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed,
+                clip_base=self.clip_base, tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
+            out_codes = codes[..., (Tp if remove_prompts else 0):max_new_tokens]
+            generated_audio = self.audio_encoder.decode([(out_codes[..., :K, :], None)])
+        if caller is not None:
+            codes.record_stream(caller)
+            generated_audio.record_stream(caller)
         # the reference's post-conditions (:550-572), checked once on the finished tensor
         bad = (codes < 0) | (codes > self.sampler.d_codebook)
         assert not bool(bad.any()), "generated sequence is incomplete or out of range"
-        out_codes = codes[..., (Tp if remove_prompts else 0):max_new_tokens]
-        generated_audio = self.audio_encoder.decode([(out_codes[..., :K, :], None)])
         return {"generated_audio": generated_audio, "s_attn_weights": None, "mha_attn_weights": None,
                 "sampled_indices": out_codes if return_sampled_indices else None}
 
