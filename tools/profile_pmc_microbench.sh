@@ -10,6 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$ROOT/tools/microbench/gemv_bench
+[ -x $B ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I$ROOT/include -I$ROOT/vaura_amd/csrc $B.hip -o $B
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/mb_$C -- $B "g3 " > $OUT/mb_$C.log 2>&1
 done
