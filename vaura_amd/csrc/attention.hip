@@ -176,6 +176,171 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Decode step for caches of at most 256 positions (every 2.56 s configuration: S = 229): ONE memory round
+// trip.  The generic kernel above pays four dependent HBM round trips at L > 128 (K chunk, K chunk, V chunk,
+// V chunk: 4.4 us at L = 1 -> 13.1 us at L = 228).  Here every cached K and V row of the (row, head) is
+// requested before anything else — the addresses need only `pos` — and lands in registers (512 threads x
+// 96 VGPRs) while the new q/k/v are gathered, rotated and appended; scores, a per-wave softmax (running max
+// per wave, combined once across the 8 waves, flash-decoding style) and P.V then run out of registers with two
+// workgroup barriers in total.
+#define ATT1_THREADS 512
+
+// NU = number of 64-position passes that hold cached rows (0..4).  One straight-line body per NU: the compiler
+// then waits with exact vmcnt values (vmcnt retires in order), and short caches issue no dead loads.
+template <int HD, int NU>
+__device__ __forceinline__ void attention256_body(const float* __restrict__ qkv, const float* __restrict__ rope,
+                                                  float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ out,
+                                                  uint16_t* __restrict__ outp, int n_head, int pos, f32x4* sqkv,
+                                                  f32x4 (*wacc)[HD / 4], float* wm, float* wl) {
+  constexpr int QUADS = HD / 4;   // 24
+  constexpr int QPL = QUADS / 8;  // 3
+  constexpr int NW = ATT1_THREADS / 64;
+  constexpr int NUA = NU > 0 ? NU : 1;
+  const f32x4* sq4 = sqkv;
+  const f32x4* sk4 = sqkv + QUADS;
+  const f32x4* sv4 = sqkv + 2 * QUADS;
+  const int h = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int D = n_head * HD;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const int sub = tid & 7;    // 16-B column group (x3) of a position
+  const int prow = tid >> 3;  // 0..63: position inside a pass of 64
+
+  // ---- 1. requests first: the new q/k/v quad + its rope entry, then the whole cache of this (row, head), K
+  //         before V.  Slots past the end of the last pass re-read the last cached row and are masked below.
+  const int gt = min(tid, 3 * QUADS - 1);
+  const int which = gt / QUADS, cq = gt % QUADS;
+  const f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
+  const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
+  __builtin_amdgcn_sched_barrier(0);   // keep these two first in program order (the scheduler sinks them otherwise)
+  f32x4 kf[NUA][QPL], vf[NUA][QPL];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int p = min(u * 64 + prow, pos - 1);
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) kf[u][i] = reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i];
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int p = min(u * 64 + prow, pos - 1);
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i];
+  }
+
+  // ---- 2. rotate q and k (v passes through), park them in LDS, append k and v to the cache.  Every thread
+  //         rotates and writes LDS (threads past the 72 real quads hit a scratch slot): an unconditional use keeps
+  //         the compiler from sinking the two loads into a branch behind the cache loads.
+  f32x4 y;
+  y[0] = gx[0] * gcs[0] - gx[1] * gcs[1];
+  y[1] = gx[1] * gcs[0] + gx[0] * gcs[1];
+  y[2] = gx[2] * gcs[2] - gx[3] * gcs[3];
+  y[3] = gx[3] * gcs[2] + gx[2] * gcs[3];
+  if (which == 2) y = gx;   // v is not rotated
+  sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
+  if (tid >= QUADS && tid < 3 * QUADS)
+    reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD)[cq] = y;
+  __syncthreads();
+
+  // ---- 3. scores: 8 lanes per position; the new position's score is computed by every 8-lane group
+  f32x4 qf[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) qf[i] = sq4[sub + 8 * i];
+  auto dot8 = [&](const f32x4* kv) {
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kv[i][c], d);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    return d;
+  };
+  f32x4 knew[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) knew[i] = sk4[sub + 8 * i];
+  const float snew = dot8(knew) * scale;
+  float sc[NUA];
+  float m = snew;   // every wave's running max includes the new position, so it is finite
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const float d = dot8(kf[u]) * scale;
+    sc[u] = (u * 64 + prow < pos) ? d : -INFINITY;
+    m = fmaxf(m, sc[u]);
+  }
+  m = wave_max(m);
+  // ---- 4. per-wave softmax numerators and P.V partial (relative to the wave's max)
+  float l = 0.f;
+  f32x4 av[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const float e = expf(sc[u] - m);   // exp(-inf) = 0 for the masked slots (they hold a finite, valid row)
+    if (sub == 0) l += e;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) av[i] += vf[u][i] * e;
+  }
+  l = wave_sum(l);
+#pragma unroll
+  for (int i = 0; i < QPL; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = av[i][c];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      av[i][c] = v;
+    }
+  const int wv = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) wacc[wv][lane + 8 * i] = av[i];
+  }
+  if (lane == 0) { wm[wv] = m; wl[wv] = l; }
+  __syncthreads();
+
+  // ---- 5. combine the 8 waves and the new position
+  if (tid < QUADS) {
+    float M = wm[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, wm[w]);
+    const float en = expf(snew - M);
+    float denom = en;
+    f32x4 o = sv4[tid] * en;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = expf(wm[w] - M);
+      denom += f * wl[w];
+      o += wacc[w][tid] * f;
+    }
+    o *= 1.0f / denom;
+    reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
+    if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
+    float* __restrict__ out, uint16_t* __restrict__ outp, int n_head, int max_len, const int32_t* __restrict__ pos_dev,
+    int pos_host) {
+  constexpr int QUADS = HD / 4;
+  __shared__ f32x4 sqkv[3 * QUADS + 64];   // rotated q | rotated k | v of the new position | scratch
+  __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
+  __shared__ float wm[ATT1_THREADS / 64], wl[ATT1_THREADS / 64];
+  const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos), pos <= 255
+  float* kc = kcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
+  float* vc = vcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
+  switch ((pos + 63) >> 6) {
+    case 0: attention256_body<HD, 0>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 1: attention256_body<HD, 1>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 2: attention256_body<HD, 2>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 3: attention256_body<HD, 3>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    default: attention256_body<HD, 4>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+  }
+}
+
 // rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
 template <int HD>
 __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qkv, const float* __restrict__ rope,
@@ -209,6 +374,11 @@ int va_launch_attention(const float* qkv, const float* rope, float* kc, float* v
                         int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
+  if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
+    VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, out, outp,
+              n_head, max_len, pos_dev, pos_host);
+    return 0;
+  }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
   VA_LAUNCH(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, rope, kc, vc, out, outp,
             n_head, max_len, pos_dev, pos_host, 0);
