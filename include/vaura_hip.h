@@ -130,6 +130,8 @@ typedef struct vaura_decoder {
   uint16_t* ws_ffn_split;    /* split rows (rows x ffn_dim)                         */
   float*    ws_ss;           /* (row_blocks, d_model/16, 16)                        */
   const float* first_norm;   /* layers[0].attn_norm (device), gain applied by the embed kernel */
+  float*    ws_attn_part;    /* optional (rows, n_head, 8, head_dim + 8): partials of the range-split attention used when
+                                rows*n_head < 256 and max_len > 256 (vaura_attention_splits); NULL -> never split       */
 } vaura_decoder;
 
 /* -------------------------------------------------------------------------------------------
@@ -215,6 +217,13 @@ int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* 
 int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
                          int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s);
 
+/* same step with the cached range of every (row, head) split over n_split (2..8) workgroups + a combine
+ * pass; part: (rows, n_head, n_split, head_dim + 8) floats of scratch.                              */
+int vaura_attention_step_split(const float* qkv, const float* rope, float* kcache, float* vcache, float* out, float* part,
+                               int rows, int n_head, int head_dim, int max_len, int pos, int n_split, vaura_stream_t s);
+/* workgroups per (row, head) the decode step uses for this shape when ws_attn_part is given (1 = no split) */
+int vaura_attention_splits(int rows, int n_head, int max_len);
+
 /* -------------------------------------------------------------------------------------------
  * a16 DacModelWrapper.decode (models/modules/dac/model.py:41-48): quantizer.from_codes + DAC
  * decoder (descript-audio-codec 1.0.0, un-vendored).  Weight-norm is folded by the caller.      */
@@ -253,6 +262,9 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
 size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T);
 
 const char* vaura_version(void);
+/* sizeof() of the descriptor structs as compiled into the library (0 dims, 1 layer_weights, 2 sampling, 3 decoder,
+ * 4 conv, 5 codec): a binding checks its mirrored struct layouts against these before the first call.            */
+size_t vaura_struct_size(int which);
 
 #ifdef __cplusplus
 }

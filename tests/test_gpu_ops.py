@@ -213,6 +213,43 @@ def test_attention_step_matches_oracle(rows, steps):
     assert torch.equal(vc[:, :, :steps].cpu(), v_ref[:, :, :steps])
 
 
+@pytest.mark.parametrize("rows,n_split", [(4, 4), (2, 8), (5, 2)])
+def test_range_split_attention_matches_oracle(rows, n_split):
+    """Long-cache decode attention split over several workgroups per (row, head) (configs[3] regime): single steps
+    at positions around every block / split edge against the fp32 restatement, on a cache filled with random
+    (already rotated) keys and values; also the generic one-workgroup kernel on the same inputs."""
+    from oracle.decoder_oracle import apply_rope, rope_table
+    H, hd, D = 16, 96, 1536
+    max_len = 1024
+    g = torch.Generator().manual_seed(rows * 10 + n_split)
+    rope = rope_table(max_len, hd)
+    k_ref = torch.randn(rows, H, max_len, hd, generator=g)
+    v_ref = torch.randn(rows, H, max_len, hd, generator=g)
+    rope_d = rope.to(DEV)
+    for pos in [0, 1, 63, 64, 65, 255, 256, 257, 511, 512, 700, 1023]:
+        qkv = torch.randn(rows, 3 * D, generator=g)
+        q, k, v = qkv.split([D, D, D], dim=-1)
+        q = apply_rope(q.view(rows, 1, H, hd), rope[pos:pos + 1]).transpose(1, 2)
+        k = apply_rope(k.view(rows, 1, H, hd), rope[pos:pos + 1]).transpose(1, 2)
+        kk = torch.cat([k_ref[:, :, :pos], k], dim=2)
+        vv = torch.cat([v_ref[:, :, :pos], v.view(rows, H, 1, hd)], dim=2)
+        sc = torch.matmul(q, kk.transpose(-1, -2)) / math.sqrt(hd)
+        ref = torch.matmul(torch.softmax(sc, -1), vv).transpose(1, 2).reshape(rows, D)
+        for split in (n_split, 1):
+            kc, vc = k_ref.to(DEV), v_ref.to(DEV)
+            qp = ops.pack_rows(qkv.to(DEV))
+            out = ops.attention_step_split(qp, rope_d, kc, vc, rows, H, hd, pos, split) if split > 1 else \
+                ops.attention_step(qp, rope_d, kc, vc, rows, H, hd, pos)
+            got = ops.unpack_rows(out, rows, D).cpu()
+            assert rel_err(got, ref) < 3e-6, (pos, split, rel_err(got, ref))
+            # the new position was appended (by exactly one workgroup), nothing else was touched
+            assert rel_err(kc[:, :, pos].cpu(), k[:, :, 0]) < 1e-6 and torch.equal(vc[:, :, pos].cpu(), v.view(rows, H, hd))
+            if pos > 0:
+                assert torch.equal(kc[:, :, :pos].cpu(), k_ref[:, :, :pos])
+    assert L.lib().vaura_attention_splits(4, 16, 1024) == 4 and L.lib().vaura_attention_splits(16, 16, 1024) == 1
+    assert L.lib().vaura_attention_splits(4, 16, 256) == 1 and L.lib().vaura_attention_splits(1, 16, 1024) == 8
+
+
 SAMPLE_CASES = [("topk1", dict(top_k=1, top_p=0.0)), ("topk128", dict(top_k=128, top_p=0.0)),
                 ("topk250", dict(top_k=250, top_p=0.0)), ("topp90", dict(top_k=250, top_p=0.9)),
                 ("topp30", dict(top_k=0, top_p=0.3)), ("plain", dict(top_k=0, top_p=0.0))]

@@ -42,15 +42,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.vaura_dac_decode(None, 0, 1, 1, 0, 0) == -1
     assert lib.vaura_packed_weight_bytes(4608, 1536, L.W_BF16) == 4608 * 1536 * 2
     assert lib.vaura_packed_weight_bytes(4608, 1536, L.W_F32) == 4608 * 1536 * 4
+    assert lib.vaura_packed_weight_bytes(4608, 1536, L.W_FP8) == 4608 * 1536 + 4608 * 4   # codes + one fp32 scale per row
 
 
 def test_struct_layouts_match_the_header():
-    # sizes the C side was compiled with (LP64): a drift here corrupts every call
-    assert C.sizeof(L.Dims) == 48
-    assert C.sizeof(L.LayerWeights) == 48
-    assert C.sizeof(L.Sampling) == 40
-    assert C.sizeof(L.Conv) == 40
-    assert C.sizeof(L.Decoder) == 48 + 32 + 8 * 15 + 8 * 5 + 8 * 5
+    # the ctypes mirrors against the sizes the C side was compiled with: a drift here corrupts every call
+    lib = L.lib()
+    for which, cls in enumerate([L.Dims, L.LayerWeights, L.Sampling, L.Decoder, L.Conv, L.Codec]):
+        assert C.sizeof(cls) == lib.vaura_struct_size(which), cls.__name__
+    assert C.sizeof(L.Dims) == 48 and C.sizeof(L.Sampling) == 40
+    assert lib.vaura_struct_size(99) == 0
 
 
 def test_sampler_plugin_keeps_reference_state_dict_and_attributes(tiny_sampler_sd):
@@ -137,3 +138,27 @@ def test_synthetic_inputs_are_keyed_by_clip_index():
     n1 = synth.exp_noise(3, 18, 1024, 5)
     n2 = synth.exp_noise(3, 18, 1024, 5)
     assert torch.equal(n1, n2) and float(n1.min()) > 0
+
+
+def test_fp8_format_statement():
+    """vaura_amd.quant states the fp8 storage format of include/vaura_hip.h on the host (the device quantiser is
+    checked against it byte for byte in the gpu suite)."""
+    from vaura_amd import quant
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 128, generator=g) * torch.logspace(-5, 2, 64)[:, None]
+    w[7] = 0.0
+    w[8, 0], w[8, 1:] = 448.0 * 2.0 ** -3, 0.0          # exactly representable maximum: scale must not skip a binade
+    s = quant.fp8_row_scales(w)
+    amax = w.abs().amax(1)
+    assert torch.equal(torch.exp2(torch.log2(s).round()), s)            # powers of two
+    assert bool((amax <= 448.0 * s).all()) and bool((amax[amax > 0] > 224.0 * s[amax > 0]).all())   # the smallest such
+    assert float(s[7]) == 1.0 and float(s[8]) == 2.0 ** -3
+    e = quant.fp8_effective_weight(w)
+    assert torch.equal(e.bfloat16().float(), e)                           # dequantised values are bf16-exact
+    live = amax > 0
+    assert float(((e - w).abs().amax(1)[live] / amax[live]).max()) <= 2.0 ** -4      # e4m3: 3 significand bits
+    sd = {"layers.0.attention.wqkv.weight": w, "layers.0.attention_norm.weight": torch.ones(4),
+          "lm_heads.0.weight": w.clone(), "layers.0.feed_forward.w3.weight": w.clone()}
+    out = quant.fp8_effective_state_dict(sd)
+    assert torch.equal(out["layers.0.attention.wqkv.weight"], e) and torch.equal(out["layers.0.feed_forward.w3.weight"], e)
+    assert out["lm_heads.0.weight"] is sd["lm_heads.0.weight"] and out["layers.0.attention_norm.weight"] is sd["layers.0.attention_norm.weight"]

@@ -48,7 +48,7 @@ class Decoder(C.Structure):
                 ("ws_h", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_attn", C.c_void_p), ("ws_ffn", C.c_void_p),
                 ("ws_logits", C.c_void_p),
                 ("ws_h_split", C.c_void_p), ("ws_attn_split", C.c_void_p), ("ws_ffn_split", C.c_void_p),
-                ("ws_ss", C.c_void_p), ("first_norm", C.c_void_p)]
+                ("ws_ss", C.c_void_p), ("first_norm", C.c_void_p), ("ws_attn_part", C.c_void_p)]
 
 
 class Conv(C.Structure):
@@ -70,6 +70,7 @@ class Codec(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/vaura_hip.h
 SIGNATURES = {
     "vaura_version": (C.c_char_p, []),
+    "vaura_struct_size": (C.c_size_t, [C.c_int]),
     "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "vaura_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "vaura_build_token_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -93,6 +94,9 @@ SIGNATURES = {
     "vaura_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vaura_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "vaura_attention_step_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vaura_attention_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "vaura_attention_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vaura_dac_decode": (C.c_int, [C.POINTER(Codec), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -122,6 +126,10 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for which, cls in enumerate([Dims, LayerWeights, Sampling, Decoder, Conv, Codec]):
+            if C.sizeof(cls) != handle.vaura_struct_size(which):
+                raise VauraHipError(f"{LIB_PATH} was built from a different include/vaura_hip.h: sizeof({cls.__name__}) is "
+                                    f"{handle.vaura_struct_size(which)} there, {C.sizeof(cls)} here (rebuild the library)")
         _lib = handle
     return _lib
 

@@ -108,7 +108,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     if (rc) return rc;
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
     rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
-                             d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, s);
+                             d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
+                             d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     PROF_B(VAURA_K_WO);    // h += Wo.attn ; emit split(h * ffn_norm) + ss               llama.py:259, 279
@@ -160,7 +161,8 @@ static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sa
     // rope + cache append + softmax(qK^T)V                               llama.py:234-257
     PROF_B(VAURA_K_ATTN);
     rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, nullptr, rows,
-                             H, hd, d->max_len, d->state, 0, s);
+                             H, hd, d->max_len, d->state, 0, d->ws_attn_part,
+                             d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     // h += wo . attn                                                      llama.py:259, 279
@@ -199,6 +201,18 @@ static hipGraph_t g_step_graph = nullptr;
 extern "C" {
 
 const char* vaura_version(void) { return "vaura_hip 0.1 (gfx950)"; }
+
+size_t vaura_struct_size(int which) {
+  switch (which) {
+    case 0: return sizeof(vaura_dims);
+    case 1: return sizeof(vaura_layer_weights);
+    case 2: return sizeof(vaura_sampling);
+    case 3: return sizeof(vaura_decoder);
+    case 4: return sizeof(vaura_conv);
+    case 5: return sizeof(vaura_codec);
+    default: return 0;
+  }
+}
 
 int vaura_decode_step(const vaura_decoder* dec, const vaura_sampling* sp, int sample, vaura_stream_t s) {
   int rc = check_decoder(dec);

@@ -341,6 +341,193 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Long caches with few (row, head) pairs (BASELINE configs[3]: 10.24 s single pass, 4 rows x 16 heads = 64
+// workgroups for 256 CUs; also small batches): split the cache range of one (row, head) over n_split workgroups
+// (flash-decoding).  Split z streams positions [z*per, (z+1)*per) in blocks of 256 with the same request-first
+// register scheme as above and an online softmax across blocks; the last split also owns the new position
+// (rotation of k, cache append, its score).  Every split writes (o relative to its max M, M, denominator) to a
+// small workspace; attention_combine_kernel merges the n_split partials, normalises and emits the packed /
+// split-row output.  part layout: [((row * H + h) * n_split + z)][HD + 8] floats, [HD] = M, [HD + 1] = denom.
+#define ATT_PART_STRIDE(HD) ((HD) + 8)
+
+template <int HD, int NU>
+__device__ __forceinline__ void attention_block(const float* __restrict__ kc, const float* __restrict__ vc, int b0, int hi,
+                                                const f32x4* qf, float scale, int sub, int prow, float& m_run, float& l_run,
+                                                f32x4* av) {
+  constexpr int QPL = HD / 32;
+  f32x4 kf[NU][QPL], vf[NU][QPL];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int p = min(b0 + u * 64 + prow, hi - 1);
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) kf[u][i] = reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i];
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int p = min(b0 + u * 64 + prow, hi - 1);
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i];
+  }
+  float sc[NU];
+  float m = m_run;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kf[u][i][c], d);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    sc[u] = (b0 + u * 64 + prow < hi) ? d * scale : -INFINITY;
+    m = fmaxf(m, sc[u]);
+  }
+  m = wave_max(m);                                   // new running max of this wave
+  const float mref = (m == -INFINITY) ? 0.f : m;     // nothing valid yet: every exp below is exp(-inf) = 0
+  const float f = expf(m_run - mref);                // rescale of what the wave has accumulated so far
+  l_run *= f;
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) av[i] *= f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const float e = expf(sc[u] - mref);
+    if (sub == 0) l_run += e;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) av[i] += vf[u][i] * e;
+  }
+  m_run = m;
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
+    float* __restrict__ part, int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
+  constexpr int QUADS = HD / 4;
+  constexpr int QPL = QUADS / 8;
+  constexpr int NW = ATT1_THREADS / 64;
+  __shared__ f32x4 sqkv[3 * QUADS + 64];
+  __shared__ f32x4 wacc[NW][QUADS];
+  __shared__ float wm[NW], wl[NW];
+  const int h = blockIdx.x, row = blockIdx.y, z = blockIdx.z, n_split = gridDim.z, tid = threadIdx.x;
+  const int D = n_head * HD;
+  const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos)
+  const bool last = z == n_split - 1;                // owner of the new position
+  const int per = (pos + n_split * 64 - 1) / (n_split * 64) * 64;
+  const int lo = z * per, hi = min(lo + per, pos);
+  const float scale = 1.0f / sqrtf((float)HD);
+  float* kc = kcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  const int sub = tid & 7, prow = tid >> 3;
+
+  // new q/k/v quad of this head; rotate q (every split) and k (used by the last split only), park in LDS
+  const int gt = min(tid, 3 * QUADS - 1);
+  const int which = gt / QUADS, cq = gt % QUADS;
+  const f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
+  const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);
+  f32x4 y;
+  y[0] = gx[0] * gcs[0] - gx[1] * gcs[1];
+  y[1] = gx[1] * gcs[0] + gx[0] * gcs[1];
+  y[2] = gx[2] * gcs[2] - gx[3] * gcs[3];
+  y[3] = gx[3] * gcs[2] + gx[2] * gcs[3];
+  if (which == 2) y = gx;
+  sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
+  if (last && tid >= QUADS && tid < 3 * QUADS)
+    reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD)[cq] = y;
+  __syncthreads();
+  f32x4 qf[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) qf[i] = sqkv[sub + 8 * i];
+
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 av[QPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float snew = -INFINITY;
+  if (last) {   // score of the new position, computed by every 8-lane group; seeds the running max
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) {
+      const f32x4 kn = sqkv[QUADS + sub + 8 * i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kn[c], d);
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    snew = d * scale;
+    m_run = snew;
+  }
+  for (int b0 = lo; b0 < hi; b0 += 256) {
+    switch (min(4, (hi - b0 + 63) >> 6)) {
+      case 1: attention_block<HD, 1>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
+      case 2: attention_block<HD, 2>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
+      case 3: attention_block<HD, 3>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
+      default: attention_block<HD, 4>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
+    }
+  }
+  l_run = wave_sum(l_run);
+#pragma unroll
+  for (int i = 0; i < QPL; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = av[i][c];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      av[i][c] = v;
+    }
+  const int wv = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) wacc[wv][lane + 8 * i] = av[i];
+  }
+  if (lane == 0) { wm[wv] = m_run; wl[wv] = l_run; }
+  __syncthreads();
+  if (tid < QUADS) {
+    float M = wm[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, wm[w]);
+    const float mref = (M == -INFINITY) ? 0.f : M;
+    const float en = last ? expf(snew - mref) : 0.f;
+    float denom = en;
+    f32x4 o = last ? sqkv[2 * QUADS + tid] * en : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = expf(wm[w] - mref);
+      denom += f * wl[w];
+      o += wacc[w][tid] * f;
+    }
+    float* pp = part + (((size_t)row * n_head + h) * n_split + z) * ATT_PART_STRIDE(HD);
+    reinterpret_cast<f32x4*>(pp)[tid] = o;
+    if (tid == 0) { pp[HD] = M; pp[HD + 1] = denom; }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void attention_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               uint16_t* __restrict__ outp, int n_head, int n_split) {
+  constexpr int QUADS = HD / 4;
+  const int h = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  if (tid >= QUADS) return;
+  const float* pp = part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD);
+  float M = -INFINITY;
+  for (int z = 0; z < n_split; ++z) M = fmaxf(M, pp[z * ATT_PART_STRIDE(HD) + HD]);   // finite: the last split holds the new position
+  float denom = 0.f;
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < n_split; ++z) {
+    const float* pz = pp + z * ATT_PART_STRIDE(HD);
+    const float f = expf(pz[HD] - M);
+    denom += f * pz[HD + 1];
+    o += reinterpret_cast<const f32x4*>(pz)[tid] * f;
+  }
+  o *= 1.0f / denom;
+  const int D = n_head * HD;
+  reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
+  if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
+}
+
 // rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
 template <int HD>
 __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qkv, const float* __restrict__ rope,
@@ -370,10 +557,24 @@ __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qk
   if (which == 2) reinterpret_cast<f32x4*>(vcache + cbase)[cq] = x;
 }
 
+int va_attention_splits(int rows, int n_head, int max_len) {
+  if (max_len <= 256) return 1;
+  const int pairs = rows * n_head;
+  return pairs >= 256 ? 1 : max(1, min(8, 256 / pairs));
+}
+
 int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, uint16_t* outp, int rows,
-                        int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, hipStream_t s) {
+                        int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, float* part, int n_split,
+                        hipStream_t s) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
+  if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
+    if (n_split > 8) return VAURA_ERR_ARG;
+    VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, part,
+              n_head, max_len, pos_dev, pos_host);
+    VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split);
+    return 0;
+  }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
     VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, out, outp,
               n_head, max_len, pos_dev, pos_host);
@@ -408,5 +609,16 @@ int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n
 extern "C" int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
                                     int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s) {
   if (pos < 0 || pos >= max_len) return VAURA_ERR_ARG;
-  return va_launch_attention(qkv, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos, as_stream(s));
+  return va_launch_attention(qkv, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos, nullptr, 1,
+                             as_stream(s));
+}
+
+extern "C" int vaura_attention_splits(int rows, int n_head, int max_len) { return va_attention_splits(rows, n_head, max_len); }
+
+extern "C" int vaura_attention_step_split(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
+                                          float* part, int rows, int n_head, int head_dim, int max_len, int pos, int n_split,
+                                          vaura_stream_t s) {
+  if (pos < 0 || pos >= max_len || !part || n_split < 2 || n_split > 8) return VAURA_ERR_ARG;
+  return va_launch_attention(qkv, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos, part, n_split,
+                             as_stream(s));
 }

@@ -165,6 +165,7 @@ class DecoderEngine:
             self.ws_attn_split = torch.zeros(rp * 3 * c.d_model, **i16)
             self.ws_ffn_split = torch.zeros(rp * 3 * c.ffn_dim, **i16)
             self.ws_ss = torch.zeros((rp // 16) * (c.d_model // 16) * 16, **f32)
+            self.ws_attn_part = torch.zeros(rows * c.nhead * 8 * (c.d_model // c.nhead + 8), **f32)
             crp = self._rows_padded(rows * n_cond_tokens)
             self.cond_in = torch.zeros(crp * c.cond_in, **f32)
             self.cond_tmp = torch.zeros(crp * c.cond_dim, **f32)
@@ -188,6 +189,7 @@ class DecoderEngine:
         d.ws_h_split, d.ws_attn_split = L.ptr(self.ws_h_split), L.ptr(self.ws_attn_split)
         d.ws_ffn_split, d.ws_ss = L.ptr(self.ws_ffn_split), L.ptr(self.ws_ss)
         d.first_norm = self.layers[0].attn_norm
+        d.ws_attn_part = L.ptr(self.ws_attn_part)
         self.dec = d
         self._shape = key
         self._graph_key = None

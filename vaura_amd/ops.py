@@ -68,6 +68,19 @@ def attention_step(qkv_p: torch.Tensor, rope: torch.Tensor, kcache: torch.Tensor
     return out
 
 
+def attention_step_split(qkv_p: torch.Tensor, rope: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, rows: int,
+                         n_head: int, head_dim: int, pos: int, n_split: int) -> torch.Tensor:
+    """attention_step with the cached range of every (row, head) split over `n_split` workgroups + a combine pass."""
+    _cuda(qkv_p, rope, kcache, vcache)
+    max_len = kcache.shape[-2]
+    out = torch.zeros(((rows + 15) // 16 * 16) * n_head * head_dim, dtype=torch.float32, device=qkv_p.device)
+    part = torch.empty(rows * n_head * n_split * (head_dim + 8), dtype=torch.float32, device=qkv_p.device)
+    L.check(L.lib().vaura_attention_step_split(L.ptr(qkv_p), L.ptr(rope), L.ptr(kcache), L.ptr(vcache), L.ptr(out),
+                                               L.ptr(part), rows, n_head, head_dim, max_len, pos, n_split,
+                                               L.current_stream()), "vaura_attention_step_split")
+    return out
+
+
 def sample(logits: torch.Tensor, batch: int, *, use_sampling: bool, temp: float = 1.0, top_k: int = 0,
            top_p: float = 0.0, cfg_scale: float = 1.0, noise: Optional[torch.Tensor] = None, seed: int = 0,
            clip_base: int = 0, step: int = 0) -> torch.Tensor:
