@@ -189,7 +189,8 @@ void vaura_step_graph_free(void);
 /* Measurement aid (bench.py): runs `n_steps` sampled steps eagerly on `s` with a hipEvent pair
  * around every launch of the kernel kinds selected by `kind_mask` (bit = vaura_kernel_kind), then
  * synchronises `s` and reports, per kind, the summed elapsed ms and the launch count (HOST arrays of
- * VAURA_K_COUNT entries).  The only entry point that creates events / synchronises.              */
+ * VAURA_K_COUNT entries).  A stage that is several launches (range-split attention) reports the sum of
+ * its launches per stage.  The only entry point that creates events / synchronises.              */
 typedef enum vaura_kernel_kind {
   VAURA_K_EMBED = 0, VAURA_K_QKV = 1, VAURA_K_ATTN = 2, VAURA_K_WO = 3, VAURA_K_W13 = 4, VAURA_K_W2 = 5,
   VAURA_K_HEADS = 6, VAURA_K_SAMPLE = 7, VAURA_K_COUNT = 8

@@ -24,20 +24,25 @@ static int check_decoder(const vaura_decoder* d) {
 
 // Optional per-launch timing (vaura_profile_loop): every launch of the selected kinds carries its own
 // start/stop events (see VA_LAUNCH), i.e. the interval rocprofv3's kernel trace reports.
-hipEvent_t va_prof_start = nullptr, va_prof_stop = nullptr;
+// A step stage may be more than one launch (range-split attention = split + combine): every launch gets its own
+// pair, a stage's time is the sum over its launches, and `stages` counts the brackets.
+int va_prof_kind = -1;
 struct StepProfiler {
   unsigned mask = 0;
   std::vector<hipEvent_t> ev[VAURA_K_COUNT];
+  int64_t stages[VAURA_K_COUNT] = {};
   void before(int kind) {
     if (!(mask & (1u << kind))) return;
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    ev[kind].push_back(a); ev[kind].push_back(b);
-    va_prof_start = a; va_prof_stop = b;
+    ++stages[kind];
+    va_prof_kind = kind;
   }
-  void after(int) { va_prof_start = nullptr; va_prof_stop = nullptr; }
+  void after(int) { va_prof_kind = -1; }
 };
 static StepProfiler* g_prof = nullptr;
+void va_prof_events(hipEvent_t* a, hipEvent_t* b) {
+  (void)hipEventCreate(a); (void)hipEventCreate(b);
+  g_prof->ev[va_prof_kind].push_back(*a); g_prof->ev[va_prof_kind].push_back(*b);
+}
 #define PROF_B(kind) do { if (g_prof) g_prof->before(kind); } while (0)
 #define PROF_A(kind) do { if (g_prof) g_prof->after(kind); } while (0)
 
@@ -300,7 +305,7 @@ int vaura_profile_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n
     }
     for (hipEvent_t ev : prof.ev[k]) (void)hipEventDestroy(ev);
     total_ms_host[k] = tot;
-    launches_host[k] = (int64_t)n;
+    launches_host[k] = prof.stages[k];
   }
   if (rc) return rc;
   return e == hipSuccess ? 0 : (int)e;

@@ -351,81 +351,86 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
 // split-row output.  part layout: [((row * H + h) * n_split + z)][HD + 8] floats, [HD] = M, [HD + 1] = denom.
 #define ATT_PART_STRIDE(HD) ((HD) + 8)
 
+// One block of up to NU*64 cached positions [b0, hi): request every K and V row first (load), then scores, online
+// softmax update of the wave's running (m, l, av) and P.V (consume).
 template <int HD, int NU>
-__device__ __forceinline__ void attention_block(const float* __restrict__ kc, const float* __restrict__ vc, int b0, int hi,
-                                                const f32x4* qf, float scale, int sub, int prow, float& m_run, float& l_run,
-                                                f32x4* av) {
-  constexpr int QPL = HD / 32;
+struct AttentionBlock {
+  static constexpr int QPL = HD / 32;
   f32x4 kf[NU][QPL], vf[NU][QPL];
+  __device__ __forceinline__ void load(const float* __restrict__ kc, const float* __restrict__ vc, int b0, int hi, int sub,
+                                       int prow) {
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int p = min(b0 + u * 64 + prow, hi - 1);
+    for (int u = 0; u < NU; ++u) {
+      const int p = min(b0 + u * 64 + prow, hi - 1);
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) kf[u][i] = reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i];
+      for (int i = 0; i < QPL; ++i) kf[u][i] = reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int p = min(b0 + u * 64 + prow, hi - 1);
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i];
+    }
   }
+  __device__ __forceinline__ void consume(int b0, int hi, const f32x4* qf, float scale, int sub, int prow, float& m_run,
+                                          float& l_run, f32x4* av) const {
+    float sc[NU];
+    float m = m_run;
 #pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int p = min(b0 + u * 64 + prow, hi - 1);
+    for (int u = 0; u < NU; ++u) {
+      float d = 0.f;
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i];
+      for (int i = 0; i < QPL; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kf[u][i][c], d);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      sc[u] = (b0 + u * 64 + prow < hi) ? d * scale : -INFINITY;
+      m = fmaxf(m, sc[u]);
+    }
+    m = wave_max(m);                                   // new running max of this wave
+    const float mref = (m == -INFINITY) ? 0.f : m;     // nothing valid yet: every exp below is exp(-inf) = 0
+    const float f = expf(m_run - mref);                // rescale of what the wave has accumulated so far
+    l_run *= f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) av[i] *= f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const float e = expf(sc[u] - mref);
+      if (sub == 0) l_run += e;
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) av[i] += vf[u][i] * e;
+    }
+    m_run = m;
   }
-  float sc[NU];
-  float m = m_run;
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    float d = 0.f;
-#pragma unroll
-    for (int i = 0; i < QPL; ++i)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kf[u][i][c], d);
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    sc[u] = (b0 + u * 64 + prow < hi) ? d * scale : -INFINITY;
-    m = fmaxf(m, sc[u]);
-  }
-  m = wave_max(m);                                   // new running max of this wave
-  const float mref = (m == -INFINITY) ? 0.f : m;     // nothing valid yet: every exp below is exp(-inf) = 0
-  const float f = expf(m_run - mref);                // rescale of what the wave has accumulated so far
-  l_run *= f;
-#pragma unroll
-  for (int i = 0; i < QPL; ++i) av[i] *= f;
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const float e = expf(sc[u] - mref);
-    if (sub == 0) l_run += e;
-#pragma unroll
-    for (int i = 0; i < QPL; ++i) av[i] += vf[u][i] * e;
-  }
-  m_run = m;
-}
+};
 
-template <int HD>
-__global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
-    float* __restrict__ part, int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
+// NU0 = passes of the FIRST block of this split's range (0 = empty range): its loads are requested before the
+// new q/k/v quad is waited for, so the gather / rotation / barrier runs under the cache round trip.
+template <int HD, int NU0>
+__device__ __forceinline__ void attention_split_body(const float* __restrict__ qkv, const float* __restrict__ rope,
+                                                     float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ pp,
+                                                     int n_head, int pos, int lo, int hi, bool last, f32x4* sqkv,
+                                                     f32x4 (*wacc)[HD / 4], float* wm, float* wl) {
   constexpr int QUADS = HD / 4;
   constexpr int QPL = QUADS / 8;
   constexpr int NW = ATT1_THREADS / 64;
-  __shared__ f32x4 sqkv[3 * QUADS + 64];
-  __shared__ f32x4 wacc[NW][QUADS];
-  __shared__ float wm[NW], wl[NW];
-  const int h = blockIdx.x, row = blockIdx.y, z = blockIdx.z, n_split = gridDim.z, tid = threadIdx.x;
+  const int h = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
   const int D = n_head * HD;
-  const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos)
-  const bool last = z == n_split - 1;                // owner of the new position
-  const int per = (pos + n_split * 64 - 1) / (n_split * 64) * 64;
-  const int lo = z * per, hi = min(lo + per, pos);
   const float scale = 1.0f / sqrtf((float)HD);
-  float* kc = kcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
-  float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
   const int sub = tid & 7, prow = tid >> 3;
 
-  // new q/k/v quad of this head; rotate q (every split) and k (used by the last split only), park in LDS
+  // new q/k/v quad of this head + rope entry, then the first block of the cache range
   const int gt = min(tid, 3 * QUADS - 1);
   const int which = gt / QUADS, cq = gt % QUADS;
   const f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
   const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);
+  __builtin_amdgcn_sched_barrier(0);
+  AttentionBlock<HD, NU0 ? NU0 : 1> first;
+  if constexpr (NU0 > 0) first.load(kc, vc, lo, hi, sub, prow);
+
+  // rotate q (every split) and k (stored by the last split only), park in LDS; unconditional use of the loads
   f32x4 y;
   y[0] = gx[0] * gcs[0] - gx[1] * gcs[1];
   y[1] = gx[1] * gcs[0] + gx[0] * gcs[1];
@@ -459,12 +464,15 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
     snew = d * scale;
     m_run = snew;
   }
-  for (int b0 = lo; b0 < hi; b0 += 256) {
-    switch (min(4, (hi - b0 + 63) >> 6)) {
-      case 1: attention_block<HD, 1>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
-      case 2: attention_block<HD, 2>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
-      case 3: attention_block<HD, 3>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
-      default: attention_block<HD, 4>(kc, vc, b0, hi, qf, scale, sub, prow, m_run, l_run, av); break;
+  if constexpr (NU0 > 0) first.consume(lo, hi, qf, scale, sub, prow, m_run, l_run, av);
+  if constexpr (NU0 == 4) {   // ranges longer than one block (cache > 256 * n_split positions)
+    for (int b0 = lo + 256; b0 < hi; b0 += 256) {
+      switch (min(4, (hi - b0 + 63) >> 6)) {
+        case 1: { AttentionBlock<HD, 1> blk; blk.load(kc, vc, b0, hi, sub, prow); blk.consume(b0, hi, qf, scale, sub, prow, m_run, l_run, av); break; }
+        case 2: { AttentionBlock<HD, 2> blk; blk.load(kc, vc, b0, hi, sub, prow); blk.consume(b0, hi, qf, scale, sub, prow, m_run, l_run, av); break; }
+        case 3: { AttentionBlock<HD, 3> blk; blk.load(kc, vc, b0, hi, sub, prow); blk.consume(b0, hi, qf, scale, sub, prow, m_run, l_run, av); break; }
+        default: { AttentionBlock<HD, 4> blk; blk.load(kc, vc, b0, hi, sub, prow); blk.consume(b0, hi, qf, scale, sub, prow, m_run, l_run, av); break; }
+      }
     }
   }
   l_run = wave_sum(l_run);
@@ -499,9 +507,33 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
       denom += f * wl[w];
       o += wacc[w][tid] * f;
     }
-    float* pp = part + (((size_t)row * n_head + h) * n_split + z) * ATT_PART_STRIDE(HD);
     reinterpret_cast<f32x4*>(pp)[tid] = o;
     if (tid == 0) { pp[HD] = M; pp[HD + 1] = denom; }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
+    float* __restrict__ part, int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
+  constexpr int QUADS = HD / 4;
+  __shared__ f32x4 sqkv[3 * QUADS + 64];
+  __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
+  __shared__ float wm[ATT1_THREADS / 64], wl[ATT1_THREADS / 64];
+  const int h = blockIdx.x, row = blockIdx.y, z = blockIdx.z, n_split = gridDim.z;
+  const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos)
+  const bool last = z == n_split - 1;                // owner of the new position
+  const int per = (pos + n_split * 64 - 1) / (n_split * 64) * 64;
+  const int lo = z * per, hi = min(lo + per, pos);
+  float* kc = kcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  float* pp = part + (((size_t)row * n_head + h) * n_split + z) * ATT_PART_STRIDE(HD);
+  switch (hi > lo ? min(4, (hi - lo + 63) >> 6) : 0) {
+    case 0: attention_split_body<HD, 0>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 1: attention_split_body<HD, 1>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 2: attention_split_body<HD, 2>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 3: attention_split_body<HD, 3>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    default: attention_split_body<HD, 4>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
   }
 }
 

@@ -17,12 +17,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // earlier, unrelated runtime call (observed: hipErrorNoDevice from a device probe) is not reported here.
 // When vaura_profile_loop arms va_prof_start/stop the launch carries its own start/stop events
 // (hipExtLaunchKernelGGL): they time exactly the kernel, like rocprofv3's kernel trace does.
-extern hipEvent_t va_prof_start, va_prof_stop;
+extern int va_prof_kind;
+void va_prof_events(hipEvent_t* start, hipEvent_t* stop);
 #define VA_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
   do {                                                                                               \
     (void)hipGetLastError();                                                                         \
-    if (va_prof_start) {                                                                             \
-      hipExtLaunchKernelGGL(kern, grid, block, smem, stream, va_prof_start, va_prof_stop, 0, __VA_ARGS__); \
+    if (va_prof_kind >= 0) {                                                                         \
+      hipEvent_t va_e0, va_e1;                                                                       \
+      va_prof_events(&va_e0, &va_e1);                                                                \
+      hipExtLaunchKernelGGL(kern, grid, block, smem, stream, va_e0, va_e1, 0, __VA_ARGS__);         \
     } else {                                                                                         \
       hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);                              \
     }                                                                                                \
