@@ -172,9 +172,16 @@ __device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, 
   p[2] = f16x4{l[0], l[1], l[2], l[3]};   // +8 halves = the lo plane of the same octet
 }
 
+// Loop order: input-channel chunk (32 channels) outermost, taps inside.  The activation block of a chunk is staged in
+// LDS ONCE with its halo — rows [j0 + min offset, j0 + BM + max offset), at most BM + 6*9 — and every tap reads it at
+// its own row shift; only the weight tile (BN x 32) is re-staged per tap.  The previous order (one (tap, chunk) tile of
+// both operands per step) pulled 28 KB through L2 per 2.4 MFLOP and sat at the L2 rate, a third of the matrix-pipe
+// rate; for a 7-tap layer this one moves 15 KB per step.
+#define XHALO 56                      // >= (taps - 1) * dilation = 54
+#define XROWS (BM + XHALO)
 __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   __shared__ u32x4 Ws[2][BK / 4][BN + 1];
-  __shared__ u32x4 Xs[2][BK / 4][BM + 1];
+  __shared__ u32x4 Xs[2][BK / 4][XROWS + 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv & 1, wm = wv >> 1;
   const int j0 = blockIdx.x * BM;
@@ -185,30 +192,43 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   const u32x4* in = reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.Lin * cq;
   const u32x4* wbase = reinterpret_cast<const u32x4*>(a.w) + (size_t)ph * a.NT * a.Cout * cq;
   const int kc = a.Cin / BK;
-  const int nk = a.NT * kc;
+  const int NT = a.NT;
+  const int nk = NT * kc;
+  const int span = (NT - 1) * (a.off_step < 0 ? -a.off_step : a.off_step);
+  const int lo_off = a.off_base + (a.off_step < 0 ? (NT - 1) * a.off_step : 0);   // smallest row offset of any tap
+  const int xrows = BM + span;
+  constexpr int XL = (XROWS * (BK / 4) + 255) / 256;   // activation quads per thread per chunk (6)
 
-  u32x4 wreg[3], xreg[4];
-  auto load_tile = [&](int kt) {
-    const int t = kt / kc, q0 = (kt % kc) * (BK / 4);
+  u32x4 wreg[3], xreg[XL];
+  auto load_w = [&](int kt) {
+    const int c = kt / NT, t = kt - c * NT;
     const u32x4* wt = wbase + (size_t)t * a.Cout * cq;
-    const int off = a.off_base + t * a.off_step;
+    const int q0 = c * (BK / 4);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
       wreg[i] = wt[(size_t)(n0 + row) * cq + q0 + kq];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
-      const int jr = j0 + row + off;
-      xreg[i] = (jr >= 0 && jr < a.Lin) ? in[(size_t)jr * cq + q0 + kq] : u32x4{0u, 0u, 0u, 0u};
-    }
   };
-  auto store_tile = [&](int buf) {
+  auto store_w = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; Ws[buf][qd & 7][qd >> 3] = wreg[i]; }
+  };
+  auto load_x = [&](int c) {
+    const int q0 = c * (BK / 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs[buf][qd & 7][qd >> 3] = xreg[i]; }
+    for (int i = 0; i < XL; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      const int jr = j0 + lo_off + row;
+      xreg[i] = (row < xrows && jr >= 0 && jr < a.Lin) ? in[(size_t)jr * cq + q0 + kq] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int qd = tid + 256 * i;
+      if ((qd >> 3) < XROWS) Xs[buf][qd & 7][qd >> 3] = xreg[i];
+    }
   };
 
   f32x4 acc[3][4];
@@ -217,34 +237,43 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
+  load_w(0);
+  load_x(0);
+  store_w(0);
+  store_x(0);
   __syncthreads();
   const int g = lane >> 4, r16 = lane & 15;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    f16x8 wh[3], wl[3], xh[4], xl[4];
+  int kt = 0;
+  for (int c = 0; c < kc; ++c) {
+    const int xb = c & 1;
+    for (int t = 0; t < NT; ++t, ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_w(kt + 1);
+      if (t == 0 && c + 1 < kc) load_x(c + 1);
+      const int shift = a.off_base + t * a.off_step - lo_off;
+      f16x8 wh[3], wl[3], xh[4], xl[4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      wh[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g][wn * 48 + i * 16 + r16]);
-      wl[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g + 1][wn * 48 + i * 16 + r16]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xh[j] = __builtin_bit_cast(f16x8, Xs[buf][2 * g][wm * 64 + j * 16 + r16]);
-      xl[j] = __builtin_bit_cast(f16x8, Xs[buf][2 * g + 1][wm * 64 + j * 16 + r16]);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 3; ++i) {
+        wh[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g][wn * 48 + i * 16 + r16]);
+        wl[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g + 1][wn * 48 + i * 16 + r16]);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        xh[j] = __builtin_bit_cast(f16x8, Xs[xb][2 * g][shift + wm * 64 + j * 16 + r16]);
+        xl[j] = __builtin_bit_cast(f16x8, Xs[xb][2 * g + 1][shift + wm * 64 + j * 16 + r16]);
       }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        }
+      if (kt + 1 < nk) store_w(buf ^ 1);
+      if (t == NT - 1 && c + 1 < kc) store_x(xb ^ 1);
+      __syncthreads();
+    }
   }
 
   const size_t obase = (size_t)b * a.Lout;
@@ -355,6 +384,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
     } else {
       p.NT = cv.taps; p.off_base = -((cv.taps - 1) / 2) * cv.dilation; p.off_step = cv.dilation;
       p.ostride = 1; p.oshift0 = 0; p.Lout = Lin; p.jcount = Lin;
+      if ((cv.taps - 1) * cv.dilation > XHALO) return VAURA_ERR_SHAPE;
     }
     dim3 grid((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph);
     VA_LAUNCH(conv_pair_kernel, grid, dim3(256), 0, s, p);
