@@ -262,6 +262,17 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
 /* floats each of the 4 workspaces must hold for (B, T) */
 size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T);
 
+/* -------------------------------------------------------------------------------------------
+ * f3 (the step after the path) post-codec scaling: normalize_audio (utils/data_utils.py:407-466) as called by
+ * scale_audio / save_results (scripts/generate.py:404, 440-461), per clip.  wav/out: (n_clips, n_samples) fp32 (may
+ * alias).  strategy: 0 'clip' (the generate_*.yaml default: clamp to +-10^(-db/20)), 1 'peak', 2 'rms' (then clamp
+ * to +-1), 3 'none' (copy).  normalize: the reference's flag (rescale only when it would otherwise clip, if 0).
+ * scratch: vaura_audio_scratch_elems(n_clips) floats (strategies 1, 2).  'loudness' (torchaudio) is not built.   */
+typedef enum vaura_audio_strategy { VAURA_AUDIO_CLIP = 0, VAURA_AUDIO_PEAK = 1, VAURA_AUDIO_RMS = 2, VAURA_AUDIO_NONE = 3 } vaura_audio_strategy;
+int vaura_audio_normalize(const float* wav, float* out, int n_clips, int64_t n_samples, int strategy, int normalize,
+                          float peak_clip_headroom_db, float rms_headroom_db, float* scratch, vaura_stream_t s);
+size_t vaura_audio_scratch_elems(int n_clips);
+
 const char* vaura_version(void);
 /* sizeof() of the descriptor structs as compiled into the library (0 dims, 1 layer_weights, 2 sampling, 3 decoder,
  * 4 conv, 5 codec): a binding checks its mirrored struct layouts against these before the first call.            */

@@ -4,6 +4,7 @@
     python tests/golden/make_golden.py full_greedy   # 24-layer model, B=2, T=220, greedy   (~4 min)
     python tests/golden/make_golden.py full_sample   # 24-layer, B=2, cfg 6, top-k 250      (~8 min)
     python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
+    python tests/golden/make_golden.py post          # post-codec audio scaling (row f3)    (seconds)
 
 Inputs are never stored when they can be regenerated: weights and features come from
 ``vaura_amd.synth`` (name-keyed seeds), sampling noise from ``synth.exp_noise(seed)``.
@@ -268,6 +269,35 @@ def gold_codec():
          decoder_dim=np.int64(ccfg.decoder_dim), codec_seed=np.int64(1))
 
 
+def gold_post():
+    """Post-codec scaling: the reference's own normalize_audio (utils/data_utils.py:407-466)
+    on seeded waveforms: loud (peaks > 1), nominal, quiet; 'clip' (the configs' default), 'peak' and 'rms'
+    with normalize True / False."""
+    rh.install()
+    cwd = os.getcwd()
+    os.chdir(rh.REFERENCE_ROOT)
+    from utils.data_utils import normalize_audio
+    os.chdir(cwd)
+    out = {}
+    gains = {"loud": 1.7, "nominal": 0.3, "quiet": 0.01}
+    n = 4096
+    for name, gain in gains.items():
+        g = torch.Generator().manual_seed(zlib_seed(name))
+        t = torch.arange(n) / 44100.0
+        wav = (torch.sin(2 * torch.pi * 440.0 * t) * 0.6 + torch.randn(n, generator=g) * 0.25)[None] * gain
+        out[f"{name}_in"] = wav.numpy()
+        for strategy, normalize, db in (("clip", True, 6.0), ("clip", True, 3.0), ("peak", True, 6.0), ("peak", False, 6.0),
+                                        ("rms", True, 6.0), ("rms", False, 6.0)):
+            o = normalize_audio(wav.clone(), normalize=normalize, strategy=strategy, peak_clip_headroom_db=db)
+            out[f"{name}_{strategy}_n{int(normalize)}_db{int(db)}"] = o.numpy()
+    save("post.npz", **out)
+
+
+def zlib_seed(name: str) -> int:
+    import zlib
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF
+
+
 if __name__ == "__main__":
     torch.set_float32_matmul_precision("highest")  # NOT main.py:34's "medium" (SURVEY.md App. A.7)
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
@@ -279,5 +309,7 @@ if __name__ == "__main__":
         gold_full_sample()
     elif what == "codec":
         gold_codec()
+    elif what == "post":
+        gold_post()
     else:
         raise SystemExit(f"unknown target {what}")

@@ -124,3 +124,78 @@ def test_pattern_plugin_on_device(golden):
     assert np.array_equal(seq.cpu().numpy(), g["T20_p8_seq"]) and np.array_equal(mask.cpu().numpy(), g["T20_p8_mask"])
     rev, ridx, rmask = pat.revert_pattern_sequence(torch.from_numpy(g["T20_p8_filled"].astype(np.int64)).to(DEV), -1)
     assert np.array_equal(rev.cpu().numpy(), g["T20_p8_rev"]) and bool(rmask.all())
+
+
+POST_CASES = [("clip", True, 6.0), ("clip", True, 3.0), ("peak", True, 6.0), ("peak", False, 6.0), ("rms", True, 6.0),
+              ("rms", False, 6.0)]
+
+
+@pytest.mark.parametrize("strategy,normalize,db", POST_CASES)
+def test_post_codec_scaling_matches_reference(golden, strategy, normalize, db):
+    """Row f3: vaura_audio_normalize against vectors from the reference's normalize_audio (utils/data_utils.py:407-466).
+    'clip' is a clamp: bit-exact.  'peak' / 'rms' multiply by a per-clip gain: the peak is exact; the rms gain comes
+    from a sum of squares whose order differs from torch's -> relative 1e-6."""
+    from vaura_amd import post
+    g = golden("post.npz")
+    names = ["loud", "nominal", "quiet"]
+    batch = torch.stack([torch.from_numpy(g[f"{n}_in"]) for n in names]).to(DEV)          # (3, 1, N): per-clip statistics
+    out = post.normalize_audio(batch, normalize=normalize, strategy=strategy, peak_clip_headroom_db=db).cpu()
+    for i, n in enumerate(names):
+        ref = torch.from_numpy(g[f"{n}_{strategy}_n{int(normalize)}_db{int(db)}"])
+        if strategy == "rms":
+            assert float((out[i] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        else:
+            assert torch.equal(out[i], ref), (n, float((out[i] - ref).abs().max()))
+
+
+def test_scale_audio_and_wav_write(tmp_path):
+    from vaura_amd import post
+    wav = (torch.randn(1, 1, 2048) * 0.8).to(DEV).half()          # the reference's codec emits fp16 (vaura_model.py:92)
+    out = post.scale_audio(wav, "clip", 44100)
+    assert out.shape == (1, 2048) and out.dtype == torch.float32 and out.device.type == "cpu"
+    assert float(out.abs().max()) <= 10 ** (-6 / 20) + 1e-7
+    post.save_wav(str(tmp_path / "a.wav"), out, 44100)
+    from scipy.io import wavfile
+    sr, data = wavfile.read(str(tmp_path / "a.wav"))
+    assert sr == 44100 and data.dtype == np.float32 and np.array_equal(data, out.numpy().reshape(-1))
+    with pytest.raises(NotImplementedError):
+        post.normalize_audio(wav.float(), strategy="loudness", sample_rate=44100)
+
+
+def test_sliding_window_caller_against_oracle_loop(model, tiny_sampler_sd):
+    """Row f1 end to end: vaura_amd.longform.generate_long (chunk schedule + prompt carry-over + rotating segment
+    window + one final codec decode) against the reference's loop (scripts/generate.py:327-369) restated here over
+    the oracle's generate; greedy, so token for token.  Scaled down: 0.30 s window, 0.10 s stride, 0.62 s clip."""
+    from math import ceil
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    from vaura_amd import longform
+    B, S_seg, t_seg = 2, 4, 2
+    feats = synth.video_features(B, tokens=S_seg * t_seg, seed=71).reshape(B, S_seg, t_seg, 768)
+    duration, window, stride, vfps = 0.62, 0.30, 0.10, 400
+    got = longform.generate_long(model, feats.to(DEV), duration, stride=stride, model_max_duration=window, vfps=vfps,
+                                 use_sampling=False, cfg_scale=1.0)
+    # --- the reference's loop, over the oracle
+    dec = DecoderOracle(tiny_sampler_sd, 2, 16)
+    FR = longform.COMPRESSION_MODEL_FRAME_RATE
+    total_gen_len, stride_tokens = int(duration * FR), int(FR * stride)
+    current, prompt_length, all_tokens, prompt = 0, 0, [], None
+    n_calls = 0
+    while current + prompt_length < total_gen_len:
+        time_offset = current / FR
+        chunk_duration = min(duration - time_offset, window)
+        max_gen_len = ceil(chunk_duration * FR)
+        ip, vt = ceil(time_offset * vfps), ceil(chunk_duration * vfps)
+        positions = torch.arange(ip // 16, (ip + vt) // 16)
+        sel = feats[:, positions % S_seg].reshape(B, -1, 768)
+        tok = go.generate(dec, sel, max_gen_len, prompt=prompt, mode="cached")
+        all_tokens.append(tok if prompt is None else tok[:, :, prompt.shape[-1]:])
+        prompt = tok[:, :, stride_tokens:]
+        prompt_length = prompt.shape[-1]
+        current += stride_tokens
+        n_calls += 1
+    ref = torch.cat(all_tokens, dim=-1)
+    assert n_calls >= 4
+    assert torch.equal(got["sampled_indices"].cpu(), ref)
+    assert got["generated_audio"].shape == (B, 1, ref.shape[-1] * 512)
+    assert bool(torch.isfinite(got["generated_audio"]).all())

@@ -162,3 +162,19 @@ def test_fp8_format_statement():
     out = quant.fp8_effective_state_dict(sd)
     assert torch.equal(out["layers.0.attention.wqkv.weight"], e) and torch.equal(out["layers.0.feed_forward.w3.weight"], e)
     assert out["lm_heads.0.weight"] is sd["lm_heads.0.weight"] and out["layers.0.attention_norm.weight"] is sd["layers.0.attention_norm.weight"]
+
+
+def test_sliding_window_schedule_known_answers():
+    """scripts/generate.py:236-237, 327-365 bookkeeping (later chunks are T=221 with a 166-token
+    prompt and a 55-token stride)."""
+    from vaura_amd.longform import chunk_schedule
+    one = chunk_schedule(2.56)
+    assert one == [dict(offset=0, max_gen_len=220, prompt_len=0, positions=None, new_tokens=220)]
+    s = chunk_schedule(5.12, 2.56, 0.64, 25)
+    assert [c["offset"] for c in s] == [0, 55, 110, 165, 220]
+    assert all(c["max_gen_len"] == 221 for c in s)
+    assert [c["prompt_len"] for c in s] == [0, 166, 166, 166, 166]
+    assert s[0]["positions"] == (0, 4) and s[1]["positions"] == (1, 5) and s[4]["positions"] == (4, 8)
+    assert sum(c["new_tokens"] for c in s) == 221 + 4 * 55
+    with pytest.raises(AssertionError):
+        chunk_schedule(5.12, 2.56, 2.56)

@@ -69,6 +69,9 @@ class Codec(C.Structure):
 
 # name -> (restype, argtypes); every symbol declared in include/vaura_hip.h
 SIGNATURES = {
+    "vaura_audio_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                        C.c_void_p, C.c_void_p]),
+    "vaura_audio_scratch_elems": (C.c_size_t, [C.c_int]),
     "vaura_version": (C.c_char_p, []),
     "vaura_struct_size": (C.c_size_t, [C.c_int]),
     "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),

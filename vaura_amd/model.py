@@ -105,10 +105,14 @@ class VAURAModel(nn.Module):
 
     # ------------------------------------------------------------------ generate
     @torch.no_grad()
-    def generate(self, frames=None, audio: Union[torch.Tensor, None] = None, clip_indices=None, max_new_tokens: int = 512,
-                 return_attention_weights: bool = False, return_sampled_indices: bool = False, check: bool = False,
-                 use_sampling: bool = True, temp: float = 1.0, top_k: int = 256, top_p: float = 0.0,
-                 remove_prompts: bool = False, prompt_is_encoded: bool = False, cfg_scale: float = 1.0) -> dict:
+    def generate_tokens(self, frames=None, audio: Union[torch.Tensor, None] = None, clip_indices=None,
+                        max_new_tokens: int = 512, return_attention_weights: bool = False,
+                        return_sampled_indices: bool = True, check: bool = False, use_sampling: bool = True,
+                        temp: float = 1.0, top_k: int = 256, top_p: float = 0.0, remove_prompts: bool = False,
+                        prompt_is_encoded: bool = False, cfg_scale: float = 1.0) -> torch.Tensor:
+        """generate() up to and including revert_pattern_sequence (vaura_model.py:410-572): (B, K, T') int64 tokens on
+        the device, no codec decode.  The sliding-window caller (vaura_amd.longform) uses this for every chunk and
+        decodes the concatenated tokens once, as the reference's script does (scripts/generate.py:366-369)."""
         assert not self.training, "do not use generation in training mode"
         if return_attention_weights:
             raise NotImplementedError("attention-weight dumps are not produced by the fused decode path")
@@ -129,19 +133,31 @@ class VAURAModel(nn.Module):
         start = Tp + 1  # Pattern.get_first_step_with_timesteps(Tp), delayed pattern
         greedy = not (use_sampling and temp > 0.0)
         noise = None if greedy else self._exp_noise(S - start, B * K, self.sampler.d_codebook)
-        with off_null_stream(eng.dev) as caller:   # decode loop + codec leave HIP's null stream together
-            codes = eng.generate_codes(
-                vis.float(), max_new_tokens, prompt=audio if Tp else None, use_sampling=use_sampling, temp=temp,
-                top_k=top_k, top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed,
-                clip_base=self.clip_base, tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
-            out_codes = codes[..., (Tp if remove_prompts else 0):max_new_tokens]
-            generated_audio = self.audio_encoder.decode([(out_codes[..., :K, :], None)])
-        if caller is not None:
-            codes.record_stream(caller)
-            generated_audio.record_stream(caller)
+        codes = eng.generate_codes(
+            vis.float(), max_new_tokens, prompt=audio if Tp else None, use_sampling=use_sampling, temp=temp,
+            top_k=top_k, top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed,
+            clip_base=self.clip_base, tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
         # the reference's post-conditions (:550-572), checked once on the finished tensor
         bad = (codes < 0) | (codes > self.sampler.d_codebook)
         assert not bool(bad.any()), "generated sequence is incomplete or out of range"
+        return codes[..., (Tp if remove_prompts else 0):max_new_tokens]
+
+    @torch.no_grad()
+    def generate(self, frames=None, audio: Union[torch.Tensor, None] = None, clip_indices=None, max_new_tokens: int = 512,
+                 return_attention_weights: bool = False, return_sampled_indices: bool = False, check: bool = False,
+                 use_sampling: bool = True, temp: float = 1.0, top_k: int = 256, top_p: float = 0.0,
+                 remove_prompts: bool = False, prompt_is_encoded: bool = False, cfg_scale: float = 1.0) -> dict:
+        K = self.num_codebooks
+        with off_null_stream(self.sampler.engine().dev) as caller:   # decode loop + codec leave HIP's null stream together
+            out_codes = self.generate_tokens(
+                frames=frames, audio=audio, clip_indices=clip_indices, max_new_tokens=max_new_tokens,
+                return_attention_weights=return_attention_weights, check=check, use_sampling=use_sampling, temp=temp,
+                top_k=top_k, top_p=top_p, remove_prompts=remove_prompts, prompt_is_encoded=prompt_is_encoded,
+                cfg_scale=cfg_scale)
+            generated_audio = self.audio_encoder.decode([(out_codes[..., :K, :], None)])
+        if caller is not None:
+            out_codes.record_stream(caller)
+            generated_audio.record_stream(caller)
         return {"generated_audio": generated_audio, "s_attn_weights": None, "mha_attn_weights": None,
                 "sampled_indices": out_codes if return_sampled_indices else None}
 
