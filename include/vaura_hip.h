@@ -263,6 +263,40 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
 size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T);
 
 /* -------------------------------------------------------------------------------------------
+ * f4 DacModelWrapper.encode (models/modules/dac/model.py:30-39): DAC encoder + residual VQ (descript-audio-codec
+ * 1.0.0, un-vendored: dac/model/dac.py Encoder, dac/nn/quantize.py).  Convolutions run on (hi, lo) fp16 pairs like the
+ * decoder's precision 1: conv weights in pair layout, weight-norm folded by the caller.                           */
+typedef struct vaura_codec_encoder {
+  int32_t n_codebooks, codebook_size, codebook_dim, latent_dim;
+  int32_t n_blocks, n_units;        /* 4 encoder blocks, 3 residual units each */
+  int32_t rates[4];                 /* (2, 4, 8, 8) */
+  int32_t enc_dim;                  /* 64: channels after the first conv; doubles per block */
+  int32_t _pad0;
+  const float* conv_in_w;           /* (7, enc_dim) fp32 = encoder.block.0 weight as [tap][Cout]          */
+  const float* conv_in_b;           /* (enc_dim) */
+  const float* alpha_res[4][3][2];  /* Snakes of each residual unit      encoder.block.{b+1}.block.{u}.block.{0,2} */
+  vaura_conv res[4][3][2];          /* {k7 dilated, k1}                  ...block.{u}.block.{1,3}                   */
+  const float* alpha_down[4];       /* Snake in front of each strided conv       encoder.block.{b+1}.block.3        */
+  vaura_conv down[4];               /* encoder.block.{b+1}.block.4 (C -> 2C, k = 2r, stride r, pad r/2) restated as a
+                                       3-tap stride-1 conv over rows of r*C channels (the (L, C) buffer read as
+                                       (L/r, r*C)): cin = r*C, cout = 2C, taps = 3, dilation = 1, stride = 1,
+                                       w'[tau+1][co][q*C + ci] = w[co][ci][tau*r + q + r/2] (0 outside [0, 2r))     */
+  const float* alpha_out;           /* final Snake                               encoder.block.{n+1}                 */
+  vaura_conv conv_out;              /* C_last -> latent, k3                      encoder.block.{n+2}                 */
+  const float* in_proj_w;           /* (K, dim, latent) weight-norm folded       quantizer.quantizers[k].in_proj     */
+  const float* in_proj_b;           /* (K, dim) */
+  const float* codebooks;           /* (K, size, dim)                                                                */
+  const float* out_proj_w;          /* (K, latent, dim)                                                              */
+  const float* out_proj_b;          /* (K, latent) */
+  float* ws[4];                     /* activation buffers, ws_elems x 4 bytes each */
+  size_t ws_elems;
+} vaura_codec_encoder;
+/* wav (B, n_samples) fp32, n_samples a multiple of prod(rates) (DAC.preprocess zero-pads on the right; the caller does)
+ * -> codes (B, K, n_samples / prod(rates)) int32 */
+int vaura_dac_encode(const vaura_codec_encoder* c, const float* wav, int B, int64_t n_samples, int32_t* codes, vaura_stream_t s);
+size_t vaura_dac_encode_workspace_elems(const vaura_codec_encoder* c, int B, int64_t n_samples);
+
+/* -------------------------------------------------------------------------------------------
  * f3 (the step after the path) post-codec scaling: normalize_audio (utils/data_utils.py:407-466) as called by
  * scale_audio / save_results (scripts/generate.py:404, 440-461), per clip.  wav/out: (n_clips, n_samples) fp32 (may
  * alias).  strategy: 0 'clip' (the generate_*.yaml default: clamp to +-10^(-db/20)), 1 'peak', 2 'rms' (then clamp
@@ -275,7 +309,7 @@ size_t vaura_audio_scratch_elems(int n_clips);
 
 const char* vaura_version(void);
 /* sizeof() of the descriptor structs as compiled into the library (0 dims, 1 layer_weights, 2 sampling, 3 decoder,
- * 4 conv, 5 codec): a binding checks its mirrored struct layouts against these before the first call.            */
+ * 4 conv, 5 codec, 6 codec_encoder): a binding checks its mirrored struct layouts against these before the first call.            */
 size_t vaura_struct_size(int which);
 
 #ifdef __cplusplus

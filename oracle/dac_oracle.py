@@ -15,7 +15,17 @@ and it ships no vectors for them.  Restated from the published DAC architecture
   Snake        x + (alpha + 1e-9)^-1 * sin(alpha * x)^2,  alpha per channel
   WN*          weight = g * v / ||v||  (norm over all dims but 0)
 
-Structure cross-check: tests/golden/codec_hf.npz (transformers' independent DacModel).
+Encode side (reference call site models/modules/dac/model.py:30-39: preprocess, model.encode):
+  preprocess   right-pad the waveform with zeros to a multiple of hop_length = prod(encoder_rates)
+  Encoder      WNConv1d(1 -> d, k=7, pad=3)
+               for r in encoder_rates: 3 x ResidualUnit(d, dilation in (1,3,9)) -> Snake(d)
+                                -> WNConv1d(d -> 2d, k=2r, stride=r, pad=ceil(r/2));  d *= 2
+               Snake(d) -> WNConv1d(d -> latent, k=3, pad=1)
+  RVQ.forward  residual = z; for each quantizer: z_e = in_proj(residual) (WNConv1d latent -> 8, k=1);
+               e = normalize(z_e), c = normalize(codebook); dist = |e|^2 - 2 e.c^T + |c|^2; code = argmax(-dist);
+               z_q = out_proj(z_e + (codebook[code] - z_e)); residual -= z_q            (dac/nn/quantize.py)
+
+Structure cross-check: tests/golden/codec_hf.npz, codec_enc_hf.npz (transformers' independent DacModel).
 """
 from __future__ import annotations
 
@@ -70,3 +80,62 @@ def decode_latent(sd: Dict[str, torch.Tensor], z: torch.Tensor, rates: Sequence[
 @torch.no_grad()
 def decode(sd: Dict[str, torch.Tensor], codes: torch.Tensor, rates: Sequence[int] = (8, 8, 4, 2)) -> torch.Tensor:
     return decode_latent(sd, from_codes(sd, codes), rates)
+
+
+def preprocess(wav: torch.Tensor, hop: int) -> torch.Tensor:
+    """(B, 1, N) -> zero-padded on the right to a multiple of `hop` (DAC.preprocess)."""
+    n = wav.shape[-1]
+    return F.pad(wav, (0, math.ceil(n / hop) * hop - n))
+
+
+def encode_latent(sd: Dict[str, torch.Tensor], wav: torch.Tensor, rates: Sequence[int] = (2, 4, 8, 8),
+                  dilations: Sequence[int] = (1, 3, 9)) -> torch.Tensor:
+    """wav (B, 1, N), N % prod(rates) == 0 -> z (B, latent, N / prod(rates))."""
+    x = F.conv1d(wav, fold(sd, "encoder.block.0."), sd["encoder.block.0.bias"].float(), padding=3)
+    for b, r in enumerate(rates):
+        p = f"encoder.block.{b + 1}.block."
+        for u, d in enumerate(dilations):
+            q = p + f"{u}.block."
+            y = snake(x, sd[q + "0.alpha"].float())
+            y = F.conv1d(y, fold(sd, q + "1."), sd[q + "1.bias"].float(), dilation=d, padding=3 * d)
+            y = snake(y, sd[q + "2.alpha"].float())
+            y = F.conv1d(y, fold(sd, q + "3."), sd[q + "3.bias"].float())
+            x = x + y
+        x = snake(x, sd[p + "3.alpha"].float())
+        x = F.conv1d(x, fold(sd, p + "4."), sd[p + "4.bias"].float(), stride=r, padding=math.ceil(r / 2))
+    n = len(rates) + 1
+    x = snake(x, sd[f"encoder.block.{n}.alpha"].float())
+    return F.conv1d(x, fold(sd, f"encoder.block.{n + 1}."), sd[f"encoder.block.{n + 1}.bias"].float(), padding=1)
+
+
+def quantize(sd: Dict[str, torch.Tensor], z: torch.Tensor, n_codebooks: int = 9, return_margin: bool = False):
+    """z (B, latent, T) -> codes (B, K, T) int64 [, margin (B, K, T): best - second-best of -dist, for tie analysis]."""
+    residual = z
+    codes, margins = [], []
+    for k in range(n_codebooks):
+        p = f"quantizer.quantizers.{k}."
+        z_e = F.conv1d(residual, fold(sd, p + "in_proj."), sd[p + "in_proj.bias"].float())
+        B, D, T = z_e.shape
+        enc = F.normalize(z_e.transpose(1, 2).reshape(B * T, D))
+        cb_raw = sd[p + "codebook.weight"].float()
+        cb = F.normalize(cb_raw)
+        dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t() + cb.pow(2).sum(1, keepdim=True).t()
+        idx = (-dist).max(1)[1]
+        if return_margin:
+            top2 = (-dist).topk(2, dim=1).values
+            margins.append((top2[:, 0] - top2[:, 1]).reshape(B, T))
+        idx = idx.reshape(B, T)
+        z_q = F.embedding(idx, cb_raw).transpose(1, 2)
+        z_q = z_e + (z_q - z_e)
+        z_q = F.conv1d(z_q, fold(sd, p + "out_proj."), sd[p + "out_proj.bias"].float())
+        residual = residual - z_q
+        codes.append(idx)
+    codes = torch.stack(codes, dim=1)
+    return (codes, torch.stack(margins, dim=1)) if return_margin else codes
+
+
+@torch.no_grad()
+def encode(sd: Dict[str, torch.Tensor], wav: torch.Tensor, rates: Sequence[int] = (2, 4, 8, 8), n_codebooks: int = 9) -> torch.Tensor:
+    """DacModelWrapper.encode (models/modules/dac/model.py:30-39): wav (B, 1, N) -> codes (B, K, ceil(N / hop))."""
+    wav = preprocess(wav.float(), int(math.prod(rates)))
+    return quantize(sd, encode_latent(sd, wav, rates), n_codebooks)

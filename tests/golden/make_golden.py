@@ -5,6 +5,7 @@
     python tests/golden/make_golden.py full_sample   # 24-layer, B=2, cfg 6, top-k 250      (~8 min)
     python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
     python tests/golden/make_golden.py post          # post-codec audio scaling (row f3)    (seconds)
+    python tests/golden/make_golden.py codec_enc     # DAC encode, transformers' DacModel   (seconds)
 
 Inputs are never stored when they can be regenerated: weights and features come from
 ``vaura_amd.synth`` (name-keyed seeds), sampling noise from ``synth.exp_noise(seed)``.
@@ -269,6 +270,52 @@ def gold_codec():
          decoder_dim=np.int64(ccfg.decoder_dim), codec_seed=np.int64(1))
 
 
+def gold_codec_enc():
+    """DAC encode cross-check with transformers' independent DacModel (reduced width: encoder 8 -> 128 = latent):
+    encoder latent + codes.  Structure check only, like gold_codec (the reference's own dependency is absent)."""
+    from transformers import DacConfig, DacModel
+    ccfg = synth.CodecCfg(latent_dim=128, encoder_dim=8, encoder_rates=(2, 4, 8, 8), decoder_dim=192)
+    hf = DacConfig(sampling_rate=44100, encoder_hidden_size=ccfg.encoder_dim, downsampling_ratios=list(ccfg.encoder_rates),
+                   decoder_hidden_size=ccfg.decoder_dim, upsampling_ratios=list(ccfg.decoder_rates),
+                   n_codebooks=9, codebook_size=1024, codebook_dim=8, hidden_size=ccfg.latent_dim)
+    m = DacModel(hf).eval()
+    sd = dict(synth.codec_state_dict(ccfg, seed=2))
+    sd.update(synth.codec_encoder_state_dict(ccfg, seed=2))
+    fold = synth.fold_weight_norm
+
+    def put(conv, prefix):
+        conv.weight.data.copy_(fold(sd[prefix + "weight_g"], sd[prefix + "weight_v"]))
+        conv.bias.data.copy_(sd[prefix + "bias"])
+
+    enc = m.encoder
+    put(enc.conv1, "encoder.block.0.")
+    for b, blk in enumerate(enc.block):
+        p = f"encoder.block.{b + 1}.block."
+        for u, ru in enumerate([blk.res_unit1, blk.res_unit2, blk.res_unit3]):
+            q = p + f"{u}.block."
+            ru.snake1.alpha.data.copy_(sd[q + "0.alpha"])
+            put(ru.conv1, q + "1.")
+            ru.snake2.alpha.data.copy_(sd[q + "2.alpha"])
+            put(ru.conv2, q + "3.")
+        blk.snake1.alpha.data.copy_(sd[p + "3.alpha"])
+        put(blk.conv1, p + "4.")
+    n = len(ccfg.encoder_rates) + 1
+    enc.snake1.alpha.data.copy_(sd[f"encoder.block.{n}.alpha"])
+    put(enc.conv2, f"encoder.block.{n + 1}.")
+    for i, q in enumerate(m.quantizer.quantizers):
+        p = f"quantizer.quantizers.{i}."
+        q.codebook.weight.data.copy_(sd[p + "codebook.weight"])
+        put(q.in_proj, p + "in_proj.")
+        put(q.out_proj, p + "out_proj.")
+    g = torch.Generator().manual_seed(22)
+    wav = torch.randn(2, 1, 512 * 6, generator=g) * 0.3
+    with torch.no_grad():
+        z = enc(wav)
+        codes = m.quantizer(z)[1]
+    save("codec_enc_hf.npz", wav=wav.numpy(), z=z.numpy(), codes=codes.numpy().astype(np.int16), codec_seed=np.int64(2),
+         encoder_dim=np.int64(ccfg.encoder_dim), latent_dim=np.int64(ccfg.latent_dim))
+
+
 def gold_post():
     """Post-codec scaling: the reference's own normalize_audio (utils/data_utils.py:407-466)
     on seeded waveforms: loud (peaks > 1), nominal, quiet; 'clip' (the configs' default), 'peak' and 'rms'
@@ -311,5 +358,7 @@ if __name__ == "__main__":
         gold_codec()
     elif what == "post":
         gold_post()
+    elif what == "codec_enc":
+        gold_codec_enc()
     else:
         raise SystemExit(f"unknown target {what}")

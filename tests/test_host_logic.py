@@ -48,7 +48,7 @@ def test_argument_errors_are_reported_without_a_gpu():
 def test_struct_layouts_match_the_header():
     # the ctypes mirrors against the sizes the C side was compiled with: a drift here corrupts every call
     lib = L.lib()
-    for which, cls in enumerate([L.Dims, L.LayerWeights, L.Sampling, L.Decoder, L.Conv, L.Codec]):
+    for which, cls in enumerate([L.Dims, L.LayerWeights, L.Sampling, L.Decoder, L.Conv, L.Codec, L.CodecEncoder]):
         assert C.sizeof(cls) == lib.vaura_struct_size(which), cls.__name__
     assert C.sizeof(L.Dims) == 48 and C.sizeof(L.Sampling) == 40
     assert lib.vaura_struct_size(99) == 0
@@ -92,8 +92,9 @@ def test_codec_plugin_surface():
     assert "decoder.model.1.block.2.block.3.weight_g" in c.model.state_dict()
     with pytest.raises(L.VauraHipError):
         c.decode(torch.zeros(1, 9, 4, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(L.VauraHipError):          # no CPU path in either direction
         c.encode(torch.zeros(1, 1, 1000))
+    assert "encoder.block.1.block.4.weight_v" in c.model.state_dict() and q[0].in_proj.weight_v.shape == (8, 1024, 1)
 
 
 @pytest.mark.parametrize("T,Tp", [(4, 0), (55, 0), (220, 0), (221, 166), (20, 8)])

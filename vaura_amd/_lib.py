@@ -67,11 +67,26 @@ class Codec(C.Structure):
                 ("ws", C.c_void_p * 4), ("ws_elems", C.c_size_t), ("precision", C.c_int32), ("_pad1", C.c_int32)]
 
 
+class CodecEncoder(C.Structure):
+    _fields_ = [("n_codebooks", C.c_int32), ("codebook_size", C.c_int32), ("codebook_dim", C.c_int32),
+                ("latent_dim", C.c_int32), ("n_blocks", C.c_int32), ("n_units", C.c_int32),
+                ("rates", C.c_int32 * 4), ("enc_dim", C.c_int32), ("_pad0", C.c_int32),
+                ("conv_in_w", C.c_void_p), ("conv_in_b", C.c_void_p),
+                ("alpha_res", ((C.c_void_p * 2) * 3) * 4), ("res", ((Conv * 2) * 3) * 4),
+                ("alpha_down", C.c_void_p * 4), ("down", Conv * 4),
+                ("alpha_out", C.c_void_p), ("conv_out", Conv),
+                ("in_proj_w", C.c_void_p), ("in_proj_b", C.c_void_p), ("codebooks", C.c_void_p),
+                ("out_proj_w", C.c_void_p), ("out_proj_b", C.c_void_p),
+                ("ws", C.c_void_p * 4), ("ws_elems", C.c_size_t)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/vaura_hip.h
 SIGNATURES = {
     "vaura_audio_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_void_p, C.c_void_p]),
     "vaura_audio_scratch_elems": (C.c_size_t, [C.c_int]),
+    "vaura_dac_encode": (C.c_int, [C.POINTER(CodecEncoder), C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vaura_dac_encode_workspace_elems": (C.c_size_t, [C.POINTER(CodecEncoder), C.c_int, C.c_int64]),
     "vaura_version": (C.c_char_p, []),
     "vaura_struct_size": (C.c_size_t, [C.c_int]),
     "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
@@ -129,7 +144,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        for which, cls in enumerate([Dims, LayerWeights, Sampling, Decoder, Conv, Codec]):
+        for which, cls in enumerate([Dims, LayerWeights, Sampling, Decoder, Conv, Codec, CodecEncoder]):
             if C.sizeof(cls) != handle.vaura_struct_size(which):
                 raise VauraHipError(f"{LIB_PATH} was built from a different include/vaura_hip.h: sizeof({cls.__name__}) is "
                                     f"{handle.vaura_struct_size(which)} there, {C.sizeof(cls)} here (rebuild the library)")

@@ -1,13 +1,13 @@
 """Drop-in codec plugin: ``target: vaura_amd.codec.DacModelWrapper``.
 
-Mirror of /root/reference/models/modules/dac/model.py:12-60 for the decode direction.  The class
+Mirror of /root/reference/models/modules/dac/model.py:12-60, both directions.  The class
 name must stay ``DacModelWrapper`` (models/vaura_model.py:87, scripts/generate.py:215).  ``.model``
 is a parameter holder with the state-dict keys of ``dac.DAC`` 1.0.0 (weight-norm parametrised:
 ``weight_g`` / ``weight_v`` / ``bias`` / ``alpha`` / ``codebook.weight``), exposing what
 ``Transformer.initialize_embeddings`` reads (``quantizer.quantizers[i].codebook.weight`` and
-``.out_proj``).  Decoding is executed by libvaura_hip.so (``CodecEngine``) in fp32.
-
-``encode`` (wav -> codes) is outside the hot path and raises.
+``.out_proj``).  ``decode`` (codes -> waveform, the hot path's last stage) and ``encode`` (waveform -> codes: raw-audio
+prompts, "compressed original" outputs) are executed by libvaura_hip.so (``CodecEngine`` /
+``CodecEncoderEngine``); there is no CPU path.
 """
 from __future__ import annotations
 
@@ -20,14 +20,14 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import synth
-from .engine import CodecEngine
+from .engine import CodecEncoderEngine, CodecEngine
 from .sampler import _tree
 
 MODEL_SR = [16000, 24000, 44000, 44100]
 
 
 class _Holder(nn.Module):
-    """``dac.DAC``-shaped parameter tree (decoder half + quantizer codebooks / out_proj)."""
+    """``dac.DAC``-shaped parameter tree (encoder, quantizer, decoder)."""
 
     def __init__(self, cfg: synth.CodecCfg, sd: tp.Dict[str, torch.Tensor]):
         super().__init__()
@@ -45,7 +45,9 @@ class DacModelWrapper(nn.Module):
             raise L.VauraHipError("only the 44.1 kHz DAC geometry is built (configs/modules/audio_codecs/dac_8kbps_wrapper.yaml)")
         self.model_sr = model_sr
         self.cfg = synth.FULL_CODEC
-        self.model = _Holder(self.cfg, synth.codec_state_dict(self.cfg, seed=synthetic_seed))
+        sd0 = dict(synth.codec_state_dict(self.cfg, seed=synthetic_seed))
+        sd0.update(synth.codec_encoder_state_dict(self.cfg, seed=synthetic_seed))
+        self.model = _Holder(self.cfg, sd0)
         if ckpt_path is not None and os.path.exists(ckpt_path):
             blob = torch.load(ckpt_path, map_location="cpu")
             sd = blob.get("state_dict", blob)
@@ -57,6 +59,8 @@ class DacModelWrapper(nn.Module):
             warnings.warn("DacModelWrapper: no checkpoint given; using seeded synthetic DAC weights")
         self._engine: tp.Optional[CodecEngine] = None
         self._engine_dev = None
+        self._enc_engine: tp.Optional[CodecEncoderEngine] = None
+        self._enc_engine_dev = None
 
     def engine(self) -> CodecEngine:
         dev = next(self.model.parameters()).device
@@ -70,8 +74,24 @@ class DacModelWrapper(nn.Module):
     def forward(self, wav: torch.Tensor):
         return self.encode(wav)
 
+    def encoder_engine(self) -> CodecEncoderEngine:
+        dev = next(self.model.parameters()).device
+        if self._enc_engine is None or self._enc_engine_dev != dev:
+            if dev.type != "cuda":
+                raise L.VauraHipError("vaura_amd.codec.DacModelWrapper encodes on a HIP device only; call .to('cuda')")
+            self._enc_engine = CodecEncoderEngine(self.cfg, {k: v.float() for k, v in self.model.state_dict().items()}, dev)
+            self._enc_engine_dev = dev
+        return self._enc_engine
+
+    @torch.no_grad()
     def encode(self, wav: torch.Tensor):
-        raise NotImplementedError("DAC encode is outside the accelerated hot path (SURVEY.md §8 f4)")
+        """wav (N) | (C=1, N) | (B, 1, N) -> codes (B, 9, ceil(N / 512)) — dac/model.py:30-39 (unsqueeze to 3 dims,
+        DAC.preprocess zero-pads to a multiple of the hop, DAC.encode)."""
+        if wav.ndim < 2:
+            wav = wav.unsqueeze(0)
+        if wav.ndim < 3:
+            wav = wav.unsqueeze(0)
+        return self.encoder_engine().encode(wav)
 
     @torch.no_grad()
     def decode(self, codes: tp.Union[torch.Tensor, tp.List[tp.Tuple[torch.Tensor]]]):

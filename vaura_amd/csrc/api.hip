@@ -215,6 +215,7 @@ size_t vaura_struct_size(int which) {
     case 3: return sizeof(vaura_decoder);
     case 4: return sizeof(vaura_conv);
     case 5: return sizeof(vaura_codec);
+    case 6: return sizeof(vaura_codec_encoder);
     default: return 0;
   }
 }

@@ -179,13 +179,17 @@ __device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, 
 // rate; for a 7-tap layer this one moves 15 KB per step.
 #define XHALO 56                      // >= (taps - 1) * dilation = 54
 #define XROWS (BM + XHALO)
+// NI = 16-column tiles per wave: output-channel tile BN_ = 32 * NI (96 for the decoder's widths, 64 for the
+// encoder's powers of two)
+template <int NI>
 __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
-  __shared__ u32x4 Ws[2][BK / 4][BN + 1];
+  constexpr int BN_ = 32 * NI;
+  __shared__ u32x4 Ws[2][BK / 4][BN_ + 1];
   __shared__ u32x4 Xs[2][BK / 4][XROWS + 1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv & 1, wm = wv >> 1;
   const int j0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = blockIdx.y * BN_;
   const int phases = a.ostride;
   const int b = blockIdx.z / phases, ph = blockIdx.z % phases;
   const int cq = a.Cin / 4;                 // 16-B quads per row (C/8 octets x 2 planes)
@@ -199,20 +203,20 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   const int xrows = BM + span;
   constexpr int XL = (XROWS * (BK / 4) + 255) / 256;   // activation quads per thread per chunk (6)
 
-  u32x4 wreg[3], xreg[XL];
+  u32x4 wreg[NI], xreg[XL];
   auto load_w = [&](int kt) {
     const int c = kt / NT, t = kt - c * NT;
     const u32x4* wt = wbase + (size_t)t * a.Cout * cq;
     const int q0 = c * (BK / 4);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
       wreg[i] = wt[(size_t)(n0 + row) * cq + q0 + kq];
     }
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; Ws[buf][qd & 7][qd >> 3] = wreg[i]; }
+    for (int i = 0; i < NI; ++i) { const int qd = tid + 256 * i; Ws[buf][qd & 7][qd >> 3] = wreg[i]; }
   };
   auto load_x = [&](int c) {
     const int q0 = c * (BK / 4);
@@ -231,9 +235,9 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
     }
   };
 
-  f32x4 acc[3][4];
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -251,11 +255,11 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
       if (kt + 1 < nk) load_w(kt + 1);
       if (t == 0 && c + 1 < kc) load_x(c + 1);
       const int shift = a.off_base + t * a.off_step - lo_off;
-      f16x8 wh[3], wl[3], xh[4], xl[4];
+      f16x8 wh[NI], wl[NI], xh[4], xl[4];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        wh[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g][wn * 48 + i * 16 + r16]);
-        wl[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g + 1][wn * 48 + i * 16 + r16]);
+      for (int i = 0; i < NI; ++i) {
+        wh[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g][wn * (NI * 16) + i * 16 + r16]);
+        wl[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g + 1][wn * (NI * 16) + i * 16 + r16]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
         xl[j] = __builtin_bit_cast(f16x8, Xs[xb][2 * g + 1][shift + wm * 64 + j * 16 + r16]);
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
     const int orow = jr * a.ostride + a.oshift0 + ph;
     if (orow < 0 || orow >= a.Lout) continue;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int co = n0 + wn * 48 + i * 16 + 4 * g;
+    for (int i = 0; i < NI; ++i) {
+      const int co = n0 + wn * (NI * 16) + i * 16 + 4 * g;
       const size_t o = (obase + (size_t)orow) * a.Cout + co;
       f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + co);
       if (a.res) v = *reinterpret_cast<const f32x4*>(a.res + o) + v;
@@ -369,9 +373,10 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
 
 static int launch_conv(const vaura_conv& cv, const float* in, const float* res, const float* alpha, float* out_raw,
                        float* out_act, int B, int Lin, int pairs, hipStream_t s) {
-  if (!cv.w || !cv.bias || (cv.cin % BK) || (cv.cout % BN)) return VAURA_ERR_SHAPE;
+  if (!cv.w || !cv.bias || (cv.cin % BK)) return VAURA_ERR_SHAPE;
   if (out_act && !alpha) return VAURA_ERR_ARG;
   if (pairs) {
+    if ((cv.cout % BN) && (cv.cout % 64)) return VAURA_ERR_SHAPE;
     ConvPArgs p;
     p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(cv.w); p.bias = cv.bias; p.res = res;
     p.alpha = alpha; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
@@ -386,10 +391,14 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       p.ostride = 1; p.oshift0 = 0; p.Lout = Lin; p.jcount = Lin;
       if ((cv.taps - 1) * cv.dilation > XHALO) return VAURA_ERR_SHAPE;
     }
-    dim3 grid((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph);
-    VA_LAUNCH(conv_pair_kernel, grid, dim3(256), 0, s, p);
+    if (cv.cout % BN == 0) {
+      VA_LAUNCH(conv_pair_kernel<3>, dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+    } else {
+      VA_LAUNCH(conv_pair_kernel<2>, dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
+    }
     return 0;
   }
+  if (cv.cout % BN) return VAURA_ERR_SHAPE;
   ConvArgs a;
   a.in = in; a.w = cv.w; a.bias = cv.bias; a.res = res; a.alpha = alpha; a.out_raw = out_raw; a.out_act = out_act;
   a.Lin = Lin; a.Cin = cv.cin; a.Cout = cv.cout;
@@ -405,6 +414,120 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
   dim3 grid((a.jcount + BM - 1) / BM, cv.cout / BN, B * phases);
   VA_LAUNCH(conv_mfma_kernel, grid, dim3(256), 0, s, a);
   return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Encode side (DacModelWrapper.encode, models/modules/dac/model.py:30-39).
+// First conv of the encoder: 1 -> C channels, k = 7, pad 3, from the raw waveform; emits the raw fp32 rows (residual
+// stream) and Snake(alpha) of them in pair layout (the input of the first residual unit).
+__global__ __launch_bounds__(256) void enc_conv_in_kernel(const float* __restrict__ wav, const float* __restrict__ w /* [7][C] */,
+                                                          const float* __restrict__ bias, const float* __restrict__ alpha,
+                                                          float* __restrict__ out_raw, uint16_t* __restrict__ out_act, int64_t L,
+                                                          int C) {
+  const int b = blockIdx.y;
+  const int qpr = C / 4;                                   // quads per row
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t l = gid / qpr;
+  const int cq = (int)(gid % qpr);
+  if (l >= L) return;
+  const float* x = wav + (size_t)b * L;
+  f32x4 v = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int64_t r = l + t - 3;
+    const float xv = (r >= 0 && r < L) ? x[r] : 0.f;
+    v += *reinterpret_cast<const f32x4*>(w + t * C + cq * 4) * xv;
+  }
+  const size_t row = (size_t)b * L + (size_t)l;
+  *reinterpret_cast<f32x4*>(out_raw + row * C + cq * 4) = v;
+  const f32x4 al = *reinterpret_cast<const f32x4*>(alpha + cq * 4);
+  f32x4 sn;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sn[r] = snake_f(v[r], al[r]);
+  store_pair4(out_act, row, cq * 4, C, sn);
+}
+
+// One residual-VQ stage for every latent row (dac/nn/quantize.py VectorQuantize.forward + the residual update of
+// ResidualVectorQuantize.forward):  z_e = in_proj(residual); code = argmax_j -(|e|^2 - 2 e.c_j + |c_j|^2) over the
+// L2-normalised encodings / codewords (first index wins a tie, like torch.max); residual -= out_proj(z_e + (c - z_e)).
+// One 256-thread workgroup per row; latent <= 2048, codebook_dim <= 8, codebook_size <= 1024.
+__global__ __launch_bounds__(256) void rvq_stage_kernel(float* __restrict__ residual /* (rows, latent) */,
+                                                        const float* __restrict__ in_w /* (dim, latent) */,
+                                                        const float* __restrict__ in_b, const float* __restrict__ cb /* (size, dim) */,
+                                                        const float* __restrict__ out_w /* (latent, dim) */,
+                                                        const float* __restrict__ out_b, int32_t* __restrict__ codes, int latent,
+                                                        int dim, int size, int T, int K, int k) {
+  __shared__ float part[4][8];
+  __shared__ float ze[8];
+  __shared__ float bestv[4];
+  __shared__ int besti[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* res = residual + (size_t)row * latent;
+  // ---- z_e = in_proj(residual)
+  float acc[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) acc[d] = 0.f;
+  for (int c = tid; c < latent; c += 256) {
+    const float x = res[c];
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+      if (d < dim) acc[d] = fmaf(in_w[(size_t)d * latent + c], x, acc[d]);
+  }
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const float s = wave_sum(acc[d]);
+    if (lane == 0) part[wv][d] = s;
+  }
+  __syncthreads();
+  if (tid < 8) ze[tid] = tid < dim ? ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + in_b[tid] : 0.f;
+  __syncthreads();
+  // ---- nearest codeword on the unit sphere
+  float e[8], en2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) en2 = fmaf(ze[d], ze[d], en2);
+  const float einv = 1.0f / fmaxf(sqrtf(en2), 1e-12f);     // F.normalize: x / max(|x|, eps)
+  float e2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { e[d] = ze[d] * einv; e2 = fmaf(e[d], e[d], e2); }
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = tid; j < size; j += 256) {
+    float c[8], cn2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { c[d] = d < dim ? cb[(size_t)j * dim + d] : 0.f; cn2 = fmaf(c[d], c[d], cn2); }
+    const float cinv = 1.0f / fmaxf(sqrtf(cn2), 1e-12f);
+    float dot = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { const float cn = c[d] * cinv; dot = fmaf(e[d], cn, dot); c2 = fmaf(cn, cn, c2); }
+    const float score = -((e2 - 2.0f * dot) + c2);
+    if (score > bv) { bv = score; bi = j; }                // ascending j per thread: first index kept on ties
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (lane == 0) { bestv[wv] = bv; besti[wv] = bi; }
+  __syncthreads();
+  float fv = bestv[0];
+  int fi = besti[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (bestv[w] > fv || (bestv[w] == fv && besti[w] < fi)) { fv = bestv[w]; fi = besti[w]; }
+  // ---- residual -= out_proj(z_e + (codeword - z_e))
+  float zq[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) zq[d] = d < dim ? ze[d] + (cb[(size_t)fi * dim + d] - ze[d]) : 0.f;
+  for (int c = tid; c < latent; c += 256) {
+    float o = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+      if (d < dim) o = fmaf(out_w[(size_t)c * dim + d], zq[d], o);
+    res[c] -= o + out_b[c];
+  }
+  if (tid == 0) codes[((size_t)(row / T) * K + k) * T + (row % T)] = fi;
 }
 
 extern "C" {
@@ -458,6 +581,73 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   const int C = c->conv_out.cin;
   if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
   VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
+  return 0;
+}
+
+size_t vaura_dac_encode_workspace_elems(const vaura_codec_encoder* c, int B, int64_t n_samples) {
+  if (!c || B <= 0 || n_samples <= 0) return 0;
+  size_t L = (size_t)n_samples, best = L * (size_t)c->enc_dim;
+  int ch = c->enc_dim;
+  for (int b = 0; b < c->n_blocks; ++b) {
+    L /= (size_t)c->rates[b];
+    ch *= 2;
+    if (L * ch > best) best = L * ch;
+  }
+  if (L * (size_t)c->latent_dim > best) best = L * (size_t)c->latent_dim;
+  return best * (size_t)B;
+}
+
+int vaura_dac_encode(const vaura_codec_encoder* c, const float* wav, int B, int64_t n_samples, int32_t* codes, vaura_stream_t s_) {
+  if (!c || !wav || !codes || B <= 0 || n_samples <= 0) return VAURA_ERR_ARG;
+  if (c->n_blocks < 1 || c->n_blocks > 4 || c->n_units != 3 || c->n_codebooks > 16 || c->codebook_dim > 8 ||
+      c->codebook_size > 1024 || c->latent_dim > 2048 || (c->enc_dim % 32))
+    return VAURA_ERR_SHAPE;
+  int64_t hop = 1;
+  for (int b = 0; b < c->n_blocks; ++b) hop *= c->rates[b];
+  if (n_samples % hop) return VAURA_ERR_SHAPE;                 // DAC.preprocess pads; the caller hands in the padded clip
+  if (c->ws_elems < vaura_dac_encode_workspace_elems(c, B, n_samples)) return VAURA_ERR_ARG;
+  for (int i = 0; i < 4; ++i) if (!c->ws[i]) return VAURA_ERR_ARG;
+  hipStream_t s = as_stream(s_);
+  float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
+
+  int64_t L = n_samples;
+  int C = c->enc_dim;
+  {
+    const int64_t total = L * (C / 4);
+    VA_LAUNCH(enc_conv_in_kernel, dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, s, wav, c->conv_in_w, c->conv_in_b,
+              c->alpha_res[0][0][0], R, reinterpret_cast<uint16_t*>(A), L, C);
+  }
+  int rc = 0;
+  for (int b = 0; b < c->n_blocks; ++b) {
+    for (int u = 0; u < 3; ++u) {
+      // y = Snake2(conv7(Snake1(x)))   (Snake1 applied by the producer)
+      rc = launch_conv(c->res[b][u][0], A, nullptr, c->alpha_res[b][u][1], nullptr, Y, B, (int)L, 1, s);
+      if (rc) return rc;
+      // x = x + conv1(y); emit Snake_next(x)
+      const float* next_alpha = (u < 2) ? c->alpha_res[b][u + 1][0] : c->alpha_down[b];
+      rc = launch_conv(c->res[b][u][1], Y, R, next_alpha, (u < 2) ? R : nullptr, A, B, (int)L, 1, s);
+      if (rc) return rc;
+    }
+    // strided conv (k = 2r, stride r, pad r/2) == 3-tap conv over rows of r*C channels (see vaura_codec_encoder.down)
+    const int r = c->rates[b];
+    const bool last = b + 1 == c->n_blocks;
+    rc = launch_conv(c->down[b], A, nullptr, last ? c->alpha_out : c->alpha_res[b + 1][0][0], last ? nullptr : Y, Z, B, (int)(L / r), 1, s);
+    if (rc) return rc;
+    L /= r;
+    C *= 2;
+    { float* t = R; R = Y; Y = t; t = A; A = Z; Z = t; }
+  }
+  // Snake (applied by the producer) -> conv k3 -> latent z, fp32 rows (B*T, latent)
+  rc = launch_conv(c->conv_out, A, nullptr, nullptr, Y, nullptr, B, (int)L, 1, s);
+  if (rc) return rc;
+  const int T = (int)L;
+  for (int k = 0; k < c->n_codebooks; ++k) {
+    VA_LAUNCH(rvq_stage_kernel, dim3((unsigned)(B * T)), dim3(256), 0, s, Y,
+              c->in_proj_w + (size_t)k * c->codebook_dim * c->latent_dim, c->in_proj_b + (size_t)k * c->codebook_dim,
+              c->codebooks + (size_t)k * c->codebook_size * c->codebook_dim,
+              c->out_proj_w + (size_t)k * c->latent_dim * c->codebook_dim, c->out_proj_b + (size_t)k * c->latent_dim, codes,
+              c->latent_dim, c->codebook_dim, c->codebook_size, T, c->n_codebooks, k);
+  }
   return 0;
 }
 

@@ -405,3 +405,111 @@ class CodecEngine:
         if caller is not None:
             wav.record_stream(caller)
         return wav
+
+
+class CodecEncoderEngine:
+    """DAC encode (waveform -> codes) on the HIP path; weights from a DAC-1.0.0-keyed state dict
+    (``encoder.block.*``, ``quantizer.quantizers.N.{in_proj,codebook,out_proj}``).  Convolutions run on (hi, lo) fp16
+    pairs like the decoder's default precision."""
+
+    def __init__(self, cfg: CodecCfg, sd: Dict[str, torch.Tensor], device="cuda:0"):
+        _require_cuda(device)
+        self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
+        self._keep = []
+        c = L.CodecEncoder()
+        c.n_codebooks, c.codebook_size, c.codebook_dim, c.latent_dim = (cfg.n_codebooks, cfg.codebook_size,
+                                                                        cfg.codebook_dim, cfg.latent_dim)
+        nb = len(cfg.encoder_rates)
+        assert nb <= 4 and len(cfg.dilations) == 3
+        c.n_blocks, c.n_units, c.enc_dim = nb, 3, cfg.encoder_dim
+        for i, r in enumerate(cfg.encoder_rates):
+            c.rates[i] = r
+        K = cfg.n_codebooks
+        f = lambda p: fold_weight_norm(sd[p + "weight_g"].float(), sd[p + "weight_v"].float())
+        q = "quantizer.quantizers."
+        c.in_proj_w = L.ptr(self._dev(torch.stack([f(f"{q}{k}.in_proj.")[:, :, 0] for k in range(K)])))
+        c.in_proj_b = L.ptr(self._dev(torch.stack([sd[f"{q}{k}.in_proj.bias"].float() for k in range(K)])))
+        c.codebooks = L.ptr(self._dev(torch.stack([sd[f"{q}{k}.codebook.weight"].float() for k in range(K)])))
+        c.out_proj_w = L.ptr(self._dev(torch.stack([f(f"{q}{k}.out_proj.")[:, :, 0] for k in range(K)])))
+        c.out_proj_b = L.ptr(self._dev(torch.stack([sd[f"{q}{k}.out_proj.bias"].float() for k in range(K)])))
+        w0 = f("encoder.block.0.")                                   # (C, 1, 7) -> [tap][C]
+        c.conv_in_w = L.ptr(self._dev(w0[:, 0, :].t()))
+        c.conv_in_b = L.ptr(self._dev(sd["encoder.block.0.bias"]))
+        d = cfg.encoder_dim
+        for b, r in enumerate(cfg.encoder_rates):
+            p = f"encoder.block.{b + 1}.block."
+            for u, dil in enumerate(cfg.dilations):
+                qq = p + f"{u}.block."
+                c.alpha_res[b][u][0] = L.ptr(self._dev(sd[qq + "0.alpha"].reshape(-1)))
+                self._conv(c.res[b][u][0], f(qq + "1.").permute(2, 0, 1), sd[qq + "1.bias"], dil)
+                c.alpha_res[b][u][1] = L.ptr(self._dev(sd[qq + "2.alpha"].reshape(-1)))
+                self._conv(c.res[b][u][1], f(qq + "3.").permute(2, 0, 1), sd[qq + "3.bias"], 1)
+            c.alpha_down[b] = L.ptr(self._dev(sd[p + "3.alpha"].reshape(-1)))
+            self._conv(c.down[b], self.strided_as_three_taps(f(p + "4."), r), sd[p + "4.bias"], 1)
+            d *= 2
+        n = nb + 1
+        c.alpha_out = L.ptr(self._dev(sd[f"encoder.block.{n}.alpha"].reshape(-1)))
+        self._conv(c.conv_out, f(f"encoder.block.{n + 1}.").permute(2, 0, 1), sd[f"encoder.block.{n + 1}.bias"], 1)
+        self.c = c
+        self._ws_key = None
+
+    @staticmethod
+    def strided_as_three_taps(w: torch.Tensor, r: int) -> torch.Tensor:
+        """Conv1d weight (2C, C, 2r) with stride r, pad r/2  ->  [3][2C][r*C]: the same sum written over rows of r*C
+        channels (input (L, C) read as (L/r, r*C)): w'[tau+1][co][q*C + ci] = w[co][ci][tau*r + q + r/2]."""
+        cout, cin, k = w.shape
+        assert k == 2 * r and r % 2 == 0
+        out = torch.zeros(3, cout, r * cin, dtype=w.dtype)
+        for tau in (-1, 0, 1):
+            for qi in range(r):
+                t = tau * r + qi + r // 2
+                if 0 <= t < k:
+                    out[tau + 1, :, qi * cin:(qi + 1) * cin] = w[:, :, t]
+        return out
+
+    def _dev(self, t):
+        d = t.detach().to(self.dev, torch.float32).contiguous()
+        self._keep.append(d)
+        return d
+
+    def _conv(self, cv: L.Conv, wl: torch.Tensor, bias: torch.Tensor, dilation: int):
+        """wl: [taps][Cout][Cin] fp32 -> (hi, lo) fp16 pair layout [taps][Cout][Cin/8][plane][8]."""
+        wl = wl.contiguous().float()
+        taps, cout, cin = wl.shape
+        hi = wl.half()
+        lo = (wl - hi.float()).half()
+        pr = torch.stack([hi.reshape(taps, cout, cin // 8, 8), lo.reshape(taps, cout, cin // 8, 8)], dim=-2)
+        keep = pr.contiguous().to(self.dev)
+        self._keep.append(keep)
+        cv.w = L.ptr(keep)
+        cv.bias = L.ptr(self._dev(bias))
+        cv.cin, cv.cout, cv.taps, cv.dilation, cv.stride = cin, cout, taps, dilation, 1
+
+    @torch.no_grad()
+    def encode(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav (B, 1, N) / (B, N) / (N) on the device -> codes (B, K, ceil(N / hop)) int64.  The zero padding of
+        ``DAC.preprocess`` is applied here."""
+        if wav.dim() == 1:
+            wav = wav[None]
+        if wav.dim() == 3:
+            wav = wav[:, 0]
+        hop = int(math.prod(self.cfg.encoder_rates))
+        B, N = wav.shape
+        T = (N + hop - 1) // hop
+        with off_null_stream(self.dev) as caller:
+            x = torch.zeros(B, T * hop, dtype=torch.float32, device=self.dev)
+            x[:, :N] = wav.to(self.dev, torch.float32)
+            need = self.lib.vaura_dac_encode_workspace_elems(C.byref(self.c), B, T * hop)
+            if self._ws_key is None or self._ws_key < need:
+                self._ws = [torch.empty(need, dtype=torch.float32, device=self.dev) for _ in range(4)]
+                for i in range(4):
+                    self.c.ws[i] = L.ptr(self._ws[i])
+                self.c.ws_elems = need
+                self._ws_key = need
+            codes = torch.empty(B, self.cfg.n_codebooks, T, dtype=torch.int32, device=self.dev)
+            L.check(self.lib.vaura_dac_encode(C.byref(self.c), L.ptr(x), B, T * hop, L.ptr(codes), L.current_stream()),
+                    "vaura_dac_encode")
+            out = codes.to(torch.int64)
+        if caller is not None:
+            out.record_stream(caller)
+        return out

@@ -117,7 +117,9 @@ class VAURAModel(nn.Module):
         if return_attention_weights:
             raise NotImplementedError("attention-weight dumps are not produced by the fused decode path")
         if audio is not None and not prompt_is_encoded:
-            raise NotImplementedError("raw-audio prompts need DAC encode (out of scope); pass encoded tokens")
+            # vaura_model.py:463-469 encodes the prompt here.  (Its unpacking `cat([encoded[0] for encoded in audio])`
+            # expects EnCodec's frame list and breaks on DacModelWrapper's (B, 9, T) tensor; the tensor is used as is.)
+            audio = self.audio_encoder.encode(audio)
         vis = self._handle_visual_conditioning(frames, clip_indices)
         if vis is None:
             raise NotImplementedError("unconditional generation is not built (every config conditions on video)")

@@ -96,6 +96,8 @@ class CodecCfg:
     codebook_dim: int = 8
     sample_rate: int = 44100
     dilations: Tuple[int, ...] = (1, 3, 9)
+    encoder_dim: int = 64                           # DAC 44.1 kHz encoder (row f4): 64 -> 128 -> 256 -> 512 -> 1024
+    encoder_rates: Tuple[int, ...] = (2, 4, 8, 8)
 
     @property
     def hop(self) -> int:
@@ -219,6 +221,31 @@ def codec_state_dict(cfg: CodecCfg = FULL_CODEC, seed: int = 0) -> Dict[str, tor
     n = len(cfg.decoder_rates) + 1
     sd[f"decoder.model.{n}.alpha"] = uniform(f"decoder.model.{n}.alpha", (1, cl, 1), 0.5, 1.5, seed)
     _wn_conv(sd, f"decoder.model.{n + 1}.", 1, cl, 7, seed, gain=0.04)
+    return sd
+
+
+def codec_encoder_state_dict(cfg: CodecCfg = FULL_CODEC, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Encoder half of a ``dac.DAC`` state dict: ``encoder.block.*`` + ``quantizer.quantizers.N.in_proj.*`` (the
+    codebooks / out_proj of ``codec_state_dict`` with the same seed complete the quantizer)."""
+    sd: Dict[str, torch.Tensor] = {}
+    for i in range(cfg.n_codebooks):
+        _wn_conv(sd, f"quantizer.quantizers.{i}.in_proj.", cfg.codebook_dim, cfg.latent_dim, 1, seed, gain=1.0)
+    d = cfg.encoder_dim
+    _wn_conv(sd, "encoder.block.0.", d, 1, 7, seed, gain=1.0)
+    for b, r in enumerate(cfg.encoder_rates):
+        p = f"encoder.block.{b + 1}.block."
+        for u in range(len(cfg.dilations)):
+            q = p + f"{u}.block."
+            sd[q + "0.alpha"] = uniform(q + "0.alpha", (1, d, 1), 0.5, 1.5, seed)
+            _wn_conv(sd, q + "1.", d, d, 7, seed, gain=0.8)
+            sd[q + "2.alpha"] = uniform(q + "2.alpha", (1, d, 1), 0.5, 1.5, seed)
+            _wn_conv(sd, q + "3.", d, d, 1, seed, gain=0.35)
+        sd[p + "3.alpha"] = uniform(p + "3.alpha", (1, d, 1), 0.5, 1.5, seed)
+        _wn_conv(sd, p + "4.", 2 * d, d, 2 * r, seed, gain=1.0)
+        d *= 2
+    n = len(cfg.encoder_rates) + 1
+    sd[f"encoder.block.{n}.alpha"] = uniform(f"encoder.block.{n}.alpha", (1, d, 1), 0.5, 1.5, seed)
+    _wn_conv(sd, f"encoder.block.{n + 1}.", cfg.latent_dim, d, 3, seed, gain=1.0)
     return sd
 
 
