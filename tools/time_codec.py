@@ -1,0 +1,31 @@
+"""Time DAC encode / decode of the full-width codec on the GPU box (DESIGN.md §3.5 numbers).
+    python tools/time_codec.py [clips]"""
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vaura_amd import synth  # noqa: E402
+from vaura_amd.engine import CodecEncoderEngine, CodecEngine  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = "cuda:0"
+cfg = synth.FULL_CODEC
+sd = dict(synth.codec_state_dict(cfg, seed=0))
+sd.update(synth.codec_encoder_state_dict(cfg, seed=0))
+dec, enc = CodecEngine(cfg, sd, dev), CodecEncoderEngine(cfg, sd, dev)
+codes = torch.randint(0, 1024, (B, 9, 220), device=dev)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    wav = dec.decode(codes)
+    enc.encode(wav)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for _ in range(5):
+        wav = dec.decode(codes)
+    ev[1].record()
+    for _ in range(5):
+        back = enc.encode(wav)
+    ev[2].record()
+torch.cuda.synchronize()
+print(f"B={B} clips of 2.56 s: decode {ev[0].elapsed_time(ev[1]) / 5:.2f} ms, encode {ev[1].elapsed_time(ev[2]) / 5:.2f} ms")
