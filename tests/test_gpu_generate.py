@@ -179,11 +179,13 @@ def test_long_context_single_pass_against_live_oracle():
     assert torch.equal(got, ref), float((got == ref).float().mean())
 
 
-@pytest.mark.parametrize("B,cfg_scale", [(2, 1.0), (3, 6.0), (10, 6.0)])
-def test_batched_prompt_prefill_against_live_oracle(B, cfg_scale):
-    """Sliding-window shape (scripts/generate.py:327-365): a 40-token prompt of a 60-token chunk is
-    teacher-forced in two passes of <= 32 positions (one weight stream per pass, not one per position),
-    then 28 positions are generated.  Rows = B or 2B (incl. two ragged row blocks).  Token-exact."""
+@pytest.mark.parametrize("B,cfg_scale,pass_positions", [(2, 1.0, 32), (3, 6.0, 32), (10, 6.0, 32), (3, 6.0, 192), (2, 1.0, 3)])
+def test_batched_prompt_prefill_against_live_oracle(B, cfg_scale, pass_positions, monkeypatch):
+    """Sliding-window shape (scripts/generate.py:327-365): a 40-token prompt of a 60-token chunk is teacher-forced
+    in passes of `pass_positions` (two GEMM passes of <= 32, one pass, or 14 passes of 3 = fewer than 4 row blocks:
+    the register-resident GEMV loop), then 28 positions are generated.  Rows = B or 2B (incl. two ragged row
+    blocks).  Token-exact."""
+    monkeypatch.setattr(DecoderEngine, "PREFILL_POSITIONS", pass_positions)
     from oracle import generate_oracle as go
     from oracle.decoder_oracle import DecoderOracle
     cfg = synth.tiny_sampler(2)

@@ -23,11 +23,32 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
   return VAURA_ERR_SHAPE;
 }
 
+template <int EPI, bool NORM>
+static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
+  const dim3 grid((unsigned)(tiles / (G3M_NW * G3M_T)), (unsigned)((a.R + G3M_RB - 1) / G3M_RB));
+  VA_LAUNCH((gemm3_kernel<EPI, NORM>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  return 0;
+}
+
+// many row blocks (a prompt being teacher-forced): GEMM tiling instead of the register-resident GEMV loop
+static int dispatch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
+  if (epilogue == E3_STORE && norm) return launch_gemm3<E3_STORE, true>(a, tiles, K, s);
+  if (epilogue == E3_STORE && !norm) return launch_gemm3<E3_STORE, false>(a, tiles, K, s);
+  if (epilogue == E3_RESID && !norm) return launch_gemm3<E3_RESID, false>(a, tiles, K, s);
+  if (epilogue == E3_SWIGLU && norm) return launch_gemm3<E3_SWIGLU, true>(a, tiles, K, s);
+  if (epilogue == E3_LOGITS && norm) return launch_gemm3<E3_LOGITS, true>(a, tiles, K, s);
+  return VAURA_ERR_SHAPE;
+}
+
 int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
   Gemv3Args a = a0;
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
   if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
   const int64_t tiles = n_weight_rows / 16;
+  if (!a.wq && a.R >= G3M_RB && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
+    a.wscale = nullptr;
+    return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
+  }
   if (a.wq) {
     a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
     return dispatch3<true>(a, tiles, K, epilogue, norm, s);

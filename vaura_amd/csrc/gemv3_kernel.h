@@ -94,6 +94,51 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
 
 __device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a)); }
 
+// Epilogue shared by the decode GEMV and the prefill GEMM: lane (m = lane & 15, q = lane >> 4) holds columns
+// 4q..4q+3 of row m of each of the T consecutive 16-column tiles starting at tile0 (already scaled by rinv).
+template <int T, int EPI>
+__device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int tile0, int lane, const f32x4* v) {
+  const int m = lane & 15, q = lane >> 4;
+  const int row = rb * 16 + m;
+  if constexpr (EPI == E3_SWIGLU) {
+    static_assert(T % 2 == 0 || EPI != E3_SWIGLU, "SwiGLU needs (w1, w3) tile pairs");
+#pragma unroll
+    for (int pr = 0; pr < T / 2; ++pr) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[2 * pr][r]) * v[2 * pr + 1][r];
+      const int tile = tile0 / 2 + pr;   // tile of the ffn dimension
+      if (a.out) reinterpret_cast<f32x4*>(a.out)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane] = o;
+      if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int tile = tile0 + t;
+      const int c0 = tile * 16 + 4 * q;
+      if constexpr (EPI == E3_LOGITS) {
+        if (row < a.rows) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + c0) = v[t];
+      } else {
+        const size_t idx = ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane;
+        f32x4 o = v[t];
+        if constexpr (EPI == E3_RESID) o += reinterpret_cast<const f32x4*>(a.res)[idx];
+        if (a.out) reinterpret_cast<f32x4*>(a.out)[idx] = o;
+        if (a.ss_out) {
+          float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
+          s += __shfl_xor(s, 16, 64);
+          s += __shfl_xor(s, 32, 64);
+          if (q == 0) a.ss_out[((size_t)rb * (a.N / 16) + tile) * 16 + m] = s;
+        }
+        if (a.outp) {
+          f32x4 u = o;
+          if (a.gain_out) u *= *reinterpret_cast<const f32x4*>(a.gain_out + c0);
+          store_split4(a.outp, row, c0, a.N, u);
+        }
+      }
+    }
+  }
+}
+
 // ABL: ablation bits for tools/microbench only (0 in the product): 1 = no MFMA, 2 = no x loads, 4 = no weight
 // loads, 8 = same k-slice order in every workgroup.
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
@@ -230,44 +275,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
         if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
         v[t] = sacc * rinv;
       }
-      const int row = rb * 16 + m;
-      if constexpr (EPI == E3_SWIGLU) {
-        static_assert(T % 2 == 0 || EPI != E3_SWIGLU, "SwiGLU needs (w1, w3) tile pairs");
-#pragma unroll
-        for (int pr = 0; pr < T / 2; ++pr) {
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[2 * pr][r]) * v[2 * pr + 1][r];
-          const int tile = blockIdx.x * (T / 2) + pr;   // tile of the ffn dimension
-          if (a.out) reinterpret_cast<f32x4*>(a.out)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane] = o;
-          if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int tile = tile0 + t;
-          const int c0 = tile * 16 + 4 * q;
-          if constexpr (EPI == E3_LOGITS) {
-            if (row < a.rows) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + c0) = v[t];
-          } else {
-            const size_t idx = ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane;
-            f32x4 o = v[t];
-            if constexpr (EPI == E3_RESID) o += reinterpret_cast<const f32x4*>(a.res)[idx];
-            if (a.out) reinterpret_cast<f32x4*>(a.out)[idx] = o;
-            if (a.ss_out) {
-              float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
-              s += __shfl_xor(s, 16, 64);
-              s += __shfl_xor(s, 32, 64);
-              if (q == 0) a.ss_out[((size_t)rb * (a.N / 16) + tile) * 16 + m] = s;
-            }
-            if (a.outp) {
-              f32x4 u = o;
-              if (a.gain_out) u *= *reinterpret_cast<const f32x4*>(a.gain_out + c0);
-              store_split4(a.outp, row, c0, a.N, u);
-            }
-          }
-        }
-      }
+      gemv3_epilogue<T, EPI>(a, rb, tile0, lane, v);
     }
   };
 
@@ -275,5 +283,104 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   for (int rb = 1; rb < a.R; ++rb) {
     __syncthreads();
     row_block(rb, false);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prefill GEMM (the prompt of the sliding-window caller, scripts/generate.py:327-365): many row blocks at once.
+// The decode kernel above keeps a workgroup's weight slice in registers and loops the row blocks, so EVERY workgroup
+// streams the activation planes of ALL positions (166 positions x 147 KB through each CU's L2 port: 85 us per GEMV
+// pass of 32 positions).  Here a workgroup owns 64 rows (4 row blocks) x 256 columns: the planes of a 32-deep k-group
+// (12 KB) are staged once in LDS and shared by 8 waves, each wave streams the weight tiles of its own 2 column tiles
+// straight into MFMA A operands (MFMA-tile layout: 1 KB contiguous per tile and k-group).  Same exact 3-plane
+// arithmetic, same epilogues; the K-sum runs in one wave in k order.
+#define G3M_RB 4
+#define G3M_T 2
+#define G3M_NW 8
+template <int EPI, bool NORM>
+__global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) {
+  constexpr int RB = G3M_RB, T = G3M_T, NW = G3M_NW;
+  __shared__ u32x4 xs[2][RB * 3 * 64];
+  __shared__ float rinv_s[RB * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int rb0 = blockIdx.y * RB;
+  const int tile0 = ((int)blockIdx.x * NW + wid) * T;
+  const int KG = K / 32;
+  const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
+  const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
+  constexpr int XL = (RB * 3 * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group (2)
+
+  u32x4 xr[XL], wr[T];
+  auto load_x = [&](int kg) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int idx = tid + i * NW * 64;                 // (rbi, plane, lane') with lane' = q * 16 + m
+      const int rbi = idx / 192, p = (idx / 64) % 3, l = idx & 63;
+      xr[i] = (idx < RB * 192 && rb0 + rbi < a.R) ? Xp[split_index16(rb0 + rbi, p, kg * 4 + (l >> 4), l & 15, K)]
+                                                  : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int idx = tid + i * NW * 64;
+      if (idx < RB * 192) xs[buf][idx] = xr[i];
+    }
+  };
+  auto load_w = [&](int kg) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) wr[t] = __builtin_nontemporal_load(Wp + ((size_t)(tile0 + t) * KG + kg) * 64 + lane);
+  };
+
+  load_x(0);
+  load_w(0);
+  if constexpr (NORM) {   // rinv of the 64 rows: ordered sum of the producer's per-tile partial sums of squares
+    if (tid < RB * 16) {
+      const int rbi = tid >> 4, mm = tid & 15;
+      float ssp = 0.f;
+      if (rb0 + rbi < a.R) {
+        const float* sp = a.ss_in + (size_t)(rb0 + rbi) * a.n_ss_in * 16 + mm;
+        for (int i = 0; i < a.n_ss_in; ++i) ssp += sp[i * 16];
+      }
+      rinv_s[tid] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+    }
+  }
+  store_x(0);
+  __syncthreads();
+
+  f32x4 acc[RB][T][3];
+#pragma unroll
+  for (int r = 0; r < RB; ++r)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kg = 0; kg < KG; ++kg) {
+    const int buf = kg & 1;
+    bf16x8 wf[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) wf[t] = __builtin_bit_cast(bf16x8, wr[t]);
+    if (kg + 1 < KG) { load_x(kg + 1); load_w(kg + 1); }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[buf][(r * 3 + p) * 64 + lane]);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[r][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf, acc[r][t][p], 0, 0, 0);
+      }
+    if (kg + 1 < KG) store_x(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    if (rb0 + r >= a.R) break;
+    const float rinv = NORM ? rinv_s[r * 16 + (lane & 15)] : 1.f;
+    f32x4 v[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = ((acc[r][t][2] + acc[r][t][1]) + acc[r][t][0]) * rinv;
+    gemv3_epilogue<T, EPI>(a, rb0 + r, tile0, lane, v);
   }
 }
