@@ -179,10 +179,10 @@ def test_long_context_single_pass_against_live_oracle():
     assert torch.equal(got, ref), float((got == ref).float().mean())
 
 
-@pytest.mark.parametrize("B,cfg_scale,pass_positions", [(2, 1.0, 32), (3, 6.0, 32), (10, 6.0, 32), (3, 6.0, 192), (2, 1.0, 3)])
+@pytest.mark.parametrize("B,cfg_scale,pass_positions", [(2, 1.0, 32), (3, 6.0, 32), (10, 6.0, 32), (3, 6.0, 192), (2, 1.0, 8)])
 def test_batched_prompt_prefill_against_live_oracle(B, cfg_scale, pass_positions, monkeypatch):
     """Sliding-window shape (scripts/generate.py:327-365): a 40-token prompt of a 60-token chunk is teacher-forced
-    in passes of `pass_positions` (two GEMM passes of <= 32, one pass, or 14 passes of 3 = fewer than 4 row blocks:
+    in passes of `pass_positions` (two GEMM passes of <= 32, one pass, or 5 passes of 8 = fewer than 16 row blocks:
     the register-resident GEMV loop), then 28 positions are generated.  Rows = B or 2B (incl. two ragged row
     blocks).  Token-exact."""
     monkeypatch.setattr(DecoderEngine, "PREFILL_POSITIONS", pass_positions)

@@ -100,12 +100,13 @@ SPLIT_GEMV_CASES = [
     (4096, 1536, L.EPI_RESID, False, 16),
     (1536, 9216, L.EPI_LOGITS, True, 7),
     (1536, 4608, L.EPI_STORE, True, 40),
-    # >= 4 row blocks: the prefill GEMM tiling (bf16 weights; fp8 keeps the row-block loop); 13 blocks = ragged M tile
-    (1536, 4608, L.EPI_STORE, True, 200),
-    (1536, 1536, L.EPI_RESID, False, 64),
-    (1536, 8192, L.EPI_SWIGLU, True, 100),
-    (4096, 1536, L.EPI_RESID, False, 200),
-    (1536, 9216, L.EPI_LOGITS, True, 70),
+    # >= 16 row blocks: the prefill GEMM tiling (bf16 weights; fp8 keeps the row-block loop); 17 / 19 blocks = ragged M tile
+    (1536, 4608, L.EPI_STORE, True, 300),
+    (1536, 1536, L.EPI_RESID, False, 256),
+    (1536, 8192, L.EPI_SWIGLU, True, 260),
+    (4096, 1536, L.EPI_RESID, False, 300),
+    (1536, 9216, L.EPI_LOGITS, True, 270),
+    (1536, 4608, L.EPI_STORE, True, 100),     # 7 row blocks: still the GEMV loop
 ]
 
 

@@ -45,7 +45,9 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
   if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
   const int64_t tiles = n_weight_rows / 16;
-  if (!a.wq && a.R >= G3M_RB && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
+  // GEMM tiling only when there are enough row blocks to fill the chip with 64 x 256 tiles (a prompt pass); a decode
+  // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
+  if (!a.wq && a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
     a.wscale = nullptr;
     return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
   }

@@ -168,18 +168,20 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
   // block; a prefill pass loops row blocks (one per prompt position) over the same registers
   u32x4 wb[T][GW];
+  // activation planes of the current batch of k-groups; the first batch of the NEXT row block is requested as soon as
+  // the last MFMA of this one has been issued, so its round trip runs under the reduction / barrier / epilogue
+  u32x4 xb[GB][3];
+  const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
+  auto load_x = [&](int rb, int b) {
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
+                             : Xp[split_index16(rb, p, (w * G + b * GB + g) * 4 + q, m, K)];
+  };
 
   auto row_block = [&](const int rb, const bool first) {
-    const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
-    u32x4 xb[GB][3];
-    auto load_x = [&](int b) {
-#pragma unroll
-      for (int g = 0; g < GB; ++g)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
-                               : Xp[split_index16(rb, p, (w * G + b * GB + g) * 4 + q, m, K)];
-    };
     if (first) {
       // interleave the issue so that k-group g is complete once W[g] and x[g] have landed
 #pragma unroll
@@ -198,8 +200,6 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
           }
         }
       }
-    } else {
-      load_x(0);
     }
     // rinv inputs: the producer's per-tile partial sums of squares, fetched by the whole workgroup in one
     // go and parked in LDS (a load->add loop in one wave pays an L2 round trip per partial: 2.4 us)
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
-      if (b > 0) load_x(b);
+      if (b > 0) load_x(rb, b);
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
 #pragma unroll
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
         if (first) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (rb + 1 < a.R) load_x(rb + 1, 0);
 
 #pragma unroll
     for (int t = 0; t < T; ++t) red[wid][t][lane] = (acc[t][2] + acc[t][1]) + acc[t][0];
