@@ -184,8 +184,13 @@ __device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, 
 template <int NI>
 __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   constexpr int BN_ = 32 * NI;
-  __shared__ u32x4 Ws[2][BK / 4][BN_ + 1];
-  __shared__ u32x4 Xs[2][BK / 4][XROWS + 1];
+  // one raw LDS block: weight tiles | activation blocks during the main loop, the fp32 output tile afterwards
+  constexpr int WS_ELEMS = 2 * (BK / 4) * (BN_ + 1), XS_ELEMS = 2 * (BK / 4) * (XROWS + 1);
+  constexpr int SP = BN_ + 4;               // padded row stride (floats) of the staged output tile
+  static_assert((WS_ELEMS + XS_ELEMS) * 16 >= BM * SP * 4, "the output tile must fit in the main loop's LDS");
+  __shared__ u32x4 smem[WS_ELEMS + XS_ELEMS];
+  auto Ws = [&](int buf, int kq, int row) -> u32x4& { return smem[(buf * (BK / 4) + kq) * (BN_ + 1) + row]; };
+  auto Xs = [&](int buf, int kq, int row) -> u32x4& { return smem[WS_ELEMS + (buf * (BK / 4) + kq) * (XROWS + 1) + row]; };
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv & 1, wm = wv >> 1;
   const int j0 = blockIdx.x * BM;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   };
   auto store_w = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) { const int qd = tid + 256 * i; Ws[buf][qd & 7][qd >> 3] = wreg[i]; }
+    for (int i = 0; i < NI; ++i) { const int qd = tid + 256 * i; Ws(buf, qd & 7, qd >> 3) = wreg[i]; }
   };
   auto load_x = [&](int c) {
     const int q0 = c * (BK / 4);
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int qd = tid + 256 * i;
-      if ((qd >> 3) < XROWS) Xs[buf][qd & 7][qd >> 3] = xreg[i];
+      if ((qd >> 3) < XROWS) Xs(buf, qd & 7, qd >> 3) = xreg[i];
     }
   };
 
@@ -258,13 +263,13 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
       f16x8 wh[NI], wl[NI], xh[4], xl[4];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        wh[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g][wn * (NI * 16) + i * 16 + r16]);
-        wl[i] = __builtin_bit_cast(f16x8, Ws[buf][2 * g + 1][wn * (NI * 16) + i * 16 + r16]);
+        wh[i] = __builtin_bit_cast(f16x8, Ws(buf, 2 * g, wn * (NI * 16) + i * 16 + r16));
+        wl[i] = __builtin_bit_cast(f16x8, Ws(buf, 2 * g + 1, wn * (NI * 16) + i * 16 + r16));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        xh[j] = __builtin_bit_cast(f16x8, Xs[xb][2 * g][shift + wm * 64 + j * 16 + r16]);
-        xl[j] = __builtin_bit_cast(f16x8, Xs[xb][2 * g + 1][shift + wm * 64 + j * 16 + r16]);
+        xh[j] = __builtin_bit_cast(f16x8, Xs(xb, 2 * g, shift + wm * 64 + j * 16 + r16));
+        xl[j] = __builtin_bit_cast(f16x8, Xs(xb, 2 * g + 1, shift + wm * 64 + j * 16 + r16));
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
@@ -280,27 +285,51 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
     }
   }
 
-  const size_t obase = (size_t)b * a.Lout;
+  // ---- epilogue through LDS: the MFMA layout gives a lane 4 channels of one row (16-byte pieces, 64-byte runs per
+  // row: half cache lines for the fp32 stream, 8-byte pieces for the pair stream); staging the tile lets every thread
+  // own a whole octet of a row, so residual reads and both output streams move 32 contiguous bytes per thread and
+  // whole 128-byte lines per 4 threads.  (The main loop ended with a barrier: its LDS is free.)
+  float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int jr = j0 + wm * 64 + j * 16 + r16;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = wm * 64 + j * 16 + r16, col = wn * (NI * 16) + i * 16 + 4 * g;
+      *reinterpret_cast<f32x4*>(stage + row * SP + col) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + n0 + col);
+    }
+  __syncthreads();
+  constexpr int OCT = BN_ / 8;              // octets per tile row
+  const size_t obase = (size_t)b * a.Lout;
+  for (int u = tid; u < BM * OCT; u += 256) {
+    const int row = u / OCT, oc = u - row * OCT;
+    const int jr = j0 + row;
     if (jr >= a.jcount) continue;
     const int orow = jr * a.ostride + a.oshift0 + ph;
     if (orow < 0 || orow >= a.Lout) continue;
+    const int co = n0 + oc * 8;
+    const size_t o = (obase + (size_t)orow) * a.Cout + co;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8 + 4);
+    if (a.res) {
+      v0 = *reinterpret_cast<const f32x4*>(a.res + o) + v0;
+      v1 = *reinterpret_cast<const f32x4*>(a.res + o + 4) + v1;
+    }
+    if (a.out_raw) {
+      *reinterpret_cast<f32x4*>(a.out_raw + o) = v0;
+      *reinterpret_cast<f32x4*>(a.out_raw + o + 4) = v1;
+    }
+    if (a.out_act) {
+      const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.alpha + co), al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4);
+      f16x8 hi, lo;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int co = n0 + wn * (NI * 16) + i * 16 + 4 * g;
-      const size_t o = (obase + (size_t)orow) * a.Cout + co;
-      f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + co);
-      if (a.res) v = *reinterpret_cast<const f32x4*>(a.res + o) + v;
-      if (a.out_raw) *reinterpret_cast<f32x4*>(a.out_raw + o) = v;
-      if (a.out_act) {
-        const f32x4 al = *reinterpret_cast<const f32x4*>(a.alpha + co);
-        f32x4 sn;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sn[r] = snake_f(v[r], al[r]);
-        store_pair4(a.out_act, obase + (size_t)orow, co, a.Cout, sn);
+      for (int r = 0; r < 4; ++r) {
+        const float s0 = snake_f(v0[r], al0[r]), s1 = snake_f(v1[r], al1[r]);
+        hi[r] = (_Float16)s0; lo[r] = (_Float16)(s0 - (float)hi[r]);
+        hi[r + 4] = (_Float16)s1; lo[r + 4] = (_Float16)(s1 - (float)hi[r + 4]);
       }
+      f16x8* dst = reinterpret_cast<f16x8*>(a.out_act + (((obase + (size_t)orow) * (size_t)(a.Cout >> 3) + (size_t)(co >> 3)) * 2) * 8);
+      dst[0] = hi;
+      dst[1] = lo;
     }
   }
 }
