@@ -11,7 +11,11 @@ src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
 # ---- kernel stats (rocprofv3 --kernel-trace --stats)
-stats = glob.glob(f"{src}/stats/**/*kernel_stats.csv", recursive=True)[0]
+def newest(pattern):
+    return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1]
+
+
+stats = newest(f"{src}/stats/**/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
@@ -24,7 +28,7 @@ open(f"profiles/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else
 
 # ---- PMC: HBM bytes per launch for the dominant kernel
 def per_kernel(path, counter):
-    f = glob.glob(f"{path}/**/*counter_collection.csv", recursive=True)[0]
+    f = newest(f"{path}/**/*counter_collection.csv")
     acc = defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
