@@ -179,12 +179,15 @@ int vaura_sample(const float* logits, int B, int K, int vocab, const vaura_sampl
 int vaura_decode_step(const vaura_decoder* dec, const vaura_sampling* sp, int sample, vaura_stream_t s);
 
 /* a1  the hot loop of VAURAModel.generate (vaura_model.py:502-547): `n_prefill` teacher-forced
- * positions then `n_steps` sampled ones, all enqueued back-to-back.  use_graph != 0 replays a
- * captured single-step hipGraph (must have been built with vaura_step_graph_build).             */
+ * positions then `n_steps` sampled ones, all enqueued back-to-back.  graph != NULL replays a captured single-step
+ * hipGraph per position (the position lives in dec->state); NULL launches every kernel eagerly.
+ * vaura_step_graph_build captures one step of (dec, sp) on `s` (not the legacy null stream) into a handle the caller
+ * owns: it is valid for exactly the buffers / shapes / sampling parameters it was built from.   */
+typedef void* vaura_step_graph_t;
 int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_prefill, int n_steps,
-                        int use_graph, vaura_stream_t s);
-int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s);
-void vaura_step_graph_free(void);
+                        vaura_step_graph_t graph, vaura_stream_t s);
+int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s, vaura_step_graph_t* out);
+void vaura_step_graph_free(vaura_step_graph_t graph);
 
 /* Measurement aid (bench.py): runs `n_steps` sampled steps eagerly on `s` with a hipEvent pair
  * around every launch of the kernel kinds selected by `kind_mask` (bit = vaura_kernel_kind), then

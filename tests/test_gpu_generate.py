@@ -304,3 +304,18 @@ def test_codec_round_trip_through_the_plugin():
     assert back.shape == (2, 9, 7) and back.dtype == torch.int64 and int(back.min()) >= 0 and int(back.max()) < 1024
     one = m(wav[0, 0])                                        # forward == encode; 1-D input is unsqueezed twice
     assert torch.equal(one, back[:1])
+
+
+def test_two_engines_interleaved_keep_their_own_step_graphs(tiny_sampler_sd):
+    """Each engine owns the hipGraph it captured (vaura_step_graph_build returns a handle): A, B, A again must
+    not replay B's graph against A's buffers."""
+    a = DecoderEngine(synth.tiny_sampler(2), tiny_sampler_sd, DEV, wdtype="bf16")
+    b = DecoderEngine(synth.tiny_sampler(2), synth.sampler_state_dict(synth.tiny_sampler(2), seed=9), DEV, wdtype="bf16")
+    fa, fb = synth.video_features(2, seed=1).to(DEV), synth.video_features(3, seed=2).to(DEV)
+    a1 = a.generate_codes(fa, 16, cfg_scale=6.0).cpu()
+    b1 = b.generate_codes(fb, 16).cpu()
+    a2 = a.generate_codes(fa, 16, cfg_scale=6.0).cpu()
+    b2 = b.generate_codes(fb, 16).cpu()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a1[:, :, :8], b1[:2, :, :8])
+    eager = a.generate_codes(fa, 16, cfg_scale=6.0, use_graph=False).cpu()
+    assert torch.equal(a1, eager)

@@ -102,9 +102,9 @@ SIGNATURES = {
     "vaura_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Sampling), C.c_void_p, C.c_int64,
                                C.c_void_p, C.c_void_p]),
     "vaura_decode_step": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_void_p]),
-    "vaura_generate_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "vaura_step_graph_build": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_void_p]),
-    "vaura_step_graph_free": (None, []),
+    "vaura_generate_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vaura_step_graph_build": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "vaura_step_graph_free": (None, [C.c_void_p]),
     "vaura_profile_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_uint, C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64), C.c_void_p]),
     "vaura_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

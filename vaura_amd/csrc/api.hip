@@ -200,8 +200,11 @@ static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sa
   return rc;
 }
 
-static hipGraphExec_t g_step_exec = nullptr;
-static hipGraph_t g_step_graph = nullptr;
+// one captured decode step; owned by the caller (one per decoder descriptor / sampling setup)
+struct StepGraph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
 
 extern "C" {
 
@@ -227,30 +230,35 @@ int vaura_decode_step(const vaura_decoder* dec, const vaura_sampling* sp, int sa
   return enqueue_step(dec, sp, sample, as_stream(s));
 }
 
-void vaura_step_graph_free(void) {
-  if (g_step_exec) { (void)hipGraphExecDestroy(g_step_exec); g_step_exec = nullptr; }
-  if (g_step_graph) { (void)hipGraphDestroy(g_step_graph); g_step_graph = nullptr; }
+void vaura_step_graph_free(vaura_step_graph_t g_) {
+  StepGraph* g = static_cast<StepGraph*>(g_);
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
 }
 
-int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s) {
+int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, vaura_stream_t s, vaura_step_graph_t* out) {
   int rc = check_decoder(dec);
   if (rc) return rc;
-  if (!sp) return VAURA_ERR_ARG;
-  vaura_step_graph_free();
+  if (!sp || !out) return VAURA_ERR_ARG;
+  *out = nullptr;
+  StepGraph* g = new StepGraph();
   hipStream_t st = as_stream(s);
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) { delete g; return (int)e; }
   rc = enqueue_step(dec, sp, 1, st);
-  e = hipStreamEndCapture(st, &g_step_graph);
-  if (rc) { vaura_step_graph_free(); return rc; }
-  if (e != hipSuccess) return (int)e;
-  e = hipGraphInstantiate(&g_step_exec, g_step_graph, nullptr, nullptr, 0);
-  if (e != hipSuccess) { vaura_step_graph_free(); return (int)e; }
+  e = hipStreamEndCapture(st, &g->graph);
+  if (rc) { vaura_step_graph_free(g); return rc; }
+  if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
+  *out = g;
   return 0;
 }
 
-int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_prefill, int n_steps, int use_graph,
-                        vaura_stream_t s) {
+int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_prefill, int n_steps,
+                        vaura_step_graph_t graph, vaura_stream_t s) {
   int rc = check_decoder(dec);
   if (rc) return rc;
   if (!sp || n_prefill < 0 || n_steps < 0) return VAURA_ERR_ARG;
@@ -270,10 +278,11 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
       if (rc) return rc;
     }
   }
-  if (use_graph) {
-    if (!g_step_exec) return VAURA_ERR_STATE;
+  if (graph) {
+    StepGraph* g = static_cast<StepGraph*>(graph);
+    if (!g->exec) return VAURA_ERR_STATE;
     for (int i = 0; i < n_steps; ++i) {
-      hipError_t e = hipGraphLaunch(g_step_exec, st);
+      hipError_t e = hipGraphLaunch(g->exec, st);
       if (e != hipSuccess) return (int)e;
     }
     return 0;

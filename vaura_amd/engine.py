@@ -110,7 +110,7 @@ class DecoderEngine:
                            cfg.codebook_dim, 7, cfg.layer_norm_eps)
         self.dec: Optional[L.Decoder] = None
         self._shape = None
-        self._graph_key = None
+        self._graph, self._graph_key = None, None
         self.weight_bytes = sum(t.numel() * t.element_size() for t in self._keep)
 
     # ------------------------------------------------------------------ helpers
@@ -261,11 +261,25 @@ class DecoderEngine:
             st = L.current_stream()
             if use_graph:
                 key = (self._shape, L.ptr(noise), bytes(sp))
-                if self._graph_key != key:
-                    L.check(self.lib.vaura_step_graph_build(C.byref(self.dec), C.byref(sp), st), "vaura_step_graph_build")
-                    self._graph_key = key
-            L.check(self.lib.vaura_generate_loop(C.byref(self.dec), C.byref(sp), n_prefill, n_steps, int(use_graph), st),
-                    "vaura_generate_loop")
+                if self._graph_key != key:       # the captured step is tied to these buffers / parameters
+                    self._free_graph()
+                    handle = C.c_void_p()
+                    L.check(self.lib.vaura_step_graph_build(C.byref(self.dec), C.byref(sp), st, C.byref(handle)),
+                            "vaura_step_graph_build")
+                    self._graph, self._graph_key = handle, key
+            L.check(self.lib.vaura_generate_loop(C.byref(self.dec), C.byref(sp), n_prefill, n_steps,
+                                                 self._graph if use_graph else None, st), "vaura_generate_loop")
+
+    def _free_graph(self):
+        if getattr(self, "_graph", None):
+            self.lib.vaura_step_graph_free(self._graph)
+        self._graph, self._graph_key = None, None
+
+    def __del__(self):
+        try:
+            self._free_graph()
+        except Exception:
+            pass
 
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T
