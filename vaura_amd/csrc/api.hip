@@ -26,7 +26,7 @@ static int check_decoder(const vaura_decoder* d) {
 // start/stop events (see VA_LAUNCH), i.e. the interval rocprofv3's kernel trace reports.
 // A step stage may be more than one launch (range-split attention = split + combine): every launch gets its own
 // pair, a stage's time is the sum over its launches, and `stages` counts the brackets.
-int va_prof_kind = -1;
+thread_local int va_prof_kind = -1;   // per calling thread: one caller thread per device
 struct StepProfiler {
   unsigned mask = 0;
   std::vector<hipEvent_t> ev[VAURA_K_COUNT];
@@ -38,7 +38,7 @@ struct StepProfiler {
   }
   void after(int) { va_prof_kind = -1; }
 };
-static StepProfiler* g_prof = nullptr;
+static thread_local StepProfiler* g_prof = nullptr;
 void va_prof_events(hipEvent_t* a, hipEvent_t* b) {
   (void)hipEventCreate(a); (void)hipEventCreate(b);
   g_prof->ev[va_prof_kind].push_back(*a); g_prof->ev[va_prof_kind].push_back(*b);

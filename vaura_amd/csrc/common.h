@@ -17,7 +17,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // earlier, unrelated runtime call (observed: hipErrorNoDevice from a device probe) is not reported here.
 // When vaura_profile_loop arms va_prof_start/stop the launch carries its own start/stop events
 // (hipExtLaunchKernelGGL): they time exactly the kernel, like rocprofv3's kernel trace does.
-extern int va_prof_kind;
+extern thread_local int va_prof_kind;
 void va_prof_events(hipEvent_t* start, hipEvent_t* stop);
 #define VA_LAUNCH(kern, grid, block, smem, stream, ...)                                              \
   do {                                                                                               \
