@@ -120,6 +120,8 @@ typedef struct vaura_decoder {
 
   float* ws_h;               /* packed rows (rows x d_model) residual stream        */
   float* ws_qkv;             /* packed rows (rows x 3*d_model)                      */
+  float* ws_qkv2;            /* optional, same shape (one position's worth): with bf16 storage the decode step's qkv GEMV
+                                then runs as two K-half workgroup sets (ws_qkv, ws_qkv2) that attention adds on load   */
   float* ws_attn;            /* packed rows (rows x d_model)                        */
   float* ws_ffn;             /* packed rows (rows x ffn_dim)                        */
   float* ws_logits;          /* row-major (rows, K*vocab)                           */
@@ -212,6 +214,8 @@ int vaura_gemv(const void* w, int wdtype, const float* x, const float* gain, con
  * (fused RMSNorm) or NULL.  Optional outputs: fp32 packed rows, split rows of out*gain_out, partial
  * sums of squares of out.  epilogue: 0 store, 1 +residual, 2 SwiGLU pairs, 4 row-major logits.       */
 int vaura_gemv_bf16(const void* w, int wdtype /* BF16 | FP8 */, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+                    float* out_khalf2 /* NULL, or (bf16, K = 1536, fused norm, store): `out` gets the partial over the first half
+                                         of K and this buffer the second half's; the consumer adds them */,
                     uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s);
 /* packed rows (rows x C) fp32 [* gain] -> split rows (3 * rows_padded * C bf16) [+ partial sums of squares] */

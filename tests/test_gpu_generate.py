@@ -224,25 +224,29 @@ def test_fp8_weights_against_live_oracle_on_dequantised_checkpoint():
 
 
 def test_fp8_full_size_agreement_with_bf16(full_sampler_sd):
-    """Full-depth model, configs[1] sampling settings, same Philox noise: (1) the fp8 engine equals the bf16
-    engine run on the dequantised checkpoint token for token (same real-number weights, different storage and
-    kernels); (2) agreement with the unquantised model is REPORTED (fp8 changes the model; no reference number
-    exists for it): teacher-forced logits error and sampled-token agreement."""
+    """Full-depth model: (1) the fp8 engine against the bf16 engine run on the dequantised checkpoint (same real-number
+    weights, different storage and kernel instances, hence different fp32 summation order): teacher-forced logits
+    within 2e-5, greedy tokens identical; (2) agreement with the unquantised model is REPORTED (fp8 changes the model;
+    no reference number exists for it): logits error, top-1 agreement, sampled-token agreement with the same Philox
+    noise at configs[1] sampling settings."""
     from vaura_amd import quant
     cfg = synth.FULL_SAMPLER
     feats = synth.video_features(2, seed=5).to(DEV)
     kw = dict(use_sampling=True, top_k=250, cfg_scale=6.0, seed=7)
     e8 = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype="fp8")
     tok8 = e8.generate_codes(feats, 220, **kw).cpu()
+    greedy8 = e8.generate_codes(feats, 220, cfg_scale=6.0).cpu()
     idx = tok8[:, :, :40].contiguous()
     lg8 = e8.logits_all_positions(idx.to(DEV), feats).cpu()
     del e8
     torch.cuda.empty_cache()
     e_eff = DecoderEngine(cfg, quant.fp8_effective_state_dict(full_sampler_sd), DEV, wdtype="bf16")
-    tok_eff = e_eff.generate_codes(feats, 220, **kw).cpu()
+    greedy_eff = e_eff.generate_codes(feats, 220, cfg_scale=6.0).cpu()
+    lg_eff = e_eff.logits_all_positions(idx.to(DEV), feats).cpu()
     del e_eff
     torch.cuda.empty_cache()
-    assert torch.equal(tok8, tok_eff), float((tok8 == tok_eff).float().mean())
+    assert float((lg8 - lg_eff).abs().max()) < 2e-5, float((lg8 - lg_eff).abs().max())
+    assert torch.equal(greedy8, greedy_eff), float((greedy8 == greedy_eff).float().mean())
     e16 = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype="bf16")
     tok16 = e16.generate_codes(feats, 220, **kw).cpu()
     lg16 = e16.logits_all_positions(idx.to(DEV), feats).cpu()

@@ -161,6 +161,29 @@ def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
             assert rel_err(ssum, (got * got).sum(-1)) < 1e-5
 
 
+@pytest.mark.parametrize("rows", [16, 5, 40])
+def test_k_split_gemv_partials_add_up(rows):
+    """Decode qkv instance: two workgroup sets over the two halves of K write two partial outputs which the consumer
+    (attention) adds on load — their sum is the fused-norm GEMV."""
+    K, N = 1536, 4608
+    g = torch.Generator().manual_seed(rows)
+    w = synth.to_bf16_exact(torch.randn(N, K, generator=g) * 0.02)
+    x = torch.randn(rows, K, generator=g)
+    gain = torch.rand(K, generator=g) + 0.5
+    xs, ss = ops.split_rows(ops.pack_rows(x.to(DEV)), rows, K, gain.to(DEV), want_ss=True)
+    rp = (rows + 15) // 16 * 16
+    out2 = torch.full((rp * N,), float("nan"), device=DEV)
+    out, _, _ = ops.gemv_bf16(ops.pack_weight(w.to(DEV), L.W_BF16), xs, rows, N, K, L.EPI_STORE, ss_in=ss, out_khalf2=out2)
+    x64 = x.double()
+    ref = ((x64 * gain.double()) * torch.rsqrt(torch.mean(x64 * x64, dim=-1, keepdim=True) + 1e-5)) @ w.double().t()
+    a, b = ops.unpack_rows(out, rows, N).cpu().double(), ops.unpack_rows(out2, rows, N).cpu().double()
+    assert rel_err(a + b, ref) < 3e-6
+    assert float(b.abs().max()) > 0.01 and rel_err(a, ref) > 0.1        # each half really is a partial
+    with pytest.raises(L.VauraHipError):                                 # only that instance is compiled
+        ops.gemv_bf16(ops.pack_weight(w[:1536].to(DEV), L.W_BF16), xs, rows, 1536, K, L.EPI_RESID,
+                      residual=torch.zeros(rp * 1536, device=DEV), out_khalf2=out2)
+
+
 def test_fp8_pack_matches_host_quantiser():
     """Device quantiser (vaura_pack_weight, VAURA_W_FP8) == the torch statement of the format: same
     power-of-two row scales, same round-to-nearest-even e4m3 codes, laid out as fp8 tile pairs."""

@@ -45,7 +45,7 @@ class Decoder(C.Structure):
                 ("empty_video", C.c_void_p), ("rope", C.c_void_p), ("cond_proj", C.c_void_p),
                 ("kcache", C.c_void_p), ("vcache", C.c_void_p), ("seq", C.c_void_p), ("state", C.c_void_p),
                 ("noise", C.c_void_p),
-                ("ws_h", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_attn", C.c_void_p), ("ws_ffn", C.c_void_p),
+                ("ws_h", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_qkv2", C.c_void_p), ("ws_attn", C.c_void_p), ("ws_ffn", C.c_void_p),
                 ("ws_logits", C.c_void_p),
                 ("ws_h_split", C.c_void_p), ("ws_attn_split", C.c_void_p), ("ws_ffn_split", C.c_void_p),
                 ("ws_ss", C.c_void_p), ("first_norm", C.c_void_p), ("ws_attn_part", C.c_void_p)]
@@ -109,7 +109,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_int64), C.c_void_p]),
     "vaura_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                              C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
-    "vaura_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "vaura_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vaura_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "vaura_attention_step_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -50,7 +50,7 @@ static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const
                     const float* gain_out, float* ss_out, const vaura_decoder* d, int N, int n_pos = 1) {
   Gemv3Args a;
   // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay bf16
-  a.wq = (d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0; a.wscale = nullptr;
+  a.wq = (d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0; a.wscale = nullptr; a.out2 = nullptr;
   a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
   a.gain_out = gain_out; a.ss_out = ss_out;
   a.R = n_pos * ((d->rows + 15) / 16);           // prefill: one group of row blocks per position
@@ -103,16 +103,19 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   PROF_A(VAURA_K_EMBED);
   if (rc) return rc;
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
+  // K-split qkv (consumer-reduced): bf16 storage, fewer than 16 row blocks (otherwise the GEMM tiling takes over)
+  float* qkv2 = (d->ws_qkv2 && d->wdtype == VAURA_W_BF16 && (rows + 15) / 16 < 16) ? d->ws_qkv2 : nullptr;
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
     PROF_B(VAURA_K_QKV);   // qkv = rinv * Wqkv.(g*h)                                  llama.py:280, 228
-    rc = va_launch_gemv3(g3(L.wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D), 3 * D, D,
-                         E3_STORE, true, s);
+    Gemv3Args aq = g3(L.wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D);
+    aq.out2 = qkv2;        // two K-half partials, added by the attention kernel on load
+    rc = va_launch_gemv3(aq, 3 * D, D, E3_STORE, true, s);
     PROF_A(VAURA_K_QKV);
     if (rc) return rc;
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
-    rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
+    rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
     PROF_A(VAURA_K_ATTN);
@@ -165,7 +168,7 @@ static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sa
     if (rc) return rc;
     // rope + cache append + softmax(qK^T)V                               llama.py:234-257
     PROF_B(VAURA_K_ATTN);
-    rc = va_launch_attention(d->ws_qkv, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, nullptr, rows,
+    rc = va_launch_attention(d->ws_qkv, nullptr, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, nullptr, rows,
                              H, hd, d->max_len, d->state, 0, d->ws_attn_part,
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
     PROF_A(VAURA_K_ATTN);

@@ -17,6 +17,7 @@
 template <int HD>
 __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     const float* __restrict__ qkv,   // packed rows (rows x 3*D)
+    const float* __restrict__ qkv2,  // optional second K-half partial of qkv (decode), added on load
     const float* __restrict__ rope,  // (max_len, HD/2, 2)
     float* __restrict__ kcache,      // (rows, H, max_len, HD)
     float* __restrict__ vcache,
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     const int which = tid / QUADS, cq = tid % QUADS;
     const int col = which * D + h * HD + cq * 4;
     f32x4 x = reinterpret_cast<const f32x4*>(qkv)[packed_quad(vrow, col >> 2, 3 * D)];
+    if (qkv2) x += reinterpret_cast<const f32x4*>(qkv2)[packed_quad(vrow, col >> 2, 3 * D)];
     if (which < 2 && !prefill) {
       const f32x4 cs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
       f32x4 y;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
 // NU = number of 64-position passes that hold cached rows (0..4).  One straight-line body per NU: the compiler
 // then waits with exact vmcnt values (vmcnt retires in order), and short caches issue no dead loads.
 template <int HD, int NU>
-__device__ __forceinline__ void attention256_body(const float* __restrict__ qkv, const float* __restrict__ rope,
+__device__ __forceinline__ void attention256_body(const float* __restrict__ qkv, const float* __restrict__ qkv2,
+                                                  const float* __restrict__ rope,
                                                   float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ out,
                                                   uint16_t* __restrict__ outp, int n_head, int pos, f32x4* sqkv,
                                                   f32x4 (*wacc)[HD / 4], float* wm, float* wl) {
@@ -210,9 +213,10 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   //         before V.  Slots past the end of the last pass re-read the last cached row and are masked below.
   const int gt = min(tid, 3 * QUADS - 1);
   const int which = gt / QUADS, cq = gt % QUADS;
-  const f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
+  f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
+  if (qkv2) gx += reinterpret_cast<const f32x4*>(qkv2)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
   const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
-  __builtin_amdgcn_sched_barrier(0);   // keep these two first in program order (the scheduler sinks them otherwise)
+  __builtin_amdgcn_sched_barrier(0);   // keep these first in program order (the scheduler sinks them otherwise)
   f32x4 kf[NUA][QPL], vf[NUA][QPL];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -324,7 +328,7 @@ template <int HD>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
     const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
     float* __restrict__ out, uint16_t* __restrict__ outp, int n_head, int max_len, const int32_t* __restrict__ pos_dev,
-    int pos_host) {
+    int pos_host, const float* __restrict__ qkv2) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];   // rotated q | rotated k | v of the new position | scratch
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -333,11 +337,11 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
   float* kc = kcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
   float* vc = vcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
   switch ((pos + 63) >> 6) {
-    case 0: attention256_body<HD, 0>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    case 1: attention256_body<HD, 1>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    case 2: attention256_body<HD, 2>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    case 3: attention256_body<HD, 3>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    default: attention256_body<HD, 4>(qkv, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
   }
 }
 
@@ -409,7 +413,8 @@ struct AttentionBlock {
 // NU0 = passes of the FIRST block of this split's range (0 = empty range): its loads are requested before the
 // new q/k/v quad is waited for, so the gather / rotation / barrier runs under the cache round trip.
 template <int HD, int NU0>
-__device__ __forceinline__ void attention_split_body(const float* __restrict__ qkv, const float* __restrict__ rope,
+__device__ __forceinline__ void attention_split_body(const float* __restrict__ qkv, const float* __restrict__ qkv2,
+                                                     const float* __restrict__ rope,
                                                      float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ pp,
                                                      int n_head, int pos, int lo, int hi, bool last, f32x4* sqkv,
                                                      f32x4 (*wacc)[HD / 4], float* wm, float* wl) {
@@ -424,7 +429,8 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
   // new q/k/v quad of this head + rope entry, then the first block of the cache range
   const int gt = min(tid, 3 * QUADS - 1);
   const int which = gt / QUADS, cq = gt % QUADS;
-  const f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
+  f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
+  if (qkv2) gx += reinterpret_cast<const f32x4*>(qkv2)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
   const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);
   __builtin_amdgcn_sched_barrier(0);
   AttentionBlock<HD, NU0 ? NU0 : 1> first;
@@ -515,7 +521,8 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
 template <int HD>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
     const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
-    float* __restrict__ part, int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host) {
+    float* __restrict__ part, int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host,
+    const float* __restrict__ qkv2) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -529,11 +536,11 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
   float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
   float* pp = part + (((size_t)row * n_head + h) * n_split + z) * ATT_PART_STRIDE(HD);
   switch (hi > lo ? min(4, (hi - lo + 63) >> 6) : 0) {
-    case 0: attention_split_body<HD, 0>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
-    case 1: attention_split_body<HD, 1>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
-    case 2: attention_split_body<HD, 2>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
-    case 3: attention_split_body<HD, 3>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
-    default: attention_split_body<HD, 4>(qkv, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 0: attention_split_body<HD, 0>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 1: attention_split_body<HD, 1>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 2: attention_split_body<HD, 2>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    case 3: attention_split_body<HD, 3>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
+    default: attention_split_body<HD, 4>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
   }
 }
 
@@ -595,25 +602,25 @@ int va_attention_splits(int rows, int n_head, int max_len) {
   return pairs >= 256 ? 1 : max(1, min(8, 256 / pairs));
 }
 
-int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, uint16_t* outp, int rows,
-                        int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, float* part, int n_split,
-                        hipStream_t s) {
+int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
+                        uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
+                        float* part, int n_split, hipStream_t s) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
     if (n_split > 8) return VAURA_ERR_ARG;
     VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, part,
-              n_head, max_len, pos_dev, pos_host);
+              n_head, max_len, pos_dev, pos_host, qkv2);
     VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split);
     return 0;
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
     VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, out, outp,
-              n_head, max_len, pos_dev, pos_host);
+              n_head, max_len, pos_dev, pos_host, qkv2);
     return 0;
   }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
-  VA_LAUNCH(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, rope, kc, vc, out, outp,
+  VA_LAUNCH(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, qkv2, rope, kc, vc, out, outp,
             n_head, max_len, pos_dev, pos_host, 0);
   return 0;
 }
@@ -632,7 +639,7 @@ int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n
   if (hd != 96) return VAURA_ERR_SHAPE;
   const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + d->max_len + 4);
-  VA_LAUNCH(attention_step_kernel<96>, dim3(H, d->rows, n_pos), dim3(ATT_THREADS), smem, s, d->ws_qkv, d->rope,
+  VA_LAUNCH(attention_step_kernel<96>, dim3(H, d->rows, n_pos), dim3(ATT_THREADS), smem, s, d->ws_qkv, (const float*)nullptr, d->rope,
             d->kcache + layer * kv_layer, d->vcache + layer * kv_layer, d->ws_attn, d->ws_attn_split, H, d->max_len, nullptr,
             p0, (d->rows + 15) / 16 * 16);
   return 0;
@@ -641,8 +648,8 @@ int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n
 extern "C" int vaura_attention_step(const float* qkv, const float* rope, float* kcache, float* vcache, float* out,
                                     int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s) {
   if (pos < 0 || pos >= max_len) return VAURA_ERR_ARG;
-  return va_launch_attention(qkv, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos, nullptr, 1,
-                             as_stream(s));
+  return va_launch_attention(qkv, nullptr, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos,
+                             nullptr, 1, as_stream(s));
 }
 
 extern "C" int vaura_attention_splits(int rows, int n_head, int max_len) { return va_attention_splits(rows, n_head, max_len); }
@@ -651,6 +658,6 @@ extern "C" int vaura_attention_step_split(const float* qkv, const float* rope, f
                                           float* part, int rows, int n_head, int head_dim, int max_len, int pos, int n_split,
                                           vaura_stream_t s) {
   if (pos < 0 || pos >= max_len || !part || n_split < 2 || n_split > 8) return VAURA_ERR_ARG;
-  return va_launch_attention(qkv, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos, part, n_split,
-                             as_stream(s));
+  return va_launch_attention(qkv, nullptr, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos,
+                             part, n_split, as_stream(s));
 }

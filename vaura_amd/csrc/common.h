@@ -68,9 +68,9 @@ inline hipStream_t as_stream(vaura_stream_t s) { return (hipStream_t)s; }
 int va_launch_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
                    int64_t rows, int64_t N, int64_t K, int epilogue, float eps, hipStream_t s);
 int va_attention_splits(int rows, int n_head, int max_len);   // workgroups per (row, head) for this shape
-int va_launch_attention(const float* qkv, const float* rope, float* kc, float* vc, float* out, uint16_t* outp, int rows,
-                        int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host, float* part, int n_split,
-                        hipStream_t s);
+int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
+                        uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
+                        float* part, int n_split, hipStream_t s);
 struct Gemv3Args;
 int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s);
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);

@@ -1,10 +1,10 @@
 // Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
 #include "gemv3_kernel.h"
 
-template <bool FP8, int G, int NW, int T, int EPI, bool NORM, int XB = 1>
+template <bool FP8, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   if (n_tiles % T) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, FP8>), dim3((unsigned)(n_tiles / T)), dim3(NW * 64), 0, s, a);
+  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, FP8, KS>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a);
   return 0;
 }
 
@@ -45,6 +45,11 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
   if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
   const int64_t tiles = n_weight_rows / 16;
+  if (a.out2) {   // the caller asked for two K-half partials (decode qkv): bf16 weights, fused norm, K = 1536 only
+    if (a.wq || K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
+    a.wscale = nullptr;
+    return launch3<false, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
+  }
   // GEMM tiling only when there are enough row blocks to fill the chip with 64 x 256 tiles (a prompt pass); a decode
   // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
   if (!a.wq && a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
@@ -144,12 +149,12 @@ int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* 
 }
 
 int vaura_gemv_bf16(const void* w, int wdtype, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
-                    uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
+                    float* out_khalf2, uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s) {
   if (!w || !x_split || rows <= 0) return VAURA_ERR_ARG;
   if (wdtype != VAURA_W_BF16 && wdtype != VAURA_W_FP8) return VAURA_ERR_DTYPE;
   Gemv3Args a;
-  a.wq = wdtype == VAURA_W_FP8; a.wscale = nullptr;
+  a.wq = wdtype == VAURA_W_FP8; a.wscale = nullptr; a.out2 = out_khalf2;
   a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
   a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
   a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K;

@@ -31,6 +31,8 @@ struct Gemv3Args {
   int n_ss_in;
   const float* res;       // E3_RESID: fp32 packed rows (rows x N)
   float* out;             // fp32 packed rows (rows x N) / row-major logits; may be null for E3_SWIGLU
+  float* out2;            // K-split instances (KS = 2): the partial sum over the second half of K goes here, `out`
+                          // holds the first half's; the consumer adds the two (E3_STORE only)
   uint16_t* outp;         // optional split rows of (out * gain_out)
   const float* gain_out;  // optional (N) gain applied before splitting (next RMSNorm)
   float* ss_out;          // optional (R, N/16, 16) partial sums of squares of `out`
@@ -143,11 +145,15 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 // loads, 8 = same k-slice order in every workgroup.
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
 // been consumed, for depths whose three planes do not fit the register budget at once)
-template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, bool FP8 = false>
+// KS = 2: two workgroups per tile group, each over one half of K, each writing its own partial output (out / out2)
+// which the CONSUMER adds (attention gathers q, k, v anyway: one more 16-byte load).  For the qkv GEMV this turns
+// 144 workgroups x 245 KB into 192 x 147 KB: more CUs, fewer bytes through each CU's L2 port, no in-kernel seam.
+template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, bool FP8 = false, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   static_assert(!FP8 || (G % 2 == 0 && (G / XB) % 2 == 0), "fp8 tile pairs hold two k-groups per lane");
+  static_assert(KS == 1 || (EPI == E3_STORE && !FP8), "K-split partials are summed by the consumer: plain stores only");
   constexpr int GW = FP8 ? G / 2 : G;   // weight registers (u32x4) per tile
-  constexpr int K = 32 * G * NW;
+  constexpr int K = 32 * G * NW * KS;
   constexpr int KG = K / 32;
   constexpr int GB = G / XB;
   static_assert(G % XB == 0, "x batches must divide the groups");
@@ -162,8 +168,11 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   const int w = (ABL & 8) ? wid : (int)((wid + blockIdx.x) % NW);
   const int m = lane & 15;
   const int q = lane >> 4;
-  const int tile0 = blockIdx.x * T;
+  const int ks = KS > 1 ? (int)(blockIdx.x % KS) : 0;            // which part of K
+  const int kgo = ks * G * NW;                                   // its first k-group
+  const int tile0 = (int)(blockIdx.x / KS) * T;
   const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
+  if (KS > 1 && ks > 0) a.out = a.out2;
 
   // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
   // block; a prefill pass loops row blocks (one per prompt position) over the same registers
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
-                             : Xp[split_index16(rb, p, (w * G + b * GB + g) * 4 + q, m, K)];
+                             : Xp[split_index16(rb, p, (kgo + w * G + b * GB + g) * 4 + q, m, K)];
   };
 
   auto row_block = [&](const int rb, const bool first) {
@@ -189,13 +198,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
         if (g < GB) {
 #pragma unroll
           for (int p = 0; p < 3; ++p)
-            xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (w * G + g) * 4 + q, m, K)];
+            xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (kgo + w * G + g) * 4 + q, m, K)];
         }
         if (!FP8 || (g & 1) == 0) {
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((w * G + g) >> 1)
-                                  : (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+                                  : (size_t)(tile0 + t) * KG + (size_t)(kgo + w * G + g);
             wb[t][FP8 ? g / 2 : g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
           }
         }

@@ -158,6 +158,7 @@ class DecoderEngine:
             self.state = torch.zeros(4, dtype=torch.int32, device=self.dev)
             self.ws_h = torch.zeros(rp * c.d_model, **f32)
             self.ws_qkv = torch.zeros(rp * 3 * c.d_model, **f32)
+            self.ws_qkv2 = torch.zeros(self._rows_padded(rows) * 3 * c.d_model, **f32)   # decode step only
             self.ws_attn = torch.zeros(rp * c.d_model, **f32)
             self.ws_ffn = torch.zeros(rp * c.ffn_dim, **f32)
             self.ws_logits = torch.zeros(rows, K * c.d_codebook, **f32)
@@ -187,6 +188,7 @@ class DecoderEngine:
         d.kcache, d.vcache, d.seq, d.state = L.ptr(self.kcache), L.ptr(self.vcache), L.ptr(self.seq), L.ptr(self.state)
         d.noise = 0
         d.ws_h, d.ws_qkv, d.ws_attn = L.ptr(self.ws_h), L.ptr(self.ws_qkv), L.ptr(self.ws_attn)
+        d.ws_qkv2 = L.ptr(self.ws_qkv2)
         d.ws_ffn, d.ws_logits = L.ptr(self.ws_ffn), L.ptr(self.ws_logits)
         d.ws_h_split, d.ws_attn_split = L.ptr(self.ws_h_split), L.ptr(self.ws_attn_split)
         d.ws_ffn_split, d.ws_ss = L.ptr(self.ws_ffn_split), L.ptr(self.ws_ss)

@@ -140,7 +140,7 @@ def unsplit_rows(sp: torch.Tensor, rows: int, Cc: int) -> torch.Tensor:
 def gemv_bf16(wp: torch.Tensor, x_split: torch.Tensor, rows: int, N: int, K: int, epilogue: int = L.EPI_STORE,
               ss_in: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               gain_out: Optional[torch.Tensor] = None, want_split: bool = False, want_ss: bool = False, eps: float = 1e-5,
-              wdtype: int = L.W_BF16):
+              wdtype: int = L.W_BF16, out_khalf2: Optional[torch.Tensor] = None):
     """Returns (out, out_split, ss_out); out is packed rows, or row-major (rows, N) for EPI_LOGITS."""
     _cuda(wp, x_split, ss_in, residual, gain_out)
     n_out = N // 2 if epilogue == L.EPI_SWIGLU else N
@@ -151,7 +151,7 @@ def gemv_bf16(wp: torch.Tensor, x_split: torch.Tensor, rows: int, N: int, K: int
     osp = torch.zeros(rp * 3 * n_out, dtype=torch.int16, device=dev) if want_split else None
     oss = torch.zeros((rp // 16) * (n_out // 16) * 16, dtype=torch.float32, device=dev) if want_ss else None
     n_ss = 0 if ss_in is None else K // 16
-    L.check(L.lib().vaura_gemv_bf16(L.ptr(wp), wdtype, L.ptr(x_split), L.ptr(ss_in), n_ss, L.ptr(residual), L.ptr(out), L.ptr(osp),
+    L.check(L.lib().vaura_gemv_bf16(L.ptr(wp), wdtype, L.ptr(x_split), L.ptr(ss_in), n_ss, L.ptr(residual), L.ptr(out), L.ptr(out_khalf2), L.ptr(osp),
                                     L.ptr(gain_out), L.ptr(oss), rows, N, K, epilogue, eps, L.current_stream()),
             "vaura_gemv_bf16")
     return out, osp, oss
