@@ -251,7 +251,7 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "kernel": ("gemv3_kernel<6, 8, 2, 2, true, 1, 0, " + ("true" if args.weights == "fp8" else "false") + ">"
+                           "kernel": ("gemv3_kernel<6, 8, 2, 2, true, 1, 0, " + ("true" if args.weights == "fp8" else "false") + ", 1>"
                                       if args.weights != "f32" else "gemv_kernel (fp32 MFMA)") + " = feed_forward.w1|w3 + SwiGLU, K=1536, N=8192",
                            "algorithmic_bytes_per_launch": ab, "avg_us_per_launch": round(per[dom], 3)}
         out["kernel_us"] = {k: round(v, 3) for k, v in per.items()}
