@@ -179,15 +179,16 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   u32x4 wb[T][GW];
   // activation planes of the current batch of k-groups; the first batch of the NEXT row block is requested as soon as
   // the last MFMA of this one has been issued, so its round trip runs under the reduction / barrier / epilogue
-  u32x4 xb[GB][3];
+  constexpr int NXB = XB > 1 ? 2 : 1;   // with several batches two are in flight (double buffer)
+  u32x4 xb[NXB][GB][3];
   const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
   auto load_x = [&](int rb, int b) {
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
-                             : Xp[split_index16(rb, p, (kgo + w * G + b * GB + g) * 4 + q, m, K)];
+        xb[b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
+                                      : Xp[split_index16(rb, p, (kgo + w * G + b * GB + g) * 4 + q, m, K)];
   };
 
   auto row_block = [&](const int rb, const bool first) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
         if (g < GB) {
 #pragma unroll
           for (int p = 0; p < 3; ++p)
-            xb[g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (kgo + w * G + g) * 4 + q, m, K)];
+            xb[0][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (kgo + w * G + g) * 4 + q, m, K)];
         }
         if (!FP8 || (g & 1) == 0) {
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
-      if (b > 0) load_x(rb, b);
+      if (b + 1 < XB) load_x(rb, b + 1);   // into the buffer batch b-1 has just released
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
 #pragma unroll
@@ -246,9 +247,9 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 #pragma unroll
           for (int p = 0; p < 3; ++p) {
             if constexpr (ABL & 1) {
-              asm volatile("" ::"v"(wf), "v"(xb[g][p]));
+              asm volatile("" ::"v"(wf), "v"(xb[b % NXB][g][p]));
             } else {
-              acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xb[g][p]), acc[t][p], 0, 0, 0);
+              acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xb[b % NXB][g][p]), acc[t][p], 0, 0, 0);
             }
           }
         }
