@@ -331,13 +331,14 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
       if (*slot == -1) *slot = tok;
     }
     if (a.state_rw) {
-      __threadfence();
-      const int arrived = atomicAdd(&a.state_rw[1], 1);
+      // No fences: nothing in THIS launch reads the token slots or the state written here; the next kernel sees them
+      // because a kernel boundary publishes all stores.  The arrival counter is a device-scope atomic (coherent by
+      // itself).  (An agent-scope release here costs an L2 write-back per workgroup: DESIGN.md §6.)
+      const int arrived = __hip_atomic_fetch_add(&a.state_rw[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (arrived == (int)(gridDim.x * gridDim.y) - 1) {
-        a.state_rw[1] = 0;
+        __hip_atomic_store(&a.state_rw[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.state_rw[0] = pos + 1;
         a.state_rw[2] = (int)step + 1;
-        __threadfence();
       }
     }
   }
