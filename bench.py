@@ -140,7 +140,7 @@ def main():
     first, _ = vdist.shard(B * world, rank, world)
     sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
     eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights)
-    codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev)
+    codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision="f16pair_w8" if args.weights == "fp8" else "f16pair")
     feats_cpu = synth.video_features(B, TV, cfg.cond_in, seed=0, first_clip=first)
     feats = feats_cpu.to(dev)
     kw = dict(use_sampling=True, temp=1.0, top_k=args.top_k, top_p=0.0, cfg_scale=args.cfg_scale, seed=1234,
@@ -195,9 +195,9 @@ def main():
                    "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
                    "weights": ({"bf16": "bf16 storage of the streamed matrices (synthetic checkpoint is bf16-representable: exact)",
                                 "f32": "fp32 storage of the streamed matrices",
-                                "fp8": "fp8 e4m3 + power-of-two row scales for the per-layer matrices, bf16 heads (a different "
-                                       "model than the bf16 one: not the headline configuration)"}[args.weights]
-                               + "; fp32 activations / accumulate / KV cache; codec on (hi, lo) fp16 pairs, fp32 accumulate"),
+                                "fp8": "fp8 e4m3 + power-of-two row scales for the per-layer matrices and the codec's conv weights, "
+                                       "bf16 heads (a different model than the bf16 one: not the headline configuration)"}[args.weights]
+                               + "; fp32 activations / accumulate / KV cache; codec activations on (hi, lo) fp16 pairs, fp32 accumulate"),
                    "hipgraph": not args.no_graph,
                    "streams": "decode loop of batch i+1 overlaps codec+gather of batch i (two HIP streams)" if args.overlap
                               else "one non-null HIP stream"},

@@ -260,7 +260,10 @@ typedef struct vaura_codec {
   int32_t precision;                /* 0: fp32 activations/weights, exact v_mfma_f32_16x16x4_f32;
                                        1: (hi, lo) fp16 pairs, 3 x v_mfma_f32_16x16x32_f16 per product: conv weights
                                           (not conv_out) must then be given in pair layout
-                                          [.. Cout][Cin/8][hi|lo][8] halves instead of [.. Cout][Cin] floats */
+                                          [.. Cout][Cin/8][hi|lo][8] halves instead of [.. Cout][Cin] floats;
+                                       2: as 1 with single-plane weights (the caller guarantees every lo plane is zero, e.g.
+                                          fp8-quantised weights: e4m3 x power-of-two scale is exact in fp16): the lo-plane
+                                          product is skipped, 2 MFMAs per product (BASELINE configs[4] codec part)        */
   int32_t _pad1;
 } vaura_codec;
 

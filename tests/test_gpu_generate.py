@@ -323,3 +323,23 @@ def test_two_engines_interleaved_keep_their_own_step_graphs(tiny_sampler_sd):
     assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a1[:, :, :8], b1[:2, :, :8])
     eager = a.generate_codes(fa, 16, cfg_scale=6.0, use_graph=False).cpu()
     assert torch.equal(a1, eager)
+
+
+def test_dac_decode_fp8_weights_against_oracle_on_dequantised_checkpoint():
+    """BASELINE configs[4], codec part: conv weights in fp8 (e4m3, power-of-two scale per output channel) are exact in one
+    fp16 plane, so the kernel skips the lo-plane product.  Same bar as the decoder's fp8 storage: the result must be the
+    oracle's decode of the DEQUANTISED checkpoint (RMS <= 1e-4); the distance to the unquantised codec is reported."""
+    from oracle import dac_oracle
+    from vaura_amd import quant
+    ccfg = synth.FULL_CODEC
+    sd = synth.codec_state_dict(ccfg, seed=1)
+    codes = torch.randint(0, 1024, (2, 9, 12), generator=torch.Generator().manual_seed(3))
+    ref_q = dac_oracle.decode(quant.fp8_effective_codec_state_dict(sd), codes, ccfg.decoder_rates)
+    ref = dac_oracle.decode(sd, codes, ccfg.decoder_rates)
+    got = CodecEngine(ccfg, sd, DEV, precision="f16pair_w8").decode(codes.to(DEV)).cpu()
+    rms = float(((got - ref_q) ** 2).mean().sqrt())
+    rms_model = float(((ref_q - ref) ** 2).mean().sqrt())
+    print(f"codec fp8 weights: rms err vs oracle on the dequantised weights {rms:.3e}; fp8 vs unquantised codec rms {rms_model:.3e} "
+          f"(signal rms {float((ref ** 2).mean().sqrt()):.3e})")
+    assert rms <= 1e-4, rms
+    assert rms_model > 1e-4        # it IS a different model

@@ -28,4 +28,14 @@ with torch.cuda.stream(s):
         back = enc.encode(wav)
     ev[2].record()
 torch.cuda.synchronize()
+w8 = CodecEngine(cfg, sd, dev, precision="f16pair_w8")
+with torch.cuda.stream(s):
+    w8.decode(codes)
+    e8 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e8[0].record()
+    for _ in range(5):
+        w8.decode(codes)
+    e8[1].record()
+torch.cuda.synchronize()
+print(f"B={B}: decode with fp8-quantised conv weights (single fp16 weight plane) {e8[0].elapsed_time(e8[1]) / 5:.2f} ms")
 print(f"B={B} clips of 2.56 s: decode {ev[0].elapsed_time(ev[1]) / 5:.2f} ms, encode {ev[1].elapsed_time(ev[2]) / 5:.2f} ms")

@@ -181,7 +181,9 @@ __device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, 
 #define XROWS (BM + XHALO)
 // NI = 16-column tiles per wave: output-channel tile BN_ = 32 * NI (96 for the decoder's widths, 64 for the
 // encoder's powers of two)
-template <int NI>
+// WS: weights have a single fp16 plane (fp8-quantised weights are exact in fp16: the lo plane is zero and its MFMA is
+// skipped — two instead of three matrix instructions per product)
+template <int NI, bool WS>
 __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   constexpr int BN_ = 32 * NI;
   // one raw LDS block: weight tiles | activation blocks during the main loop, the fp32 output tile afterwards
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+          if constexpr (!WS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
         }
@@ -421,9 +423,11 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       if ((cv.taps - 1) * cv.dilation > XHALO) return VAURA_ERR_SHAPE;
     }
     if (cv.cout % BN == 0) {
-      VA_LAUNCH(conv_pair_kernel<3>, dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      else VA_LAUNCH((conv_pair_kernel<3, false>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
     } else {
-      VA_LAUNCH(conv_pair_kernel<2>, dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
+      if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
+      else VA_LAUNCH((conv_pair_kernel<2, false>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
     }
     return 0;
   }
@@ -582,7 +586,7 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   for (int i = 0; i < 4; ++i) if (!c->ws[i]) return VAURA_ERR_ARG;
   hipStream_t s = as_stream(s_);
   const int pr = c->precision;
-  if (pr != 0 && pr != 1) return VAURA_ERR_DTYPE;
+  if (pr != 0 && pr != 1 && pr != 2) return VAURA_ERR_DTYPE;
   float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
 
   VA_LAUNCH(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,

@@ -338,11 +338,16 @@ class CodecEngine:
 
     def __init__(self, cfg: CodecCfg, sd: Dict[str, torch.Tensor], device="cuda:0", precision: str = "f16pair"):
         """precision: "f16pair" (default; activations/weights as (hi, lo) fp16 pairs on the fp16 MFMA, error
-        ~1e-6 RMS) or "f32" (exact fp32 MFMA)."""
+        ~1e-6 RMS), "f32" (exact fp32 MFMA), or "f16pair_w8" (BASELINE configs[4]: conv weights quantised to fp8 e4m3 with
+        a power-of-two scale per output channel — a different model, ``quant.fp8_effective_codec_state_dict`` says which;
+        such weights are exact in one fp16 plane, so a product costs two MFMAs instead of three)."""
         _require_cuda(device)
         self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
         self._keep = []
-        self.pairs = {"f32": 0, "f16pair": 1}[precision]
+        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2}[precision]
+        if self.pairs == 2:
+            from .quant import fp8_effective_codec_state_dict
+            sd = fp8_effective_codec_state_dict(sd)
         c = L.Codec()
         c.precision = self.pairs
         c.n_codebooks, c.codebook_size, c.codebook_dim, c.latent_dim = (cfg.n_codebooks, cfg.codebook_size,

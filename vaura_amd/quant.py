@@ -46,3 +46,29 @@ def fp8_effective_state_dict(sd: dict) -> dict:
         if k.startswith("layers.") and k.endswith(FP8_LAYER_KEYS):
             out[k] = fp8_effective_weight(v)
     return out
+
+
+def fp8_effective_codec_state_dict(sd: dict) -> dict:
+    """DAC state dict whose decoder convolutions (every ``decoder.model.*`` conv except the final C -> 1 one) are replaced
+    by their fp8-dequantised values: e4m3 with one power-of-two scale per OUTPUT channel over (input channels x taps).
+    Weight-norm parametrisation is kept foldable: ``weight_v`` holds the dequantised weight and ``weight_g`` its own norm,
+    so ``g * v / |v|`` returns it unchanged."""
+    out = dict(sd)
+    for k in list(sd):
+        if not (k.startswith("decoder.model.") and k.endswith("weight_v")):
+            continue
+        p = k[: -len("weight_v")]
+        v, g = sd[k].float(), sd[p + "weight_g"].float()
+        w = v * (g / v.norm(2, dim=tuple(range(1, v.dim())), keepdim=True))      # folded weight
+        transposed = g.shape[0] == w.shape[0] and w.dim() == 3 and (".block.1." in p and p.count(".block.") == 1)
+        if transposed:       # ConvTranspose1d (Cin, Cout, k): output channels on dim 1
+            cin, cout, kk = w.shape
+            we = fp8_effective_weight(w.permute(1, 0, 2).reshape(cout, cin * kk)).reshape(cout, cin, kk).permute(1, 0, 2).contiguous()
+        else:                # Conv1d (Cout, Cin, k)
+            cout, cin, kk = w.shape
+            if cout == 1:
+                continue     # the last conv (C -> 1) stays as is: it runs in fp32
+            we = fp8_effective_weight(w.reshape(cout, cin * kk)).reshape(cout, cin, kk)
+        out[k] = we
+        out[p + "weight_g"] = we.norm(2, dim=tuple(range(1, we.dim())), keepdim=True)
+    return out
