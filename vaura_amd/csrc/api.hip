@@ -103,8 +103,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   PROF_A(VAURA_K_EMBED);
   if (rc) return rc;
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
-  // K-split qkv (consumer-reduced): bf16 storage, fewer than 16 row blocks (otherwise the GEMM tiling takes over)
-  float* qkv2 = (d->ws_qkv2 && d->wdtype == VAURA_W_BF16 && (rows + 15) / 16 < 16) ? d->ws_qkv2 : nullptr;
+  // K-split qkv (consumer-reduced): fewer than 16 row blocks (otherwise the GEMM tiling takes over)
+  float* qkv2 = (d->ws_qkv2 && (rows + 15) / 16 < 16) ? d->ws_qkv2 : nullptr;
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;

@@ -46,7 +46,11 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
   const int64_t tiles = n_weight_rows / 16;
   if (a.out2) {   // the caller asked for two K-half partials (decode qkv): bf16 weights, fused norm, K = 1536 only
-    if (a.wq || K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
+    if (K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
+    if (a.wq) {   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
+      a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
+      return launch3<true, 6, 4, 3, E3_STORE, true, 1, 2>(a, tiles, s);
+    }
     a.wscale = nullptr;
     return launch3<false, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
   }

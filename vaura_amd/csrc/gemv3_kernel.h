@@ -151,7 +151,8 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, bool FP8 = false, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
   static_assert(!FP8 || (G % 2 == 0 && (G / XB) % 2 == 0), "fp8 tile pairs hold two k-groups per lane");
-  static_assert(KS == 1 || (EPI == E3_STORE && !FP8), "K-split partials are summed by the consumer: plain stores only");
+  static_assert(KS == 1 || EPI == E3_STORE, "K-split partials are summed by the consumer: plain stores only");
+  static_assert(!FP8 || (G * NW) % 2 == 0, "fp8 tile pairs: a K part must start on an even k-group");
   constexpr int GW = FP8 ? G / 2 : G;   // weight registers (u32x4) per tile
   constexpr int K = 32 * G * NW * KS;
   constexpr int KG = K / 32;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
         if (!FP8 || (g & 1) == 0) {
 #pragma unroll
           for (int t = 0; t < T; ++t) {
-            const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((w * G + g) >> 1)
+            const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((kgo + w * G + g) >> 1)
                                   : (size_t)(tile0 + t) * KG + (size_t)(kgo + w * G + g);
             wb[t][FP8 ? g / 2 : g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
           }
