@@ -100,7 +100,7 @@ SPLIT_GEMV_CASES = [
     (4096, 1536, L.EPI_RESID, False, 16),
     (1536, 9216, L.EPI_LOGITS, True, 7),
     (1536, 4608, L.EPI_STORE, True, 40),
-    # >= 16 row blocks: the prefill GEMM tiling (bf16 weights; fp8 keeps the row-block loop); 17 / 19 blocks = ragged M tile
+    # >= 16 row blocks: the prefill GEMM tiling (bf16 and fp8 weights); 17 / 19 blocks = ragged M tile
     (1536, 4608, L.EPI_STORE, True, 300),
     (1536, 1536, L.EPI_RESID, False, 256),
     (1536, 8192, L.EPI_SWIGLU, True, 260),

@@ -26,7 +26,8 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
 template <int EPI, bool NORM>
 static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
   const dim3 grid((unsigned)(tiles / (G3M_NW * G3M_T)), (unsigned)((a.R + G3M_RB - 1) / G3M_RB));
-  VA_LAUNCH((gemm3_kernel<EPI, NORM>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  if (a.wq) VA_LAUNCH((gemm3_kernel<EPI, NORM, true>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  else VA_LAUNCH((gemm3_kernel<EPI, NORM, false>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
   return 0;
 }
 
@@ -56,8 +57,8 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   }
   // GEMM tiling only when there are enough row blocks to fill the chip with 64 x 256 tiles (a prompt pass); a decode
   // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
-  if (!a.wq && a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
-    a.wscale = nullptr;
+  if (a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
+    a.wscale = a.wq ? reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K) : nullptr;
     return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
   }
   if (a.wq) {

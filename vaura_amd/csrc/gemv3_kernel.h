@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
 #define G3M_RB 4
 #define G3M_T 2
 #define G3M_NW 8
-template <int EPI, bool NORM>
+template <int EPI, bool NORM, bool FP8 = false>
 __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) {
   constexpr int RB = G3M_RB, T = G3M_T, NW = G3M_NW;
   __shared__ u32x4 xs[2][RB * 3 * 64];
@@ -339,9 +339,11 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
       if (idx < RB * 192) xs[buf][idx] = xr[i];
     }
   };
-  auto load_w = [&](int kg) {
+  auto load_w = [&](int kg) {   // fp8 tile pairs: one 16-byte load carries k-groups kg and kg + 1
+    if (FP8 && (kg & 1)) return;
 #pragma unroll
-    for (int t = 0; t < T; ++t) wr[t] = __builtin_nontemporal_load(Wp + ((size_t)(tile0 + t) * KG + kg) * 64 + lane);
+    for (int t = 0; t < T; ++t)
+      wr[t] = __builtin_nontemporal_load(Wp + (FP8 ? (size_t)(tile0 + t) * (KG / 2) + (kg >> 1) : (size_t)(tile0 + t) * KG + kg) * 64 + lane);
   };
 
   load_x(0);
@@ -372,7 +374,10 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
     const int buf = kg & 1;
     bf16x8 wf[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) wf[t] = __builtin_bit_cast(bf16x8, wr[t]);
+    for (int t = 0; t < T; ++t) {
+      if constexpr (FP8) wf[t] = (kg & 1) ? fp8x8_to_bf16(wr[t].z, wr[t].w) : fp8x8_to_bf16(wr[t].x, wr[t].y);
+      else wf[t] = __builtin_bit_cast(bf16x8, wr[t]);
+    }
     if (kg + 1 < KG) { load_x(kg + 1); load_w(kg + 1); }
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -392,7 +397,11 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
     const float rinv = NORM ? rinv_s[r * 16 + (lane & 15)] : 1.f;
     f32x4 v[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) v[t] = ((acc[r][t][2] + acc[r][t][1]) + acc[r][t][0]) * rinv;
+    for (int t = 0; t < T; ++t) {
+      f32x4 sacc = (acc[r][t][2] + acc[r][t][1]) + acc[r][t][0];
+      if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * (lane >> 4));
+      v[t] = sacc * rinv;
+    }
     gemv3_epilogue<T, EPI>(a, rb0 + r, tile0, lane, v);
   }
 }
