@@ -197,11 +197,6 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
       // interleave the issue so that k-group g is complete once W[g] and x[g] have landed
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        if (g < GB) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            xb[0][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (kgo + w * G + g) * 4 + q, m, K)];
-        }
         if (!FP8 || (g & 1) == 0) {
 #pragma unroll
           for (int t = 0; t < T; ++t) {
@@ -211,6 +206,12 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          xb[0][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (kgo + w * G + g) * 4 + q, m, K)];
     }
     // rinv inputs: the producer's per-tile partial sums of squares, fetched by the whole workgroup in one
     // go and parked in LDS (a load->add loop in one wave pays an L2 round trip per partial: 2.4 us)
