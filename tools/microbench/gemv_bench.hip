@@ -170,7 +170,7 @@ int main(int argc, char** argv) {
     return a;
   };
 #define G3(name, G, NW, T, EPI, NORM, XB, ABL, grid, N, resid, split, bytes) \
-  REPORT(name, time_launches([&](int s) { hipLaunchKernelGGL((gemv3_kernel<G, NW, T, EPI, NORM, XB, ABL>), dim3(grid), dim3(NW * 64), 0, g_stream, a3(s, N, NORM, resid, split)); }, NSETS, iters), bytes)
+  REPORT(name, time_launches([&](int s) { hipLaunchKernelGGL((gemv3_kernel<G, NW, T, EPI, NORM, XB, ABL>), dim3(grid), dim3(NW * 64), 0, g_stream, a3(s, N, NORM, resid, split).W, a3(s, N, NORM, resid, split).XP, a3(s, N, NORM, resid, split)); }, NSETS, iters), bytes)
   const double bq = 4608.0 * 1536 * 2, bo = 1536.0 * 1536 * 2, b13 = 8192.0 * 1536 * 2, b2 = 1536.0 * 4096 * 2, bh = 9216.0 * 1536 * 2;
   G3("g3 qkv <6,8,1> norm", 6, 8, 1, E3_STORE, true, 1, 0, 288, 4608, false, false, bq);
   G3("   qkv same-phase slices (old)", 6, 8, 1, E3_STORE, true, 1, 8, 288, 4608, false, false, bq);
@@ -211,8 +211,8 @@ int main(int argc, char** argv) {
                              (size_t)(8192.0 * 1536 * 2), stride, out);
           CK(hipEventRecord(join[i], s2));
         }
-        hipLaunchKernelGGL((gemv3_kernel<6, 8, 2, E3_SWIGLU, true, 1, 0>), dim3(256), dim3(512), 0, g_stream, a3(i, 4096, true, false, true));
-        hipLaunchKernelGGL((gemv3_kernel<6, 8, 1, E3_RESID, false, 1, 0>), dim3(96), dim3(512), 0, g_stream, a3(i, 1536, false, true, true));
+        hipLaunchKernelGGL((gemv3_kernel<6, 8, 2, E3_SWIGLU, true, 1, 0>), dim3(256), dim3(512), 0, g_stream, a3(i, 4096, true, false, true).W, a3(i, 4096, true, false, true).XP, a3(i, 4096, true, false, true));
+        hipLaunchKernelGGL((gemv3_kernel<6, 8, 1, E3_RESID, false, 1, 0>), dim3(96), dim3(512), 0, g_stream, a3(i, 1536, false, true, true).W, a3(i, 1536, false, true, true).XP, a3(i, 1536, false, true, true));
         if (do_prefetch) CK(hipStreamWaitEvent(g_stream, join[i], 0));
       }
       CK(hipStreamEndCapture(g_stream, &graph));

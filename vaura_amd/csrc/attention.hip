@@ -326,9 +326,10 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
 
 template <int HD>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
-    float* __restrict__ out, uint16_t* __restrict__ outp, int n_head, int max_len, const int32_t* __restrict__ pos_dev,
-    int pos_host, const float* __restrict__ qkv2) {
+    // argument order = what the dependent chain needs first (the leading 14 dwords are preloaded into SGPRs)
+    const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
+    const float* __restrict__ qkv2, const float* __restrict__ rope, int n_head, int max_len, int pos_host,
+    float* __restrict__ out, uint16_t* __restrict__ outp) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];   // rotated q | rotated k | v of the new position | scratch
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -520,9 +521,9 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
 
 template <int HD>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ rope, float* __restrict__ kcache, float* __restrict__ vcache,
-    float* __restrict__ part, int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host,
-    const float* __restrict__ qkv2) {
+    const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
+    const float* __restrict__ qkv2, const float* __restrict__ rope, int n_head, int max_len, int pos_host,
+    float* __restrict__ part) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -609,14 +610,14 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
     if (n_split > 8) return VAURA_ERR_ARG;
-    VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, part,
-              n_head, max_len, pos_dev, pos_host, qkv2);
+    VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2,
+              rope, n_head, max_len, pos_host, part);
     VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split);
     return 0;
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
-    VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, qkv, rope, kc, vc, out, outp,
-              n_head, max_len, pos_dev, pos_host, qkv2);
+    VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
+              n_head, max_len, pos_host, out, outp);
     return 0;
   }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);

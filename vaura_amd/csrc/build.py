@@ -14,7 +14,10 @@ SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac
 HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", os.path.join("..", "..", "include", "vaura_hip.h")]
 LIB = os.path.join(HERE, "libvaura_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs at wave launch (gfx94x/gfx950); the
+# compiler keeps a compatibility prologue that loads them the old way when the firmware does not preload
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:

@@ -4,7 +4,7 @@
 template <bool FP8, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   if (n_tiles % T) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, FP8, KS>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a);
+  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, FP8, KS>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a.W, a.XP, a);
   return 0;
 }
 

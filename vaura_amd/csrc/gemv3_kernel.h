@@ -149,7 +149,11 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 // which the CONSUMER adds (attention gathers q, k, v anyway: one more 16-byte load).  For the qkv GEMV this turns
 // 144 workgroups x 245 KB into 192 x 147 KB: more CUs, fewer bytes through each CU's L2 port, no in-kernel seam.
 template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, bool FP8 = false, int KS = 1>
-__global__ __launch_bounds__(NW * 64) void gemv3_kernel(Gemv3Args a) {
+__global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a) {
+  // Wq / XPq duplicate a.W / a.XP as explicit scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs
+  // at wave launch, so the address arithmetic of the first (weight) loads does not wait for a kernarg s_load
+  a.W = Wq;
+  a.XP = XPq;
   static_assert(!FP8 || (G % 2 == 0 && (G / XB) % 2 == 0), "fp8 tile pairs hold two k-groups per lane");
   static_assert(KS == 1 || EPI == E3_STORE, "K-split partials are summed by the consumer: plain stores only");
   static_assert(!FP8 || (G * NW) % 2 == 0, "fp8 tile pairs: a K part must start on an even k-group");

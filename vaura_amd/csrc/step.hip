@@ -166,7 +166,10 @@ __device__ __forceinline__ int block_count(int v, int* si) {
 }
 
 // V == 1024 == 4 * SMP_THREADS: thread t owns candidates 4t .. 4t+3
-__global__ __launch_bounds__(SMP_THREADS) void sample_kernel(SampleArgs a) {
+__global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __restrict__ logits_q, const int32_t* __restrict__ state_q,
+                                                             SampleArgs a) {
+  a.logits = logits_q;   // explicit scalar copies: preloaded into SGPRs at wave launch (the struct is not)
+  a.state = state_q;
   __shared__ float sv[8];
   __shared__ int si[8];
   __shared__ float sp[1024];   // top-p: sorted probabilities
@@ -354,7 +357,7 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
   a.B = B; a.K = K; a.V = vocab; a.T = T; a.S = S;
   a.use_sampling = sp->use_sampling; a.top_k = sp->top_k; a.temp = sp->temp; a.top_p = sp->top_p;
   a.cfg_scale = sp->cfg_scale; a.seed = sp->seed; a.clip_base = sp->clip_base; a.step_host = step_host;
-  VA_LAUNCH(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a);
+  VA_LAUNCH(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a.logits, a.state, a);
   return 0;
 }
 
