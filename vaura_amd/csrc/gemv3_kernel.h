@@ -274,7 +274,11 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       }
     }
     __syncthreads();
-    if (wid == 0) {
+    // Epilogue: one wave per output tile where the tiles are independent (store / residual / logits), so T waves
+    // finish the T tiles side by side; SwiGLU needs both tiles of a (w1, w3) pair in the same lane: one wave does all.
+    constexpr int EW = (EPI == E3_SWIGLU) ? 1 : T;     // waves taking part
+    constexpr int ET = (EPI == E3_SWIGLU) ? T : 1;     // tiles per such wave
+    if (wid < EW) {
       float rinv = 1.f;
       if constexpr (NORM) {
         float ssp = 0.f;
@@ -283,16 +287,17 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         ssp += __shfl_xor(ssp, 32, 64);
         rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
       }
-      f32x4 v[T];
+      f32x4 v[ET];
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
+      for (int e = 0; e < ET; ++e) {
+        const int t = (EPI == E3_SWIGLU) ? e : wid;
         f32x4 sacc = red[0][t][lane];
 #pragma unroll
         for (int i = 1; i < NW; ++i) sacc += red[i][t][lane];
         if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
-        v[t] = sacc * rinv;
+        v[e] = sacc * rinv;
       }
-      gemv3_epilogue<T, EPI>(a, rb, tile0, lane, v);
+      gemv3_epilogue<ET, EPI>(a, rb, (EPI == E3_SWIGLU) ? tile0 : tile0 + wid, lane, v);
     }
   };
 
