@@ -38,8 +38,13 @@ class _Holder(nn.Module):
 
 
 class DacModelWrapper(nn.Module):
-    def __init__(self, model_sr: int = 24000, ckpt_path: tp.Optional[str] = None, synthetic_seed: int = 0) -> None:
+    def __init__(self, model_sr: int = 24000, ckpt_path: tp.Optional[str] = None, synthetic_seed: int = 0,
+                 precision: str = "f16pair") -> None:
+        """``model_sr`` / ``ckpt_path`` as in the reference (dac/model.py:12-25).  Extras understood by this plugin only:
+        ``precision`` of the decode convolutions — "f16pair" (default), "f32" (exact fp32 MFMA) or "f16pair_w8" (fp8 conv
+        weights, BASELINE configs[4]) — and ``synthetic_seed`` for the weights used when no checkpoint is given."""
         super().__init__()
+        self.precision = precision
         assert model_sr in MODEL_SR, "Invalid model samplerate"
         if model_sr not in (44000, 44100):
             raise L.VauraHipError("only the 44.1 kHz DAC geometry is built (configs/modules/audio_codecs/dac_8kbps_wrapper.yaml)")
@@ -67,7 +72,8 @@ class DacModelWrapper(nn.Module):
         if self._engine is None or self._engine_dev != dev:
             if dev.type != "cuda":
                 raise L.VauraHipError("vaura_amd.codec.DacModelWrapper decodes on a HIP device only; call .to('cuda')")
-            self._engine = CodecEngine(self.cfg, {k: v.float() for k, v in self.model.state_dict().items()}, dev)
+            self._engine = CodecEngine(self.cfg, {k: v.float() for k, v in self.model.state_dict().items()}, dev,
+                                       precision=self.precision)
             self._engine_dev = dev
         return self._engine
 
