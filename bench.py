@@ -52,48 +52,61 @@ def decode_loop_bytes(cfg: synth.SamplerCfg, wbytes: int, rows: int, steps: int)
     return tot
 
 
-def cpu_baseline(sd, feats_cpu, cfg_scale):
-    """Oracle (CPU port of the reference path) on this box's host cores, bounded sample.
-    The reference recomputes the whole prefix every step (models/vaura_model.py:504-506): time the
-    full-prefix forward of ONE clip (2 rows with CFG) at four prefix lengths and integrate over the
-    228 steps; also time the KV-cached variant so the GPU/CPU ratio is not just the algorithmic gap."""
+def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
+    """Oracle (CPU port of the reference path) on this box's host cores, bounded sample (~10-30 s).
+    `value`: the KV-cached port at the GPU's own batch (all `n_clips` clips, 2 rows each with CFG), measured over real
+    steps at the start and near the end of a clip (the per-step cost grows with the cache) — so that GPU/CPU is not just
+    the algorithmic gap.  `reference_algorithm_extrapolated`: the reference itself keeps no cache and re-feeds the whole
+    prefix every step (models/vaura_model.py:504-506); its cost is EXTRAPOLATED from the full-prefix forward of ONE clip
+    timed at four prefix lengths and integrated over the 228 steps (a full run is minutes per clip)."""
     from oracle.decoder_oracle import CachedDecoder, DecoderOracle
     cfg = synth.FULL_SAMPLER
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
-    cond = feats_cpu[:1]
-    cond = torch.cat([cond, dec.null_condition(cond)], 0) if cfg_scale > 1 else cond
     g = torch.Generator().manual_seed(0)
-    pts = [8, 64, 128, 228]
-    ts = []
+    n_steps = T_FRAMES + K_CB - 1
     with torch.no_grad():
+        cond = feats_cpu[:n_clips]
+        cond = torch.cat([cond, dec.null_condition(cond)], 0) if cfg_scale > 1 else cond
+        rows = cond.shape[0]
+        cd = CachedDecoder(dec, cond, n_steps + 1)
+        tok = torch.randint(0, 1024, (rows, K_CB), generator=g)
+        cd.step(tok)                      # warm-up (allocations, thread pool)
+        reps = 6
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cd.step(tok)
+        t_early = (time.perf_counter() - t0) / reps
+        cd.pos = n_steps - reps - 1       # late steps: attention over ~220 cached positions (zeros: same work)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cd.step(tok)
+        t_late = (time.perf_counter() - t0) / reps
+        cached_s = 0.5 * (t_early + t_late) * n_steps
+        cached_tok_s = n_clips * K_CB * T_FRAMES / cached_s
+        # the reference's cache-less algorithm, one clip
+        cond1 = cond[[0, n_clips]] if cfg_scale > 1 else cond[:1]
+        pts = [8, 64, 128, 228]
+        ts = []
         for Lq in pts:
-            idx = torch.randint(0, 1024, (cond.shape[0], K_CB, Lq), generator=g)
+            idx = torch.randint(0, 1024, (cond1.shape[0], K_CB, Lq), generator=g)
             t0 = time.perf_counter()
-            dec.forward_full(idx, cond)
+            dec.forward_full(idx, cond1)
             ts.append(time.perf_counter() - t0)
-        # piecewise-linear integral of t(L) over L = 1..228
         total = 0.0
         xs = [1] + pts
         ys = [ts[0]] + ts
         for i in range(1, len(xs)):
             total += 0.5 * (ys[i] + ys[i - 1]) * (xs[i] - xs[i - 1])
-        faithful_tok_s = K_CB * T_FRAMES / total
-        cd = CachedDecoder(dec, cond, 64)
-        n = 24
-        tok = torch.randint(0, 1024, (cond.shape[0], K_CB), generator=g)
-        cd.step(tok)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            cd.step(tok)
-        cached_step = (time.perf_counter() - t0) / n
-    cached_tok_s = K_CB * T_FRAMES / (cached_step * 228)
     return {
-        "value": round(faithful_tok_s, 2), "unit": "codec tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"oracle/ fp32 torch-CPU port, 1 clip (rows={cond.shape[0]}, cfg {cfg_scale}): full-prefix forward "
-                   f"(the reference's no-cache algorithm) timed at L={pts} -> {['%.3f' % t for t in ts]} s, integrated over "
-                   f"228 steps = {total:.1f} s/clip, decode loop only (codec excluded); KV-cached variant "
-                   f"{cached_step * 1e3:.1f} ms/step"),
-        "kv_cached_value": round(cached_tok_s, 2),
+        "value": round(cached_tok_s, 2), "unit": "codec tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle/ fp32 torch-CPU port with a K/V cache, the GPU's batch ({n_clips} clips, rows={rows}, cfg {cfg_scale}): "
+                   f"{reps} steps at cache length ~1 ({t_early * 1e3:.0f} ms/step) and {reps} at ~{n_steps - reps} "
+                   f"({t_late * 1e3:.0f} ms/step), mean x {n_steps} steps = {cached_s:.1f} s per batch; decode loop only (codec excluded)"),
+        "reference_algorithm_extrapolated": {
+            "value": round(K_CB * T_FRAMES / total, 2), "unit": "codec tokens/s", "clips": 1,
+            "how": (f"cache-less full-prefix forward (what the reference runs every step) of ONE clip (rows={cond1.shape[0]}) timed at "
+                    f"L={pts} -> {['%.3f' % t for t in ts]} s, piecewise-linear integral over {n_steps} steps = {total:.1f} s per clip: "
+                    "an extrapolation, not a full run")},
     }
 
 
@@ -112,6 +125,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="experiment: codec + gather of batch i on a second stream (slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the second timed region (f32 storage on the un-rounded checkpoint)")
+    ap.add_argument("--no-plugin", action="store_true", help="skip timing VAURAModel.generate() through the plugin classes")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
@@ -138,6 +153,9 @@ def main():
     ccfg = synth.FULL_CODEC
     B = args.batch
     first, _ = vdist.shard(B * world, rank, world)
+    # Two synthetic checkpoints (no network: weights are regenerated from seeds): the bf16-representable one (every
+    # storage then holds the same numbers: bf16 storage is exact for it) and, for `value_f32_storage`, the UN-rounded one
+    # — fp32 weights bf16 cannot hold, i.e. what a real V-AURA checkpoint looks like: "auto" resolves to f32 storage there.
     sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
     eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights)
     codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision="f16pair_w8" if args.weights == "fp8" else "f16pair")
@@ -167,16 +185,19 @@ def main():
                 vdist.gather_clips(wav, counts)
         return codes, wav
 
-    for _ in range(args.warmup):
-        step()
-    vdist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        codes, wav = step()
-    torch.cuda.synchronize(dev)
-    vdist.barrier()
-    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+    def timed(fn):
+        for _ in range(args.warmup):
+            fn()
+        vdist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = fn()
+        torch.cuda.synchronize(dev)
+        vdist.barrier()
+        return vdist.max_over_ranks(time.perf_counter() - t0, dev), res
+
+    elapsed, (codes, wav) = timed(step)
 
     assert codes.shape == (B, K_CB, T_FRAMES) and int(codes.min()) >= 0 and int(codes.max()) < 1024
     assert wav.shape == (B, 1, T_FRAMES * HOP) and bool(torch.isfinite(wav).all())
@@ -188,7 +209,7 @@ def main():
         "metric": f"audio codec tokens/sec (whole node), {'10.24' if long_ctx else '2.56'} s clips",
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",   # dtype = the arithmetic type: fp32 products / accumulate (exact bf16-plane products), whatever the storage
         "config": {"workload": (f"configs[{3 if long_ctx else 1}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
@@ -202,7 +223,27 @@ def main():
                    "streams": "decode loop of batch i+1 overlaps codec+gather of batch i (two HIP streams)" if args.overlap
                               else "one non-null HIP stream"},
         "sec_audio_per_sec": round(world * B * T_FRAMES * HOP / 44100.0 * args.steps / elapsed, 2),
+        "value_storage": {"bf16": "bf16 storage, bf16-representable synthetic checkpoint (exact for THAT checkpoint)",
+                          "f32": "f32 storage", "fp8": "fp8 storage (a different model)"}[args.weights],
     }
+
+    # ---- the same job on an UN-rounded checkpoint with the plugin's default storage decision ("auto" -> f32): the
+    #      reference-exact configuration for real (fp32) checkpoints.  Every rank runs it (same barriers).
+    if not args.no_extras and args.weights == "bf16" and not args.no_f32:
+        eng_main = eng
+        sd_raw = synth.sampler_state_dict(cfg, seed=0, round_bf16=False)
+        eng = DecoderEngine(cfg, sd_raw, dev)                    # wdtype="auto"
+        assert eng.wdtype == "f32", eng.wdtype
+        del sd_raw
+        el32, (codes32, wav32) = timed(step)
+        assert int(codes32.min()) >= 0 and int(codes32.max()) < 1024 and bool(torch.isfinite(wav32).all())
+        out["value_f32_storage"] = round(tokens / el32, 1)
+        out["ms_per_step_f32_storage"] = round(1e3 * el32 / args.steps, 3)
+        out["f32_storage_checkpoint"] = ("un-rounded synthetic checkpoint (fp32 weights, not bf16-representable: real-checkpoint-shaped); "
+                                         "storage chosen by weight_dtype='auto'; fp32 weights split into exact bf16 planes in registers")
+        del eng
+        torch.cuda.empty_cache()
+        eng = eng_main
 
     if rank == 0 and not args.no_extras:
         # ---- split of one step + dominant-kernel roofline, measured live with HIP events
@@ -239,25 +280,80 @@ def main():
         L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), n_steps, 0xFF, tot, cnt,
                                            int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
         per = {name: 1e3 * tot[bit] / max(1, cnt[bit]) for name, bit in kinds.items()}   # us per launch
-        dom = "w13"
-        ab = algorithmic_bytes_per_launch(dom, cfg, wbytes, rows)
+        launches = {name: int(cnt[bit]) for name, bit in kinds.items()}
+        total_us = {k: per[k] * launches[k] for k in per}
+        # per-kind roofline fraction of the weight-streaming GEMVs; the DOMINANT kernel is the one with the largest total
+        # time over the loop (launch count x average duration), not the largest per-launch byte count
+        gemv_kinds = ["qkv", "wo", "w13", "w2", "heads"]
+        frac = {k: algorithmic_bytes_per_launch(k, cfg, wbytes, rows) / (per[k] * 1e-6) / 1e9 / HBM_PEAK_GBS for k in gemv_kinds}
+        kv_avg = 2.0 * rows * cfg.d_model * 4 * (n_steps + 1) / 2.0 + 2.0 * rows * cfg.d_model * 4     # K,V rows read (avg) + written
+        frac["attn"] = kv_avg / (per["attn"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        dom = max(gemv_kinds + ["attn"], key=lambda k: total_us[k])
+        ab = kv_avg if dom == "attn" else algorithmic_bytes_per_launch(dom, cfg, wbytes, rows)
         ach = ab / (per[dom] * 1e-6) / 1e9
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "pmc_w13.json")
-        if os.path.exists(pmc):
+        names = json.load(open(os.path.join(REPO, "profiles", "kernel_names.json"))) if os.path.exists(
+            os.path.join(REPO, "profiles", "kernel_names.json")) else {}
+        kname = names.get(args.weights, {}).get(dom, dom)
+        # HBM traffic of that kernel from the PMC passes over the SAME library (tools/pmc_driver.cpp + tools/profile_pmc.sh):
+        # only quoted when the committed record is for this kernel instance and storage, else null
+        traffic, tsrc = None, None
+        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith(f"_pmc_hbm_bytes_{args.weights}.json")), reverse=True):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                rec = json.load(open(os.path.join(REPO, "profiles", cand)))
+                hit = rec.get("weights") == args.weights and rec.get("rows") == rows and rec.get("kernels", {}).get(kname)
+                if hit:
+                    traffic, tsrc = hit["hbm_bytes_per_launch"], f"profiles/{cand}"
+                    break
             except Exception:
-                traffic = None
+                continue
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                           "kernel": ("gemv3_kernel<6, 8, 2, 2, true, 1, 0, " + ("true" if args.weights == "fp8" else "false") + ", 1>"
-                                      if args.weights != "f32" else "gemv_kernel (fp32 MFMA)") + " = feed_forward.w1|w3 + SwiGLU, K=1536, N=8192",
-                           "algorithmic_bytes_per_launch": ab, "avg_us_per_launch": round(per[dom], 3)}
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                           "kernel": f"{kname} = {dom}", "dominant_by": "total time over the decode loop",
+                           "share_of_loop_kernel_time": round(total_us[dom] / sum(total_us.values()), 4),
+                           "algorithmic_bytes_per_launch": ab, "avg_us_per_launch": round(per[dom], 3),
+                           "launches": launches[dom]}
         out["kernel_us"] = {k: round(v, 3) for k, v in per.items()}
+        out["kernel_frac_of_hbm_peak"] = {k: round(v, 4) for k, v in frac.items()}
+
+        # ---- the plugin surface (wall = generate() entry -> waveform): VAURAModel.generate() built from
+        #      reference-style config dicts, same workload, next to the engine-level number above
+        if not args.no_plugin and not long_ctx and args.weights == "bf16":
+            import warnings
+            from vaura_amd.model import VAURAModel
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                model = VAURAModel(
+                    feature_extractor_config={"target": "vaura_amd.feature_extractor.MotionFormer"},
+                    audio_encoder_config={"target": "vaura_amd.codec.DacModelWrapper", "params": {"model_sr": 44100, "synthetic": True}},
+                    sampler_config={"target": "vaura_amd.sampler.Transformer", "params": cfg.yaml_params()},
+                    visual_bridge_config={"target": "torch.nn.Identity"},
+                    pattern_provider_config={"target": "vaura_amd.patterns.DelayedPatternProvider", "params": {"n_q": 9}},
+                    flatten_vis_feats=True, freeze_feature_extractor=True, noise_mode="philox", seed=1234)
+            model.sampler.load_state_dict(sd, strict=True)
+            model.sampler.audio_tokens_per_video_frame = 7
+            model = model.to(dev)
+            frames = feats.reshape(B, TV // 8, 8, cfg.cond_in)
+            gkw = dict(frames=frames, audio=None, max_new_tokens=T_FRAMES, return_sampled_indices=True, use_sampling=True,
+                       temp=1.0, top_k=args.top_k, top_p=0.0, prompt_is_encoded=True, cfg_scale=args.cfg_scale)
+            for _ in range(2):
+                r = model.generate(**gkw)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = model.generate(**gkw)
+            torch.cuda.synchronize(dev)
+            t_plugin = (time.perf_counter() - t0) / reps
+            assert r["generated_audio"].shape == (B, 1, T_FRAMES * HOP)
+            out["plugin_surface"] = {"what": "vaura_amd.model.VAURAModel.generate() (plugin classes from config dicts), same workload, "
+                                             f"storage {model.sampler.resolved_weight_dtype} (auto)",
+                                     "ms_per_step": round(1e3 * t_plugin, 3),
+                                     "tokens_per_s": round(B * K_CB * T_FRAMES / t_plugin, 1),
+                                     "delta_ms_vs_engines": round(1e3 * t_plugin - (t_loop + t_codec), 3)}
+            del model, r
+            torch.cuda.empty_cache()
 
         if world == 1 and not args.no_cpu_baseline and not long_ctx:
-            out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale)
+            out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale, B)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
 
     if rank == 0:

@@ -34,3 +34,11 @@ def full_sampler_sd():
 def tiny_sampler_sd():
     from vaura_amd import synth
     return synth.sampler_state_dict(synth.tiny_sampler(2), seed=3)
+
+
+@pytest.fixture(scope="session")
+def full_sampler_sd_raw():
+    """The same 694 M parameters WITHOUT the bf16 rounding: fp32 weights bf16 cannot hold, i.e. what a real V-AURA
+    checkpoint (fp32 master weights of 16-mixed training) looks like to the storage decision."""
+    from vaura_amd import synth
+    return synth.sampler_state_dict(synth.FULL_SAMPLER, seed=0, round_bf16=False)

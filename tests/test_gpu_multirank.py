@@ -1,0 +1,48 @@
+"""The N > 1 product path on real hardware: two fresh child processes, one rank each, 4 + 4 clips,
+must gather exactly what one process produces for the 8 clips — tokens bit for bit (Philox noise is keyed by the global
+clip index, `clip_base`) and the waveform bit for bit (same kernels on the same tokens).  On a 1-GPU box both ranks
+share cuda:0 and the collectives run over gloo on host copies; with >= 2 GPUs the same test runs over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("total", [8, 5])
+def test_two_ranks_gather_what_one_rank_generates(tmp_path, total):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(HERE, "shard_worker.py")
+    one = tmp_path / "one.npz"
+    r = subprocess.run([sys.executable, worker, "--out", str(one), "--total", str(total)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = tmp_path / "two.npz"
+    multi_gpu = torch.cuda.device_count() >= 2
+    env2 = dict(env)
+    if not multi_gpu:
+        env2.update(VAURA_BENCH_BACKEND="gloo", VAURA_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, "--out", str(two),
+                        "--total", str(total)], env=env2, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(one), np.load(two)
+    assert int(b["world"]) == 2 and int(a["world"]) == 1
+    assert a["codes"].shape == (total, 9, 24) and a["codes"].min() >= 0 and a["codes"].max() < 1024
+    assert np.array_equal(a["codes"], b["codes"])
+    assert np.array_equal(a["wav"], b["wav"]) and np.isfinite(a["wav"]).all() and np.abs(a["wav"]).max() > 0

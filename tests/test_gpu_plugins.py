@@ -21,7 +21,7 @@ def _model(sd, noise_mode="torch_cpu"):
         warnings.simplefilter("ignore")
         m = VAURAModel(
             feature_extractor_config={"target": "vaura_amd.feature_extractor.MotionFormer"},
-            audio_encoder_config={"target": "vaura_amd.codec.DacModelWrapper", "params": {"model_sr": 44100}},
+            audio_encoder_config={"target": "vaura_amd.codec.DacModelWrapper", "params": {"model_sr": 44100, "synthetic": True}},
             sampler_config={"target": "vaura_amd.sampler.Transformer", "params": cfg.yaml_params()},
             visual_bridge_config={"target": "torch.nn.Identity"},
             pattern_provider_config={"target": "vaura_amd.patterns.DelayedPatternProvider", "params": {"n_q": 9}},

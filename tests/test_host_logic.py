@@ -84,7 +84,7 @@ def test_codec_plugin_surface():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         from vaura_amd.codec import DacModelWrapper
-        c = DacModelWrapper(model_sr=44100)
+        c = DacModelWrapper(model_sr=44100, synthetic=True)
     assert type(c).__name__ == "DacModelWrapper" and c.sample_rate == 44100 and c.channels == 1
     q = c.model.quantizer.quantizers
     assert len(q) == 9 and q[0].codebook.weight.shape == (1024, 8)
@@ -179,3 +179,89 @@ def test_sliding_window_schedule_known_answers():
     assert sum(c["new_tokens"] for c in s) == 221 + 4 * 55
     with pytest.raises(AssertionError):
         chunk_schedule(5.12, 2.56, 2.56)
+
+
+def test_auto_weight_storage_follows_the_checkpoint():
+    """"auto" (the plugin default) stores bf16 only when that loses nothing; an un-rounded (real-checkpoint-shaped) dict
+    resolves to f32 — the reference samples in fp32 (configs/vaura_defaults.yaml precision: 32)."""
+    from vaura_amd.engine import bf16_lossless, resolve_weight_dtype
+    from vaura_amd.sampler import Transformer
+    cfg = synth.tiny_sampler(1)
+    rounded = synth.sampler_state_dict(cfg, seed=1, round_bf16=True)
+    raw = synth.sampler_state_dict(cfg, seed=1, round_bf16=False)
+    assert resolve_weight_dtype(rounded, "auto") == "bf16" and resolve_weight_dtype(raw, "auto") == "f32"
+    assert resolve_weight_dtype(raw, "bf16") == "bf16"       # forcing a storage is still possible (and rounds)
+    one = dict(rounded)
+    k = "layers.0.feed_forward.w2.weight"
+    one[k] = one[k].clone()
+    one[k][3, 5] += 2.0 ** -20                               # a single unrepresentable weight is enough
+    assert not bf16_lossless(one[k]) and resolve_weight_dtype(one, "auto") == "f32"
+    assert Transformer(**cfg.yaml_params()).weight_dtype == "auto"
+
+
+def test_sampler_engine_cache_sees_parent_loads(tiny_sampler_sd):
+    """nn.Module.load_state_dict on a PARENT never calls the child's override: the packed-weights cache is keyed on the
+    parameters' versions / storage instead."""
+    from vaura_amd.sampler import Transformer
+    cfg = synth.tiny_sampler(2)
+    m = Transformer(**cfg.yaml_params())
+    parent = torch.nn.Module()
+    parent.add_module("sampler", m)
+    f0 = m._weights_fingerprint()
+    parent.load_state_dict({"sampler." + k: v for k, v in tiny_sampler_sd.items()}, strict=True)
+    f1 = m._weights_fingerprint()
+    assert f0 != f1
+    with torch.no_grad():
+        m.norm.weight.mul_(1.5)
+    assert m._weights_fingerprint() != f1
+
+
+def test_codec_plugin_refuses_to_run_on_unintended_weights(tmp_path):
+    """The reference downloads weights or fails; it never decodes with random ones (dac/model.py:20-25)."""
+    import warnings
+    from vaura_amd.codec import DacModelWrapper
+    with pytest.raises(L.VauraHipError, match="no checkpoint"):
+        DacModelWrapper(model_sr=44100)
+    with pytest.raises(L.VauraHipError, match="does not exist"):
+        DacModelWrapper(model_sr=44100, ckpt_path=str(tmp_path / "nope.pth"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = DacModelWrapper(model_sr=44100, synthetic=True, synthetic_seed=7)
+    sd = ref.model.state_dict()
+    # a dac.DAC.save-style file with torch >= 2.1 weight-norm names loads completely ...
+    ren = {k.replace("weight_g", "parametrizations.weight.original0").replace("weight_v", "parametrizations.weight.original1"): v
+           for k, v in sd.items()}
+    good = tmp_path / "dac.pth"
+    torch.save({"state_dict": ren, "metadata": {}}, good)
+    c = DacModelWrapper(model_sr=44100, ckpt_path=str(good))
+    assert all(torch.equal(c.model.state_dict()[k], v) for k, v in sd.items())
+    # ... a file that misses keys (or has other names) is an error, not a partial load
+    part = tmp_path / "part.pth"
+    torch.save({"state_dict": {k: v for k, v in sd.items() if not k.startswith("decoder.model.3")}}, part)
+    with pytest.raises(L.VauraHipError, match="keys missing"):
+        DacModelWrapper(model_sr=44100, ckpt_path=str(part))
+    # the engine cache follows precision and parameter edits
+    k0 = c._weights_fingerprint("cuda:0")
+    c.precision = "f32"
+    assert c._weights_fingerprint("cuda:0") != k0
+
+
+def test_generate_loop_refuses_to_run_past_the_sequence():
+    """vaura_generate_loop feeds positions [0, n_prefill + n_steps) and writes seq[..., position + 1]: more than S - 1
+    positions is an argument error (checked before anything is enqueued; no GPU needed)."""
+    import ctypes as C
+    lib = L.lib()
+    d = L.Decoder()
+    d.dims = L.Dims(24, 1536, 16, 4096, 9, 1024, 512, 1024, 768, 8, 7, 1e-5)
+    d.wdtype, d.batch, d.rows, d.max_len, d.timesteps, d.seq_len, d.n_cond_tokens = L.W_BF16, 2, 2, 256, 220, 229, 32
+    lw = (L.LayerWeights * 24)()
+    d.layers_host = C.cast(lw, C.POINTER(L.LayerWeights))
+    for name, typ in L.Decoder._fields_:
+        if typ is C.c_void_p and name != "noise":
+            setattr(d, name, 0x1000)        # never dereferenced: the call fails on its arguments first
+    sp = L.Sampling(0, 1.0, 0, 0.0, 1.0, 0, 0)
+    assert lib.vaura_generate_loop(C.byref(d), C.byref(sp), 0, 229, None, None) == -1      # VAURA_ERR_ARG
+    assert lib.vaura_generate_loop(C.byref(d), C.byref(sp), 167, 63, None, None) == -1     # 230 positions of 229
+    assert lib.vaura_generate_loop(C.byref(d), C.byref(sp), -1, 5, None, None) == -1
+    d.max_len = 128
+    assert lib.vaura_generate_loop(C.byref(d), C.byref(sp), 0, 200, None, None) == -1      # K/V rows would not exist

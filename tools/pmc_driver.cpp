@@ -1,0 +1,111 @@
+// Stand-alone driver of the PRODUCT library for counter collection:  rocprofv3 --pmc ... -- ./pmc_driver <libvaura_hip.so> [...]
+// rocprofv3 --pmc under python crashes on this image, and a profile of a separately compiled microbenchmark says nothing about
+// the shipped code object — so this program dlopen()s the very libvaura_hip.so the plugins load and calls vaura_decode_step
+// (include/vaura_hip.h) on a full-size decoder descriptor (24 layers, 1536/4096, 16 rows = 8 clips with CFG) filled with seeded
+// values.  No python, no env/bash hop: the program itself goes after `--`.
+//
+//   pmc_driver <lib> [--weights bf16|f32] [--steps 24] [--pos0 100] [--rows 16]
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../include/vaura_hip.h"
+
+#define CK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e__)); exit(2); } } while (0)
+
+__global__ void fill_f32(float* p, size_t n, float scale, float offset, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = offset + scale * ((float)(h & 0xffff) / 32768.0f - 1.0f);
+  }
+}
+__global__ void fill_bf16(uint16_t* p, size_t n, float scale, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const float v = scale * ((float)(h & 0xffff) / 32768.0f - 1.0f);
+    p[i] = (uint16_t)(__builtin_bit_cast(uint32_t, v) >> 16);
+  }
+}
+__global__ void fill_i32(int32_t* p, size_t n, int32_t v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static uint32_t g_seed = 1;
+static float* dev_f32(size_t n, float scale, float offset = 0.f) {
+  float* p; CK(hipMalloc(&p, n * 4));
+  fill_f32<<<1024, 256>>>(p, n, scale, offset, g_seed++);
+  return p;
+}
+static void* dev_weight(size_t n, int wd) {   // any bytes are a valid MFMA-tile image: the layout is a permutation
+  if (wd == VAURA_W_BF16) { uint16_t* p; CK(hipMalloc(&p, n * 2)); fill_bf16<<<1024, 256>>>(p, n, 0.035f, g_seed++); return p; }
+  return dev_f32(n, 0.035f);
+}
+template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights bf16|f32] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
+  int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16;
+  for (int i = 2; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--weights")) wd = !strcmp(argv[i + 1], "f32") ? VAURA_W_F32 : VAURA_W_BF16;
+    else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
+  }
+  void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+  if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+  auto step = (int (*)(const vaura_decoder*, const vaura_sampling*, int, vaura_stream_t))dlsym(lib, "vaura_decode_step");
+  auto ssize = (size_t (*)(int))dlsym(lib, "vaura_struct_size");
+  if (!step || !ssize || ssize(3) != sizeof(vaura_decoder)) { fprintf(stderr, "library / header mismatch\n"); return 1; }
+
+  const int NL = 24, D = 1536, F = 4096, H = 16, K = 9, V = 1024, Tv = 32, T = 220, S = T + K, ML = 256;
+  const int batch = rows / 2, rp = (rows + 15) / 16 * 16;
+  vaura_decoder d;
+  memset(&d, 0, sizeof d);
+  d.dims = vaura_dims{NL, D, H, F, K, V, 512, 1024, 768, 8, 7, 1e-5f};
+  d.wdtype = wd; d.batch = batch; d.rows = rows; d.max_len = ML; d.timesteps = T; d.seq_len = S; d.n_cond_tokens = Tv;
+  d.prefill_positions = 0;
+  std::vector<vaura_layer_weights> lw(NL);
+  for (int l = 0; l < NL; ++l) {
+    lw[l].wqkv = dev_weight((size_t)3 * D * D, wd); lw[l].wo = dev_weight((size_t)D * D, wd);
+    lw[l].w13 = dev_weight((size_t)2 * F * D, wd); lw[l].w2 = dev_weight((size_t)D * F, wd);
+    lw[l].attn_norm = dev_f32(D, 0.2f, 1.0f); lw[l].ffn_norm = dev_f32(D, 0.2f, 1.0f);
+  }
+  d.layers_host = lw.data();
+  d.heads = dev_weight((size_t)K * V * D, wd);
+  d.final_norm = dev_f32(D, 0.2f, 1.0f);
+  d.tok_emb = dev_f32((size_t)K * (V + 1) * 8, 1.f); d.tok_proj_w = dev_f32((size_t)K * 1024 * 8, 0.3f); d.tok_proj_b = dev_f32((size_t)K * 1024, 0.02f);
+  d.tok_table = dev_f32((size_t)K * (V + 1) * 1024, 0.5f);
+  d.empty_video = dev_f32(512, 0.02f);
+  d.rope = dev_f32((size_t)ML * 48 * 2, 0.7f);
+  d.cond_proj = dev_f32((size_t)((rows * Tv + 15) / 16 * 16) * 512, 0.3f);
+  d.kcache = dev_f32((size_t)NL * rows * H * ML * 96, 0.5f); d.vcache = dev_f32((size_t)NL * rows * H * ML * 96, 0.5f);
+  int32_t* seq; CK(hipMalloc(&seq, (size_t)batch * K * S * 4)); fill_i32<<<64, 256>>>(seq, (size_t)batch * K * S, 7);
+  d.seq = seq;
+  d.state = dev_zero<int32_t>(4);
+  d.noise = nullptr;
+  d.ws_h = dev_zero<float>((size_t)rp * D); d.ws_qkv = dev_zero<float>((size_t)rp * 3 * D); d.ws_qkv2 = dev_zero<float>((size_t)rp * 3 * D);
+  d.ws_attn = dev_zero<float>((size_t)rp * D); d.ws_ffn = dev_zero<float>((size_t)rp * F); d.ws_logits = dev_zero<float>((size_t)rows * K * V);
+  d.ws_h_split = dev_zero<uint16_t>((size_t)rp * 3 * D); d.ws_attn_split = dev_zero<uint16_t>((size_t)rp * 3 * D);
+  d.ws_ffn_split = dev_zero<uint16_t>((size_t)rp * 3 * F); d.ws_ss = dev_zero<float>((size_t)(rp / 16) * (D / 16) * 16);
+  d.first_norm = lw[0].attn_norm;
+  d.ws_attn_part = nullptr;
+  vaura_sampling sp{1, 1.0f, 250, 0.0f, 6.0f, 1234ull, 0ull};
+  hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  CK(hipDeviceSynchronize());
+  const int32_t st0[4] = {pos0, 0, 0, 0};
+  CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
+  for (int i = 0; i < steps; ++i) {
+    const int rc = step(&d, &sp, 1, st);
+    if (rc) { fprintf(stderr, "vaura_decode_step: %d\n", rc); return 3; }
+  }
+  CK(hipStreamSynchronize(st));
+  int32_t st1[4];
+  CK(hipMemcpy(st1, d.state, sizeof st1, hipMemcpyDeviceToHost));
+  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wd == VAURA_W_F32 ? "f32" : "bf16", rows, pos0, st1[0] - 1);
+  return st1[0] == pos0 + steps ? 0 : 4;
+}

@@ -1,60 +1,118 @@
-"""Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the small, committed summaries under profiles/."""
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the small, committed summaries under profiles/:
+
+  <tag>_bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the python bench command
+  <tag>_bench_under_rocprof.json      the JSON line that run printed
+  <tag>_driver_kernel_stats_<w>.csv   the same kernels through tools/pmc_driver (the product .so), w = bf16 | f32
+  <tag>_pmc_hbm_bytes_<w>.json        HBM bytes per launch per kernel from separate FETCH_SIZE / WRITE_SIZE passes on the driver
+  kernel_names.json                   storage -> decode-step stage -> kernel name as rocprofv3 prints it (bench.py quotes it)
+
+The summariser REFUSES to write the PMC record unless every decode-step kernel name of the PMC passes also appears in the
+bench's own kernel stats: counters from an old build or another code object cannot end up next to fresh timings.
+"""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
-# ---- kernel stats (rocprofv3 --kernel-trace --stats)
+
 def newest(pattern):
-    return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1]
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def stage_of(name):
+    """decode-step stage of a kernel name (template arguments: G, NW, T, EPI, NORM, ...)."""
+    if name.startswith("attention_step256_kernel") or name.startswith("attention_split_kernel") or name.startswith("attention_step_kernel"):
+        return "attn"
+    m = re.match(r"gemv3_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", name)
+    if m:
+        g, epi, norm = int(m.group(1)), int(m.group(4)), m.group(5) == "true"
+        if epi == 0 and norm:
+            return "qkv"
+        if epi == 1:
+            return "w2" if g == 16 else "wo"
+        if epi == 2:
+            return "w13"
+        if epi == 4:
+            return "heads"
+    if name.startswith("sample_kernel"):
+        return "sample"
+    if name.startswith("embed_kernel"):
+        return "embed"
+    return None
+
+
+def clean(name):
+    return re.sub(r"\(.*$", "", name.replace("void ", "")).strip()
+
+
+def write_stats(path, dst, header):
+    rows = list(csv.DictReader(open(path)))
+    with open(dst, "w") as f:
+        f.write(f"# {header}\n")
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    return rows
 
 
 stats = newest(f"{src}/stats/**/*kernel_stats.csv")
-rows = list(csv.DictReader(open(stats)))
-with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline\n")
-    w = csv.writer(f)
-    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-    for r in rows:
-        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+rows = write_stats(stats, f"profiles/{tag}_bench_kernel_stats.csv",
+                   "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32 --no-plugin")
+bench_names = {clean(r["Name"]) for r in rows}
 log = [l for l in open(f"{src}/bench_stats.log").read().splitlines() if l.startswith("{")]
 open(f"profiles/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else "{}") + "\n")
 
-# ---- PMC: HBM bytes per launch for the dominant kernel
+
 def per_kernel(path, counter):
     f = newest(f"{path}/**/*counter_collection.csv")
     acc = defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    if f:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[clean(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
-# the PMC passes come from the stand-alone harness (tools/profile_pmc_microbench.sh): rocprofv3 --pmc crashes at
-# start-up under the python bench on this image, and the harness runs the same kernel instantiations
-fetch = per_kernel(f"{src}/mb_FETCH_SIZE", "FETCH_SIZE")
-write = per_kernel(f"{src}/mb_WRITE_SIZE", "WRITE_SIZE")
-out = {}
-for k in fetch:
-    if "gemv3" not in k:
+
+names = {}
+for w in ("bf16", "f32"):
+    st = newest(f"{src}/drv_stats_{w}/**/*kernel_stats.csv")
+    if not st:
         continue
-    fs, n = fetch[k]
-    ws = write.get(k, (0.0, 0))[0]
-    # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts exactly half the
-    # bytes of wide coalesced reads (128-B requests tallied as 64 B) -> double it; WRITE_SIZE is exact.
-    out[k] = {"launches": n, "FETCH_SIZE_KiB_raw": fs, "WRITE_SIZE_KiB_raw": ws,
-              "hbm_read_bytes_per_launch": fs * 1024 * 2, "hbm_write_bytes_per_launch": ws * 1024,
-              "hbm_bytes_per_launch": fs * 1024 * 2 + ws * 1024}
-json.dump(out, open(f"profiles/{tag}_pmc_hbm_bytes.json", "w"), indent=1)
-out["_source"] = "tools/profile_pmc_microbench.sh (tools/microbench/gemv_bench 'g3 '): product kernel templates on cycling weight sets"
-dom = [k for k in out if "gemv3_kernel<6, 8, 2, 2, true" in k]
-if dom:
-    json.dump({"kernel": dom[0], **out[dom[0]]}, open("profiles/pmc_w13.json", "w"), indent=1)
-    print("w13:", out[dom[0]])
-for r in rows[:12]:
-    print(r["Name"][:70].ljust(70), r["Calls"].rjust(7), "%9.2f us" % (float(r["AverageNs"]) / 1e3), r["Percentage"])
+    drows = write_stats(st, f"profiles/{tag}_driver_kernel_stats_{w}.csv",
+                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {w} --steps 24 --pos0 100")
+    avg_ns = {clean(r["Name"]): float(r["AverageNs"]) for r in drows}
+    names[w] = {stage_of(n): n for n in avg_ns if stage_of(n)}
+    fetch = per_kernel(f"{src}/drv_FETCH_SIZE_{w}", "FETCH_SIZE")
+    write = per_kernel(f"{src}/drv_WRITE_SIZE_{w}", "WRITE_SIZE")
+    step_kernels = {k for k in fetch if stage_of(k)}
+    if w == "bf16":
+        missing = sorted(step_kernels - bench_names)
+        if missing:
+            raise SystemExit(f"PMC kernel names not in the bench's kernel stats (stale build?): {missing}")
+    out = {"weights": w, "rows": 16, "kernels": {},
+           "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- tools/pmc_driver libvaura_hip.so "
+                     f"--weights {w} --steps 24 --pos0 100 (cache length 100..123)",
+           "formula": "hbm_bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half the "
+                      "bytes of wide coalesced reads on gfx950; WRITE_SIZE is exact)"}
+    for k in sorted(step_kernels):
+        fs, n = fetch[k]
+        ws = write.get(k, (0.0, 0))[0]
+        out["kernels"][k] = {"stage": stage_of(k), "launches": n, "FETCH_SIZE_KiB_raw": fs, "WRITE_SIZE_KiB_raw": ws,
+                             "hbm_read_bytes_per_launch": fs * 2048, "hbm_write_bytes_per_launch": ws * 1024,
+                             "hbm_bytes_per_launch": fs * 2048 + ws * 1024, "avg_ns_same_driver_run": avg_ns.get(k)}
+    json.dump(out, open(f"profiles/{tag}_pmc_hbm_bytes_{w}.json", "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print(f"{w} {v['stage']:6s} {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB  {(v['avg_ns_same_driver_run'] or 0) / 1e3:7.2f} us  {k[:80]}")
+if names:
+    json.dump(names, open("profiles/kernel_names.json", "w"), indent=1)
+for r in rows[:14]:
+    print(clean(r["Name"])[:70].ljust(70), r["Calls"].rjust(7), "%9.2f us" % (float(r["AverageNs"]) / 1e3), r["Percentage"])

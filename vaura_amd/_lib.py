@@ -166,6 +166,8 @@ def ptr(t) -> int:
     return 0 if t is None else int(t.data_ptr())
 
 
-def current_stream() -> int:
+def current_stream(device=None) -> int:
+    """Raw handle of torch's current stream ON ``device`` (default: torch's current device).  Engines pass their own
+    device: the current stream of another device would order nothing here."""
     import torch
-    return int(torch.cuda.current_stream().cuda_stream)
+    return int(torch.cuda.current_stream(device).cuda_stream)

@@ -38,11 +38,14 @@ class _Holder(nn.Module):
 
 
 class DacModelWrapper(nn.Module):
-    def __init__(self, model_sr: int = 24000, ckpt_path: tp.Optional[str] = None, synthetic_seed: int = 0,
-                 precision: str = "f16pair") -> None:
+    def __init__(self, model_sr: int = 24000, ckpt_path: tp.Optional[str] = None, synthetic: bool = False,
+                 synthetic_seed: int = 0, precision: str = "f16pair") -> None:
         """``model_sr`` / ``ckpt_path`` as in the reference (dac/model.py:12-25).  Extras understood by this plugin only:
         ``precision`` of the decode convolutions — "f16pair" (default), "f32" (exact fp32 MFMA) or "f16pair_w8" (fp8 conv
-        weights, BASELINE configs[4]) — and ``synthetic_seed`` for the weights used when no checkpoint is given."""
+        weights, BASELINE configs[4]); ``synthetic=True`` (or env VAURA_SYNTHETIC_CODEC=1) asks for seeded synthetic weights
+        (``synthetic_seed``) — benchmarks and tests on machines without checkpoints.  Without it a checkpoint is REQUIRED:
+        the reference downloads one when ``ckpt_path`` is absent (dac/model.py:20-23) and never runs on random weights; this
+        build has no network path, so it raises instead of silently producing noise."""
         super().__init__()
         self.precision = precision
         assert model_sr in MODEL_SR, "Invalid model samplerate"
@@ -53,28 +56,52 @@ class DacModelWrapper(nn.Module):
         sd0 = dict(synth.codec_state_dict(self.cfg, seed=synthetic_seed))
         sd0.update(synth.codec_encoder_state_dict(self.cfg, seed=synthetic_seed))
         self.model = _Holder(self.cfg, sd0)
-        if ckpt_path is not None and os.path.exists(ckpt_path):
-            blob = torch.load(ckpt_path, map_location="cpu")
-            sd = blob.get("state_dict", blob)
-            own = self.model.state_dict()
-            self.model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        synthetic = synthetic or os.environ.get("VAURA_SYNTHETIC_CODEC") == "1"
+        if ckpt_path is not None:
+            if not os.path.exists(ckpt_path):
+                raise L.VauraHipError(f"DacModelWrapper: checkpoint {ckpt_path!r} does not exist (the reference would download "
+                                      "one here, dac/model.py:23; there is no network path in this build)")
+            self.model.load_state_dict(self.checkpoint_state_dict(ckpt_path, self.model.state_dict()), strict=True)
+        elif synthetic:
+            warnings.warn("DacModelWrapper: seeded SYNTHETIC DAC weights (synthetic=True): output is not real audio")
         else:
-            # the reference downloads weights here (dac/model.py:23); there is no network on the
-            # target machines, so fall back to seeded synthetic weights and say so.
-            warnings.warn("DacModelWrapper: no checkpoint given; using seeded synthetic DAC weights")
+            raise L.VauraHipError("DacModelWrapper: no checkpoint.  Pass ckpt_path=<DAC 44.1 kHz weights> (the reference downloads "
+                                  "them, dac/model.py:20-23; this build cannot), or synthetic=True for seeded synthetic weights")
         self._engine: tp.Optional[CodecEngine] = None
-        self._engine_dev = None
+        self._engine_key = None
         self._enc_engine: tp.Optional[CodecEncoderEngine] = None
-        self._enc_engine_dev = None
+        self._enc_engine_key = None
+
+    @staticmethod
+    def checkpoint_state_dict(ckpt_path: str, own: tp.Dict[str, torch.Tensor]) -> tp.Dict[str, torch.Tensor]:
+        """Tensors of a ``dac.DAC.save`` file for exactly the keys of ``own``.  Accepts both weight-norm spellings
+        (``weight_g`` / ``weight_v`` and torch >= 2.1's ``parametrizations.weight.original0`` / ``original1``); every key of
+        ``own`` must be present with the right shape — a partial load would decode plausible-looking noise."""
+        blob = torch.load(ckpt_path, map_location="cpu")
+        sd = blob.get("state_dict", blob) if isinstance(blob, dict) else blob
+        ren = {}
+        for k, v in sd.items():
+            k = k.replace("parametrizations.weight.original0", "weight_g").replace("parametrizations.weight.original1", "weight_v")
+            ren[k[len("model."):] if k.startswith("model.") and k[len("model."):] in own else k] = v
+        missing = [k for k in own if k not in ren]
+        bad = [k for k in own if k in ren and tuple(ren[k].shape) != tuple(own[k].shape)]
+        if missing or bad:
+            raise L.VauraHipError(f"DacModelWrapper: {ckpt_path!r} is not a DAC 44.1 kHz checkpoint this build can use: "
+                                  f"{len(missing)} keys missing (e.g. {missing[:3]}), {len(bad)} shape mismatches (e.g. {bad[:3]})")
+        return {k: ren[k] for k in own}
+
+    def _weights_fingerprint(self, dev):
+        return (str(dev), self.precision) + tuple((t._version, t.data_ptr()) for t in self.model.parameters())
 
     def engine(self) -> CodecEngine:
         dev = next(self.model.parameters()).device
-        if self._engine is None or self._engine_dev != dev:
+        key = self._weights_fingerprint(dev)
+        if self._engine is None or self._engine_key != key:
             if dev.type != "cuda":
                 raise L.VauraHipError("vaura_amd.codec.DacModelWrapper decodes on a HIP device only; call .to('cuda')")
             self._engine = CodecEngine(self.cfg, {k: v.float() for k, v in self.model.state_dict().items()}, dev,
                                        precision=self.precision)
-            self._engine_dev = dev
+            self._engine_key = key
         return self._engine
 
     def forward(self, wav: torch.Tensor):
@@ -82,11 +109,12 @@ class DacModelWrapper(nn.Module):
 
     def encoder_engine(self) -> CodecEncoderEngine:
         dev = next(self.model.parameters()).device
-        if self._enc_engine is None or self._enc_engine_dev != dev:
+        key = self._weights_fingerprint(dev)
+        if self._enc_engine is None or self._enc_engine_key != key:
             if dev.type != "cuda":
                 raise L.VauraHipError("vaura_amd.codec.DacModelWrapper encodes on a HIP device only; call .to('cuda')")
             self._enc_engine = CodecEncoderEngine(self.cfg, {k: v.float() for k, v in self.model.state_dict().items()}, dev)
-            self._enc_engine_dev = dev
+            self._enc_engine_key = key
         return self._enc_engine
 
     @torch.no_grad()

@@ -9,6 +9,9 @@
 
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
 
+// The compiled kernels are specialised for the one geometry every shipped V-AURA config uses
+// (configs/modules/samplers/llama_9cbs.yaml: 1536 / 4096 / 16 heads of 96 / 1024-entry codebooks); anything else
+// is refused with VAURA_ERR_SHAPE rather than run on the wrong tiling.
 static int check_decoder(const vaura_decoder* d) {
   if (!d || !d->layers_host || !d->heads || !d->final_norm || !d->tok_emb || !d->tok_proj_w || !d->tok_proj_b ||
       !d->tok_table || !d->empty_video || !d->rope || !d->cond_proj || !d->kcache || !d->vcache || !d->seq || !d->state || !d->ws_h ||
@@ -49,8 +52,10 @@ void va_prof_events(hipEvent_t* a, hipEvent_t* b) {
 static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
                     const float* gain_out, float* ss_out, const vaura_decoder* d, int N, int n_pos = 1) {
   Gemv3Args a;
-  // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay bf16
-  a.wq = (d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0; a.wscale = nullptr; a.out2 = nullptr;
+  // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay bf16.
+  // VAURA_W_F32: fp32 MFMA tiles, split into bf16 planes in registers by the GEMV itself
+  a.wq = d->wdtype == VAURA_W_F32 ? 2 : ((d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0);
+  a.wscale = nullptr; a.out2 = nullptr;
   a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
   a.gain_out = gain_out; a.ss_out = ss_out;
   a.R = n_pos * ((d->rows + 15) / 16);           // prefill: one group of row blocks per position
@@ -92,7 +97,8 @@ static int enqueue_prefill_chunk_bf16(const vaura_decoder* d, int p0, int n, hip
   return 0;
 }
 
-// bf16-stored weights: activations travel as exact hi/mid/lo bf16 planes, products on the bf16 MFMA
+// plane path (bf16 / fp8 storage, and fp32 storage when the split workspaces are given): activations travel as exact
+// hi/mid/lo bf16 planes, products on the bf16 MFMA
 static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
@@ -150,7 +156,9 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
 }
 
 static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
-  if (d->wdtype == VAURA_W_BF16 || d->wdtype == VAURA_W_FP8) return enqueue_step_bf16(d, sp, sample, s);
+  // fp32 storage: plane path when the caller provides the split workspaces, else the exact-fp32-MFMA GEMVs (gemv_kernel.h)
+  if (d->wdtype == VAURA_W_BF16 || d->wdtype == VAURA_W_FP8 || (d->wdtype == VAURA_W_F32 && d->ws_h_split))
+    return enqueue_step_bf16(d, sp, sample, s);
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
   const int rows = d->rows;
@@ -265,8 +273,11 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
   int rc = check_decoder(dec);
   if (rc) return rc;
   if (!sp || n_prefill < 0 || n_steps < 0) return VAURA_ERR_ARG;
+  // the loop feeds positions [0, n_prefill + n_steps) and the sampler writes seq[..., position + 1]: the last written
+  // slot must exist (the reference's loop is range(start, S), vaura_model.py:502), and so must its K/V rows
+  if (n_prefill + n_steps > dec->seq_len - 1 || n_prefill + n_steps > dec->max_len) return VAURA_ERR_ARG;
   hipStream_t st = as_stream(s);
-  if (n_prefill > 0 && dec->wdtype != VAURA_W_F32 && dec->prefill_positions > 0) {
+  if (n_prefill > 0 && dec->ws_h_split && dec->prefill_positions > 0) {
     // the caller guarantees state[0] == 0 at entry (vaura_pattern_build + zeroed state)
     for (int p0 = 0; p0 < n_prefill; p0 += dec->prefill_positions) {
       const int n = (n_prefill - p0 < dec->prefill_positions) ? n_prefill - p0 : dec->prefill_positions;

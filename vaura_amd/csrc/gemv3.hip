@@ -1,24 +1,27 @@
 // Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
 #include "gemv3_kernel.h"
 
-template <bool FP8, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
+template <int WT, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   if (n_tiles % T) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, FP8, KS>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a.W, a.XP, a);
+  VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, WT, KS>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a.W, a.XP, a);
   return 0;
 }
 
-template <bool FP8>
+template <int WT>
 static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
+  // fp32 weights are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
+  // flight) like the K = 4096 instances their four, so that the slice a wave holds fits the register file without spills
+  constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
   if (K == 1536) {
-    if (epilogue == E3_STORE && norm) return launch3<FP8, 6, 8, 2, E3_STORE, true>(a, tiles, s);
-    if (epilogue == E3_STORE && !norm) return launch3<FP8, 6, 8, 1, E3_STORE, false>(a, tiles, s);
-    if (epilogue == E3_RESID && !norm) return launch3<FP8, 6, 8, 1, E3_RESID, false>(a, tiles, s);
-    if (epilogue == E3_SWIGLU && norm) return launch3<FP8, 6, 8, 2, E3_SWIGLU, true>(a, tiles, s);
-    if (epilogue == E3_LOGITS && norm) return launch3<FP8, 6, 8, 3, E3_LOGITS, true>(a, tiles, s);
+    if (epilogue == E3_STORE && norm) return launch3<WT, 6, 8, 2, E3_STORE, true, XB2>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<WT, 6, 8, 1, E3_STORE, false>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<WT, 6, 8, 1, E3_RESID, false>(a, tiles, s);
+    if (epilogue == E3_SWIGLU && norm) return launch3<WT, 6, 8, 2, E3_SWIGLU, true, XB2>(a, tiles, s);
+    if (epilogue == E3_LOGITS && norm) return launch3<WT, 6, 8, (WT == 2 ? 2 : 3), E3_LOGITS, true, XB2>(a, tiles, s);
   } else if (K == 4096) {
-    if (epilogue == E3_RESID && !norm) return launch3<FP8, 16, 8, 1, E3_RESID, false, 4>(a, tiles, s);
-    if (epilogue == E3_STORE && !norm) return launch3<FP8, 16, 8, 1, E3_STORE, false, 4>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<WT, 16, 8, 1, E3_RESID, false, XB4>(a, tiles, s);
+    if (epilogue == E3_STORE && !norm) return launch3<WT, 16, 8, 1, E3_STORE, false, XB4>(a, tiles, s);
   }
   return VAURA_ERR_SHAPE;
 }
@@ -26,8 +29,9 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
 template <int EPI, bool NORM>
 static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
   const dim3 grid((unsigned)(tiles / (G3M_NW * G3M_T)), (unsigned)((a.R + G3M_RB - 1) / G3M_RB));
-  if (a.wq) VA_LAUNCH((gemm3_kernel<EPI, NORM, true>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
-  else VA_LAUNCH((gemm3_kernel<EPI, NORM, false>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  if (a.wq == 1) VA_LAUNCH((gemm3_kernel<EPI, NORM, 1>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  else if (a.wq == 2) VA_LAUNCH((gemm3_kernel<EPI, NORM, 2>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  else VA_LAUNCH((gemm3_kernel<EPI, NORM, 0>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
   return 0;
 }
 
@@ -48,25 +52,27 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   const int64_t tiles = n_weight_rows / 16;
   if (a.out2) {   // the caller asked for two K-half partials (decode qkv): bf16 weights, fused norm, K = 1536 only
     if (K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
-    if (a.wq) {   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
+    if (a.wq == 1) {   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
       a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
-      return launch3<true, 6, 4, 3, E3_STORE, true, 1, 2>(a, tiles, s);
+      return launch3<1, 6, 4, 3, E3_STORE, true, 1, 2>(a, tiles, s);
     }
     a.wscale = nullptr;
-    return launch3<false, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
+    if (a.wq == 2) return launch3<2, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
+    return launch3<0, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
   }
   // GEMM tiling only when there are enough row blocks to fill the chip with 64 x 256 tiles (a prompt pass); a decode
   // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
   if (a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
-    a.wscale = a.wq ? reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K) : nullptr;
+    a.wscale = a.wq == 1 ? reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K) : nullptr;
     return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
   }
-  if (a.wq) {
+  if (a.wq == 1) {
     a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
-    return dispatch3<true>(a, tiles, K, epilogue, norm, s);
+    return dispatch3<1>(a, tiles, K, epilogue, norm, s);
   }
   a.wscale = nullptr;
-  return dispatch3<false>(a, tiles, K, epilogue, norm, s);
+  if (a.wq == 2) return dispatch3<2>(a, tiles, K, epilogue, norm, s);
+  return dispatch3<0>(a, tiles, K, epilogue, norm, s);
 }
 
 // ---------------------------------------------------------------------------- fp8 weight ingress
@@ -157,9 +163,9 @@ int vaura_gemv_bf16(const void* w, int wdtype, const uint16_t* x_split, const fl
                     float* out_khalf2, uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s) {
   if (!w || !x_split || rows <= 0) return VAURA_ERR_ARG;
-  if (wdtype != VAURA_W_BF16 && wdtype != VAURA_W_FP8) return VAURA_ERR_DTYPE;
+  if (wdtype != VAURA_W_BF16 && wdtype != VAURA_W_FP8 && wdtype != VAURA_W_F32) return VAURA_ERR_DTYPE;
   Gemv3Args a;
-  a.wq = wdtype == VAURA_W_FP8; a.wscale = nullptr; a.out2 = out_khalf2;
+  a.wq = wdtype == VAURA_W_FP8 ? 1 : (wdtype == VAURA_W_F32 ? 2 : 0); a.wscale = nullptr; a.out2 = out_khalf2;
   a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
   a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
   a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K;

@@ -23,8 +23,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 enum { E3_STORE = 0, E3_RESID = 1, E3_SWIGLU = 2, E3_LOGITS = 4 };
 
 struct Gemv3Args {
-  const void* W;          // bf16 MFMA tiles, or fp8 tile pairs + per-row scales (wq = 1)
-  int wq;                 // 0: bf16 weights, 1: fp8 e4m3 weights with power-of-two row scales
+  const void* W;          // bf16 MFMA tiles, fp8 tile pairs + per-row scales (wq = 1), or fp32 MFMA tiles (wq = 2)
+  int wq;                 // 0: bf16 weights, 1: fp8 e4m3 weights with power-of-two row scales, 2: fp32 weights (split in registers)
   const float* wscale;    // wq = 1: (weight rows) power-of-two scales (set by the launcher: they follow the tiles)
   const uint16_t* XP;     // split rows (rows x K)
   const float* ss_in;     // NORM: (R, n_ss_in, 16) partial sums of squares of the raw input rows
@@ -94,6 +94,57 @@ __device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// fp32 weights (VAURA_W_F32 on the plane path): 8 consecutive-k weights of a lane arrive as two 16-byte loads and are
+// split in registers into exact hi / mid / lo bf16 planes (same truncation split as the activations: w = hi + mid + lo,
+// 8 + 8 + 8 significand bits), so every product of the 3 x 3 plane pairs is exact on the bf16 matrix cores.
+__device__ __forceinline__ void split3_w8(const u32x4 a, const u32x4 b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t uh = w[i] & 0xffff0000u;
+    const float r1 = u2f(w[i]) - u2f(uh);
+    const uint32_t um = f2u(r1) & 0xffff0000u;
+    const float r2 = r1 - u2f(um);
+    h[i] = uh; m[i] = um; l[i] = f2u(r2);
+  }
+  const u32x4 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]};
+  const u32x4 pm = {(m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]};
+  const u32x4 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u),
+                    (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u)};
+  hi = __builtin_bit_cast(bf16x8, ph);
+  mid = __builtin_bit_cast(bf16x8, pm);
+  lo = __builtin_bit_cast(bf16x8, pl);
+}
+
+// One 32-deep k-group of one 16-column tile: bf16 / fp8 weights -> one product per activation plane (acc[p], p = plane of
+// x); fp32 weights -> all nine plane pairs, accumulated by magnitude class (acc[0] hi.hi, acc[1] 2^-8, acc[2] 2^-16,
+// acc[3] the rest) so that small terms never align against large ones before the final ordered sum.
+template <int WT>
+__device__ __forceinline__ void mfma_group(const bf16x8* wf /* 1 or 3 planes */, const u32x4* x3, f32x4* acc) {
+  const bf16x8 x0 = __builtin_bit_cast(bf16x8, x3[0]), x1 = __builtin_bit_cast(bf16x8, x3[1]), x2 = __builtin_bit_cast(bf16x8, x3[2]);
+  if constexpr (WT == 2) {
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x1, acc[1], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x0, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x2, acc[2], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x1, acc[2], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], x0, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x2, acc[3], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], x1, acc[3], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], x2, acc[3], 0, 0, 0);
+  } else {
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x1, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x2, acc[2], 0, 0, 0);
+  }
+}
+template <int WT>
+__device__ __forceinline__ f32x4 acc_sum(const f32x4* acc) {
+  if constexpr (WT == 2) return ((acc[3] + acc[2]) + acc[1]) + acc[0];
+  else return (acc[2] + acc[1]) + acc[0];
+}
+
 __device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a)); }
 
 // Epilogue shared by the decode GEMV and the prefill GEMM: lane (m = lane & 15, q = lane >> 4) holds columns
@@ -145,29 +196,38 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 // loads, 8 = same k-slice order in every workgroup.
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
 // been consumed, for depths whose three planes do not fit the register budget at once)
+// WT = storage of the weights: 0 bf16 MFMA tiles, 1 fp8 tile pairs (+ row scales), 2 fp32 MFMA tiles (two 16-byte halves per
+// lane and k-group), split into bf16 planes in registers (split3_w8).  With WT = 2 and XB > 1 the weights travel in the same
+// batches as the activation planes (two batches in flight) instead of all up front: 8 bytes x 16 k-groups do not fit.
 // KS = 2: two workgroups per tile group, each over one half of K, each writing its own partial output (out / out2)
 // which the CONSUMER adds (attention gathers q, k, v anyway: one more 16-byte load).  For the qkv GEMV this turns
 // 144 workgroups x 245 KB into 192 x 147 KB: more CUs, fewer bytes through each CU's L2 port, no in-kernel seam.
-template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, bool FP8 = false, int KS = 1>
+template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, int WT = 0, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a) {
   // Wq / XPq duplicate a.W / a.XP as explicit scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs
   // at wave launch, so the address arithmetic of the first (weight) loads does not wait for a kernarg s_load
   a.W = Wq;
   a.XP = XPq;
+  constexpr bool FP8 = WT == 1, F32 = WT == 2;
   static_assert(!FP8 || (G % 2 == 0 && (G / XB) % 2 == 0), "fp8 tile pairs hold two k-groups per lane");
   static_assert(KS == 1 || EPI == E3_STORE, "K-split partials are summed by the consumer: plain stores only");
   static_assert(!FP8 || (G * NW) % 2 == 0, "fp8 tile pairs: a K part must start on an even k-group");
-  constexpr int GW = FP8 ? G / 2 : G;   // weight registers (u32x4) per tile
   constexpr int K = 32 * G * NW * KS;
   constexpr int KG = K / 32;
   constexpr int GB = G / XB;
   static_assert(G % XB == 0, "x batches must divide the groups");
+  constexpr bool WBATCH = F32 && XB > 1;      // weights fetched batch by batch, with the planes
+  constexpr int WH = F32 ? 2 : 1;             // 16-byte loads per lane, tile and k-group
+  constexpr int GW = FP8 ? G / 2 : (WBATCH ? 2 * GB : G);   // weight register groups per tile
+  constexpr int NACC = F32 ? 4 : 3;
   __shared__ f32x4 red[NW][T][64];
   constexpr int SSL = NORM ? 2048 : 4;   // n_ss_in * 16 <= 2048 floats
   __shared__ float ssl[SSL];
 
   const int lane = threadIdx.x & 63;
-  const int wid = threadIdx.x >> 6;
+  // the wave index is uniform, but only readfirstlane proves it to the compiler: weight / plane bases then live in SGPRs
+  // (global_load with an SGPR base + one VGPR lane offset) instead of one 64-bit VGPR address per 4 KB of stream
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // de-phase the k-slices across workgroups: every workgroup reads the SAME activation planes, and with
   // identical slice order all CUs of an XCD hit the same L2 channel at the same time
   const int w = (ABL & 8) ? wid : (int)((wid + blockIdx.x) % NW);
@@ -176,46 +236,56 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   const int ks = KS > 1 ? (int)(blockIdx.x % KS) : 0;            // which part of K
   const int kgo = ks * G * NW;                                   // its first k-group
   const int tile0 = (int)(blockIdx.x / KS) * T;
-  const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
   if (KS > 1 && ks > 0) a.out = a.out2;
+  // Every stream load is a buffer load: descriptor + uniform byte offset in SGPRs, ONE 32-bit VGPR (lane * 16) as the only
+  // per-lane address part (the split-rows index of lane (m, q) is uniform + 16 * q + m = uniform + lane).  With flat 64-bit
+  // addresses hipcc kept a VGPR pair per 4 KB of stream alive (spills in the fp32-weight instances) and spent VALU on them.
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, -16, 0x00020000);
+  const int lane16 = lane * 16;
 
   // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
   // block; a prefill pass loops row blocks (one per prompt position) over the same registers
-  u32x4 wb[T][GW];
+  u32x4 wb[T][GW][WH];
+  // weights of k-groups [g0, g0 + n) of this wave's slice -> register groups [slot0, slot0 + n)
+  auto load_w = [&](int g0, int n, int slot0) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g < g0 || g >= g0 + n) continue;
+      if (FP8 && (g & 1)) continue;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((kgo + w * G + g) >> 1)
+                              : (size_t)(tile0 + t) * KG + (size_t)(kgo + w * G + g);
+        const int slot = slot0 + (FP8 ? (g - g0) / 2 : g - g0);
+#pragma unroll
+        for (int hh = 0; hh < WH; ++hh)
+          wb[t][slot][hh] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
+                                      : __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+      }
+    }
+  };
   // activation planes of the current batch of k-groups; the first batch of the NEXT row block is requested as soon as
   // the last MFMA of this one has been issued, so its round trip runs under the reduction / barrier / epilogue
   constexpr int NXB = XB > 1 ? 2 : 1;   // with several batches two are in flight (double buffer)
   u32x4 xb[NXB][GB][3];
-  const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
   auto load_x = [&](int rb, int b) {
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         xb[b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
-                                      : Xp[split_index16(rb, p, (kgo + w * G + b * GB + g) * 4 + q, m, K)];
+                                      : __builtin_amdgcn_raw_buffer_load_b128(
+                                            xrs, lane16, (int)(((rb * 3 + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
   };
 
   auto row_block = [&](const int rb, const bool first) {
-    if (first) {
-      // interleave the issue so that k-group g is complete once W[g] and x[g] have landed
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (!FP8 || (g & 1) == 0) {
-#pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((kgo + w * G + g) >> 1)
-                                  : (size_t)(tile0 + t) * KG + (size_t)(kgo + w * G + g);
-            wb[t][FP8 ? g / 2 : g] = (ABL & 4) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : __builtin_nontemporal_load(Wp + kg * 64 + lane);
-          }
-        }
-      }
+    if (first || WBATCH) {
+      // all weight tiles first (HBM misses), then the planes (L2 hits)
+      if constexpr (WBATCH) load_w(0, GB, 0);
+      else load_w(0, G, 0);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < GB; ++g)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          xb[0][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : Xp[split_index16(rb, p, (kgo + w * G + g) * 4 + q, m, K)];
+      if (first) load_x(rb, 0);
     }
     // rinv inputs: the producer's per-tile partial sums of squares, fetched by the whole workgroup in one
     // go and parked in LDS (a load->add loop in one wave pays an L2 round trip per partial: 2.4 us)
@@ -230,33 +300,36 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       }
     }
 
-    f32x4 acc[T][3];
+    f32x4 acc[T][NACC];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < NACC; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
-      if (b + 1 < XB) load_x(rb, b + 1);   // into the buffer batch b-1 has just released
+      if (b + 1 < XB) {   // into the buffers batch b-1 has just released
+        if constexpr (WBATCH) load_w((b + 1) * GB, GB, ((b + 1) & 1) * GB);
+        load_x(rb, b + 1);
+      }
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          bf16x8 wf;
+          bf16x8 wf[F32 ? 3 : 1];
           if constexpr (FP8) {
-            const u32x4 pr = wb[t][(b * GB + g) / 2];
-            wf = (g & 1) ? fp8x8_to_bf16(pr.z, pr.w) : fp8x8_to_bf16(pr.x, pr.y);
+            const u32x4 pr = wb[t][(b * GB + g) / 2][0];
+            wf[0] = (g & 1) ? fp8x8_to_bf16(pr.z, pr.w) : fp8x8_to_bf16(pr.x, pr.y);
+          } else if constexpr (F32) {
+            const int slot = WBATCH ? (b & 1) * GB + g : b * GB + g;
+            split3_w8(wb[t][slot][0], wb[t][slot][WH - 1], wf[0], wf[1], wf[2]);
           } else {
-            wf = __builtin_bit_cast(bf16x8, wb[t][b * GB + g]);
+            wf[0] = __builtin_bit_cast(bf16x8, wb[t][b * GB + g][0]);
           }
-#pragma unroll
-          for (int p = 0; p < 3; ++p) {
-            if constexpr (ABL & 1) {
-              asm volatile("" ::"v"(wf), "v"(xb[b % NXB][g][p]));
-            } else {
-              acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xb[b % NXB][g][p]), acc[t][p], 0, 0, 0);
-            }
+          if constexpr (ABL & 1) {
+            asm volatile("" ::"v"(wf[0]), "v"(xb[b % NXB][g][0]), "v"(xb[b % NXB][g][1]), "v"(xb[b % NXB][g][2]));
+          } else {
+            mfma_group<WT>(wf, xb[b % NXB][g], acc[t]);
           }
         }
         if (first) __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
     if (rb + 1 < a.R) load_x(rb + 1, 0);
 
 #pragma unroll
-    for (int t = 0; t < T; ++t) red[wid][t][lane] = (acc[t][2] + acc[t][1]) + acc[t][0];
+    for (int t = 0; t < T; ++t) red[wid][t][lane] = acc_sum<WT>(acc[t]);
     if constexpr (NORM) {
 #pragma unroll
       for (int j = 0; j < SSN; ++j) {
@@ -319,9 +392,12 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
 #define G3M_RB 4
 #define G3M_T 2
 #define G3M_NW 8
-template <int EPI, bool NORM, bool FP8 = false>
+template <int EPI, bool NORM, int WT = 0>
 __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) {
   constexpr int RB = G3M_RB, T = G3M_T, NW = G3M_NW;
+  constexpr bool FP8 = WT == 1, F32 = WT == 2;
+  constexpr int WH = F32 ? 2 : 1;
+  constexpr int NACC = F32 ? 4 : 3;
   __shared__ u32x4 xs[2][RB * 3 * 64];
   __shared__ float rinv_s[RB * 16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -332,7 +408,7 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
   const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
   constexpr int XL = (RB * 3 * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group (2)
 
-  u32x4 xr[XL], wr[T];
+  u32x4 xr[XL], wr[T][WH];
   auto load_x = [&](int kg) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
@@ -353,7 +429,9 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
     if (FP8 && (kg & 1)) return;
 #pragma unroll
     for (int t = 0; t < T; ++t)
-      wr[t] = __builtin_nontemporal_load(Wp + (FP8 ? (size_t)(tile0 + t) * (KG / 2) + (kg >> 1) : (size_t)(tile0 + t) * KG + kg) * 64 + lane);
+#pragma unroll
+      for (int hh = 0; hh < WH; ++hh)
+        wr[t][hh] = __builtin_nontemporal_load(Wp + ((FP8 ? (size_t)(tile0 + t) * (KG / 2) + (kg >> 1) : (size_t)(tile0 + t) * KG + kg) * WH + hh) * 64 + lane);
   };
 
   load_x(0);
@@ -372,31 +450,32 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
   store_x(0);
   __syncthreads();
 
-  f32x4 acc[RB][T][3];
+  f32x4 acc[RB][T][NACC];
 #pragma unroll
   for (int r = 0; r < RB; ++r)
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int p = 0; p < NACC; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int kg = 0; kg < KG; ++kg) {
     const int buf = kg & 1;
-    bf16x8 wf[T];
+    bf16x8 wf[T][F32 ? 3 : 1];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      if constexpr (FP8) wf[t] = (kg & 1) ? fp8x8_to_bf16(wr[t].z, wr[t].w) : fp8x8_to_bf16(wr[t].x, wr[t].y);
-      else wf[t] = __builtin_bit_cast(bf16x8, wr[t]);
+      if constexpr (FP8) wf[t][0] = (kg & 1) ? fp8x8_to_bf16(wr[t][0].z, wr[t][0].w) : fp8x8_to_bf16(wr[t][0].x, wr[t][0].y);
+      else if constexpr (F32) split3_w8(wr[t][0], wr[t][WH - 1], wf[t][0], wf[t][1], wf[t][2]);
+      else wf[t][0] = __builtin_bit_cast(bf16x8, wr[t][0]);
     }
     if (kg + 1 < KG) { load_x(kg + 1); load_w(kg + 1); }
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
+    for (int r = 0; r < RB; ++r) {
+      u32x4 x3[3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const bf16x8 xf = __builtin_bit_cast(bf16x8, xs[buf][(r * 3 + p) * 64 + lane]);
+      for (int p = 0; p < 3; ++p) x3[p] = xs[buf][(r * 3 + p) * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[r][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], xf, acc[r][t][p], 0, 0, 0);
-      }
+      for (int t = 0; t < T; ++t) mfma_group<WT>(wf[t], x3, acc[r][t]);
+    }
     if (kg + 1 < KG) store_x(buf ^ 1);
     __syncthreads();
   }
@@ -408,7 +487,7 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
     f32x4 v[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      f32x4 sacc = (acc[r][t][2] + acc[r][t][1]) + acc[r][t][0];
+      f32x4 sacc = acc_sum<WT>(acc[r][t]);
       if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * (lane >> 4));
       v[t] = sacc * rinv;
     }

@@ -77,7 +77,7 @@ int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t
   const vaura_dims& m = d->dims;
   const int D = m.cond_dim + m.tok_dim;
   if (!d->tok_table || (D % 256)) return VAURA_ERR_SHAPE;
-  const bool split = d->wdtype != VAURA_W_F32;
+  const bool split = d->wdtype != VAURA_W_F32 || d->ws_h_split != nullptr;   // plane path (api.hip enqueue_step)
   if (split && (!d->ws_h_split || !d->ws_ss || !d->first_norm)) return VAURA_ERR_ARG;
   VA_LAUNCH(embed_kernel, dim3(d->rows, D / 256, n_pos), dim3(64), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
             d->tok_table, d->ws_h, split ? d->ws_h_split : nullptr, d->first_norm, d->ws_ss, d->batch, m.n_codebooks,
@@ -330,8 +330,10 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
       const int offset = pos + 1;
       const int t = offset - 1 - k;
       const int tok = (t >= 0 && t < a.T) ? token : V;
-      int32_t* slot = a.seq + ((size_t)b * a.K + k) * a.S + offset;
-      if (*slot == -1) *slot = tok;
+      if (offset < a.S) {   // a step past the end of the sequence (refused by vaura_generate_loop) must not write
+        int32_t* slot = a.seq + ((size_t)b * a.K + k) * a.S + offset;
+        if (*slot == -1) *slot = tok;
+      }
     }
     if (a.state_rw) {
       // No fences: nothing in THIS launch reads the token slots or the state written here; the next kernel sees them

@@ -49,9 +49,34 @@ def off_null_stream(dev: torch.device):
     if side is None:
         side = _PRIVATE_STREAMS[dev] = torch.cuda.Stream(dev)
     side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        yield cur
-    cur.wait_stream(side)
+    try:
+        with torch.cuda.stream(side):
+            yield cur
+    finally:
+        # also on an exception: kernels already enqueued on the side stream must still be ordered before later null-stream work
+        cur.wait_stream(side)
+
+
+def bf16_lossless(w: torch.Tensor) -> bool:
+    """True when every element of ``w`` survives a round trip through bf16 (so bf16 storage computes on the same numbers)."""
+    w = w.detach().float()
+    return bool(torch.equal(w.to(torch.bfloat16).float(), w))
+
+
+def streamed_matrices(sd: Dict[str, torch.Tensor]):
+    """The matrices the decode loop streams every step (98 % of the bytes)."""
+    from .synth import is_streamed_weight
+    return [k for k in sd if is_streamed_weight(k)]
+
+
+def resolve_weight_dtype(sd: Dict[str, torch.Tensor], wdtype: str) -> str:
+    """"auto" -> "bf16" when EVERY streamed matrix is bf16-representable (storage then loses nothing: half the HBM bytes,
+    same real numbers), else "f32" (the reference runs the sampler in fp32, configs/vaura_defaults.yaml `precision: 32`;
+    rounding 694 M trained weights to bf16 flips greedy tokens: SURVEY.md §7 "Hard parts").  A real V-AURA checkpoint
+    (fp32 master weights of 16-mixed training) resolves to "f32"."""
+    if wdtype != "auto":
+        return wdtype
+    return "bf16" if all(bf16_lossless(sd[k]) for k in streamed_matrices(sd)) else "f32"
 
 
 def _require_cuda(dev: torch.device):
@@ -61,10 +86,19 @@ def _require_cuda(dev: torch.device):
 
 
 class DecoderEngine:
-    def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "bf16"):
+    def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
+                 f32_kernels: str = "planes"):
+        """wdtype: storage of the streamed matrices — "auto" (bf16 iff lossless for this checkpoint, else f32; see
+        ``resolve_weight_dtype``), "bf16" (rounds a checkpoint that is not bf16-representable: NOT reference-exact then),
+        "f32", "fp8".  f32_kernels: "planes" (default: fp32 weights split into bf16 planes in registers, same kernels as the
+        bf16 storage) or "mfma32" (the exact-fp32-MFMA GEMVs of gemv_kernel.h, kept as a cross-check)."""
         _require_cuda(device)
         self.cfg = cfg
         self.dev = torch.device(device)
+        self.requested_wdtype = wdtype
+        wdtype = resolve_weight_dtype(sd, wdtype)
+        assert f32_kernels in ("planes", "mfma32")
+        self.planes = not (wdtype == "f32" and f32_kernels == "mfma32")   # activations travel as bf16 planes
         # "fp8": e4m3 + power-of-two row scales for the four per-layer matrices (BASELINE configs[4]); the codebook
         # heads stay bf16.  The model then IS the one with weights quant.fp8_effective_weight(W): same kernels,
         # same exact-fp32 activation arithmetic.
@@ -104,7 +138,7 @@ class DecoderEngine:
             self._keep.append(self.tok_table)
             L.check(self.lib.vaura_build_token_table(L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b),
                                                      L.ptr(self.tok_table), K, cfg.d_codebook + 1, cfg.codebook_dim,
-                                                     cfg.tok_dim, L.current_stream()), "vaura_build_token_table")
+                                                     cfg.tok_dim, L.current_stream(self.dev)), "vaura_build_token_table")
             torch.cuda.synchronize(self.dev)
         self.dims = L.Dims(cfg.num_layers, D, cfg.nhead, F, K, cfg.d_codebook, cfg.cond_dim, cfg.tok_dim, cfg.cond_in,
                            cfg.codebook_dim, 7, cfg.layer_norm_eps)
@@ -123,8 +157,8 @@ class DecoderEngine:
         N, K = w.shape
         src = w.detach().to(self.dev, torch.float32).contiguous()
         dst = torch.empty(self.lib.vaura_packed_weight_bytes(N, K, wd), dtype=torch.uint8, device=self.dev)
-        L.check(self.lib.vaura_pack_weight(L.ptr(src), L.ptr(dst), N, K, wd, L.current_stream()), "vaura_pack_weight")
-        torch.cuda.current_stream().synchronize()  # src may be freed right after
+        L.check(self.lib.vaura_pack_weight(L.ptr(src), L.ptr(dst), N, K, wd, L.current_stream(self.dev)), "vaura_pack_weight")
+        torch.cuda.current_stream(self.dev).synchronize()  # src may be freed right after
         self._keep.append(dst)
         return dst
 
@@ -148,7 +182,7 @@ class DecoderEngine:
         if self._shape == key:
             return
         with torch.cuda.device(self.dev):
-            pp = min(self.PREFILL_POSITIONS, S) if self.wdtype != "f32" else 1
+            pp = min(self.PREFILL_POSITIONS, S) if self.planes else 1
             rp = self._rows_padded(rows) * pp     # decode uses the first position's worth of row blocks
             f32 = dict(dtype=torch.float32, device=self.dev)
             self.rope = rope_table(max_len, c.head_dim, c.rope_base).to(self.dev)
@@ -188,10 +222,13 @@ class DecoderEngine:
         d.kcache, d.vcache, d.seq, d.state = L.ptr(self.kcache), L.ptr(self.vcache), L.ptr(self.seq), L.ptr(self.state)
         d.noise = 0
         d.ws_h, d.ws_qkv, d.ws_attn = L.ptr(self.ws_h), L.ptr(self.ws_qkv), L.ptr(self.ws_attn)
-        d.ws_qkv2 = L.ptr(self.ws_qkv2)
+        d.ws_qkv2 = L.ptr(self.ws_qkv2) if self.planes else 0
         d.ws_ffn, d.ws_logits = L.ptr(self.ws_ffn), L.ptr(self.ws_logits)
-        d.ws_h_split, d.ws_attn_split = L.ptr(self.ws_h_split), L.ptr(self.ws_attn_split)
-        d.ws_ffn_split, d.ws_ss = L.ptr(self.ws_ffn_split), L.ptr(self.ws_ss)
+        if self.planes:
+            d.ws_h_split, d.ws_attn_split = L.ptr(self.ws_h_split), L.ptr(self.ws_attn_split)
+            d.ws_ffn_split, d.ws_ss = L.ptr(self.ws_ffn_split), L.ptr(self.ws_ss)
+        else:   # NULL split workspaces select the exact-fp32-MFMA step (api.hip enqueue_step)
+            d.ws_h_split = d.ws_attn_split = d.ws_ffn_split = d.ws_ss = 0
         d.first_norm = self.layers[0].attn_norm
         d.ws_attn_part = L.ptr(self.ws_attn_part)
         self.dec = d
@@ -215,7 +252,7 @@ class DecoderEngine:
                 raise L.VauraHipError(f"CFG null embedding has {self.uncond.shape[0]} tokens, condition has {Tv}")
             x = torch.cat([x, torch.zeros_like(x) + self.uncond], dim=0)
         x = x.reshape(self.rows * Tv, Cin).contiguous()
-        st = L.current_stream()
+        st = L.current_stream(self.dev)
         n = self.rows * Tv
         L.check(self.lib.vaura_pack_rows(L.ptr(x), L.ptr(self.cond_in), n, Cin, st), "vaura_pack_rows")
         L.check(self.lib.vaura_prefill_cond(C.byref(self.dims), L.ptr(self.cond_in), L.ptr(self.fc1), L.ptr(self.fc2),
@@ -227,7 +264,7 @@ class DecoderEngine:
         """(rows, Tv, cond_dim) row-major view of the hoisted video MLP output (tests)."""
         n = self.rows * self.Tv
         out = torch.empty(n, self.cfg.cond_dim, dtype=torch.float32, device=self.dev)
-        L.check(self.lib.vaura_unpack_rows(L.ptr(self.cond_proj), L.ptr(out), n, self.cfg.cond_dim, L.current_stream()),
+        L.check(self.lib.vaura_unpack_rows(L.ptr(self.cond_proj), L.ptr(out), n, self.cfg.cond_dim, L.current_stream(self.dev)),
                 "vaura_unpack_rows")
         return out.view(self.rows, self.Tv, self.cfg.cond_dim)
 
@@ -246,7 +283,7 @@ class DecoderEngine:
             assert Tp < T, "gt audio prompt can not be longer than max_new_tokens"
             self.codes_i32[..., :Tp] = prompt.to(self.dev, torch.int32)
         L.check(self.lib.vaura_pattern_build(L.ptr(self.codes_i32), L.ptr(self.seq), self.batch, K, T,
-                                             self.cfg.d_codebook, L.current_stream()), "vaura_pattern_build")
+                                             self.cfg.d_codebook, L.current_stream(self.dev)), "vaura_pattern_build")
         self.state.zero_()
         return Tp
 
@@ -260,7 +297,7 @@ class DecoderEngine:
         self._noise_keepalive = noise
         use_graph = bool(use_graph and n_steps > 0)
         with (off_null_stream(self.dev) if use_graph else contextlib.nullcontext()):
-            st = L.current_stream()
+            st = L.current_stream(self.dev)
             if use_graph:
                 key = (self._shape, L.ptr(noise), bytes(sp))
                 if self._graph_key != key:       # the captured step is tied to these buffers / parameters
@@ -286,7 +323,7 @@ class DecoderEngine:
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T
         L.check(self.lib.vaura_pattern_revert(L.ptr(self.seq), L.ptr(self.codes_i32), self.batch, K, T, self.S, -1,
-                                              L.current_stream()), "vaura_pattern_revert")
+                                              L.current_stream(self.dev)), "vaura_pattern_revert")
         return self.codes_i32
 
     @torch.no_grad()
@@ -324,7 +361,7 @@ class DecoderEngine:
         self.state.zero_()
         out = torch.empty(Bs, K, Lq, self.cfg.d_codebook, dtype=torch.float32, device=self.dev)
         sp = self._sampling(False, 1.0, 0, 0.0, 1.0, 0, 0)
-        st = L.current_stream()
+        st = L.current_stream(self.dev)
         keep = self.seq.clone()
         for p in range(Lq):
             L.check(self.lib.vaura_decode_step(C.byref(self.dec), C.byref(sp), 1, st), "vaura_decode_step")
@@ -422,7 +459,7 @@ class CodecEngine:
                 self.c.ws_elems = need
                 self._ws_key = need
             wav = torch.empty(B, 1, T * self.cfg.hop, dtype=torch.float32, device=self.dev)
-            L.check(self.lib.vaura_dac_decode(C.byref(self.c), L.ptr(ci), B, T, L.ptr(wav), L.current_stream()),
+            L.check(self.lib.vaura_dac_decode(C.byref(self.c), L.ptr(ci), B, T, L.ptr(wav), L.current_stream(self.dev)),
                     "vaura_dac_decode")
             self._codes_keepalive = ci
         if caller is not None:
@@ -530,7 +567,7 @@ class CodecEncoderEngine:
                 self.c.ws_elems = need
                 self._ws_key = need
             codes = torch.empty(B, self.cfg.n_codebooks, T, dtype=torch.int32, device=self.dev)
-            L.check(self.lib.vaura_dac_encode(C.byref(self.c), L.ptr(x), B, T * hop, L.ptr(codes), L.current_stream()),
+            L.check(self.lib.vaura_dac_encode(C.byref(self.c), L.ptr(x), B, T * hop, L.ptr(codes), L.current_stream(self.dev)),
                     "vaura_dac_encode")
             out = codes.to(torch.int64)
         if caller is not None:

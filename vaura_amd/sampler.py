@@ -56,7 +56,7 @@ class Transformer(nn.Module):
                  activation: str = "relu", layer_norm_eps: float = 1e-5, batch_first: bool = False,
                  norm_first: bool = False, num_codebooks: int = 2, positional_embedder: str = "sinusoidal",
                  use_visual_conditioning: bool = True, use_delay_strategy: bool = False,
-                 cond_feature_channel_scaler: int = 2, weight_dtype: str = "bf16"):
+                 cond_feature_channel_scaler: int = 2, weight_dtype: str = "auto"):
         super().__init__()
         self.cfg = SamplerCfg(num_layers=num_layers, d_model=d_model, nhead=nhead, d_codebook=d_codebook,
                               num_codebooks=num_codebooks, block_size_audio=block_size_audio,
@@ -73,7 +73,10 @@ class Transformer(nn.Module):
                                       norm_eps=layer_norm_eps, rope_base=c.rope_base, initializer_range=0.02)
         self.audio_tokens_per_video_frame: Optional[int] = None
         self.codebook_pattern = None
-        self.weight_dtype = weight_dtype  # storage of the streamed matrices on the device: "bf16" | "f32" | "fp8"
+        # Storage of the streamed matrices on the device.  "auto" (default): bf16 when that is lossless for the loaded
+        # checkpoint, else f32 — i.e. always the reference's fp32 numbers (engine.resolve_weight_dtype).  "bf16" / "fp8"
+        # force a smaller storage and ROUND a checkpoint that does not fit it (not token-exact any more); "f32" forces fp32.
+        self.weight_dtype = weight_dtype
 
         D, F = c.d_model, c.ffn_dim
         shapes = {
@@ -119,10 +122,16 @@ class Transformer(nn.Module):
         self._engine = None
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
+    def _weights_fingerprint(self):
+        """Changes whenever a parameter is rewritten in place (``_version``), replaced (``data_ptr``) or moved: covers a
+        ``load_state_dict`` on the PARENT module (which never calls this class's override), ``initialize_embeddings`` and
+        manual edits, so a stale packed copy is never decoded from."""
+        return tuple((t._version, t.data_ptr()) for t in list(self.parameters()) + list(self.buffers()))
+
     def engine(self) -> DecoderEngine:
-        """Pack the current parameters for the HIP path (once per device / weight dtype)."""
+        """Pack the current parameters for the HIP path (once per device / weight dtype / parameter state)."""
         dev = self.norm.weight.device
-        key = (str(dev), self.weight_dtype)
+        key = (str(dev), self.weight_dtype, self._weights_fingerprint())
         if self._engine is None or self._engine_key != key:
             if dev.type != "cuda":
                 raise L.VauraHipError("vaura_amd.sampler.Transformer runs on a HIP device only; call .to('cuda') first")
@@ -130,6 +139,11 @@ class Transformer(nn.Module):
             self._engine = DecoderEngine(self.cfg, sd, dev, wdtype=self.weight_dtype)
             self._engine_key = key
         return self._engine
+
+    @property
+    def resolved_weight_dtype(self) -> str:
+        """What "auto" resolved to for the parameters currently loaded ("bf16" | "f32" | "fp8")."""
+        return self.engine().wdtype
 
     # ------------------------------------------------------------------ reference call surface
     @torch.no_grad()
