@@ -317,6 +317,10 @@ int vaura_audio_normalize(const float* wav, float* out, int n_clips, int64_t n_s
                           float peak_clip_headroom_db, float rms_headroom_db, float* scratch, vaura_stream_t s);
 size_t vaura_audio_scratch_elems(int n_clips);
 
+/* Measurement aid (tools/pmc_driver, A/B timing): selects kernel variants for launches enqueued (or graphs captured) afterwards.
+ * bit 0: wo / w2 GEMVs as one workgroup per column tile instead of the row-split pair.  0 = the product configuration.   */
+void vaura_set_debug_flags(unsigned flags);
+
 const char* vaura_version(void);
 /* sizeof() of the descriptor structs as compiled into the library (0 dims, 1 layer_weights, 2 sampling, 3 decoder,
  * 4 conv, 5 codec, 6 codec_encoder): a binding checks its mirrored struct layouts against these before the first call.            */

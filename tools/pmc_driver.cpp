@@ -5,11 +5,15 @@
 // values.  No python, no env/bash hop: the program itself goes after `--`.
 //
 //   pmc_driver <lib> [--weights bf16|f32] [--steps 24] [--pos0 100] [--rows 16]
+//   pmc_driver <lib> --time 7 [--flags 0,1,...] [--weights ...]     A/B timing, no profiler: for every debug-flag set
+//       (vaura_set_debug_flags) one captured step graph; `--time` rounds of the full 228-step loop per variant, INTERLEAVED in
+//       one process (median / min reported), then the per-stage averages of one eager pass (vaura_profile_loop)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "../include/vaura_hip.h"
@@ -49,8 +53,14 @@ template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * 
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights bf16|f32] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
-  int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16;
+  int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16, rounds = 0;
+  std::vector<unsigned> variants{0u};
   for (int i = 2; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--time")) rounds = atoi(argv[i + 1]);
+    if (!strcmp(argv[i], "--flags")) {
+      variants.clear();
+      for (char* t = strtok(argv[i + 1], ","); t; t = strtok(nullptr, ",")) variants.push_back((unsigned)strtoul(t, nullptr, 0));
+    }
     if (!strcmp(argv[i], "--weights")) wd = !strcmp(argv[i + 1], "f32") ? VAURA_W_F32 : VAURA_W_BF16;
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
@@ -97,6 +107,49 @@ int main(int argc, char** argv) {
   vaura_sampling sp{1, 1.0f, 250, 0.0f, 6.0f, 1234ull, 0ull};
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CK(hipDeviceSynchronize());
+  if (rounds > 0) {
+    auto gbuild = (int (*)(const vaura_decoder*, const vaura_sampling*, vaura_stream_t, vaura_step_graph_t*))dlsym(lib, "vaura_step_graph_build");
+    auto gloop = (int (*)(const vaura_decoder*, const vaura_sampling*, int, int, vaura_step_graph_t, vaura_stream_t))dlsym(lib, "vaura_generate_loop");
+    auto setf = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags");
+    auto prof = (int (*)(const vaura_decoder*, const vaura_sampling*, int, unsigned, double*, int64_t*, vaura_stream_t))dlsym(lib, "vaura_profile_loop");
+    if (!gbuild || !gloop || !setf || !prof) { fprintf(stderr, "missing symbols\n"); return 1; }
+    const int n = S - 1;
+    std::vector<vaura_step_graph_t> graphs(variants.size());
+    for (size_t v = 0; v < variants.size(); ++v) {
+      setf(variants[v]);
+      const int rc = gbuild(&d, &sp, st, &graphs[v]);
+      if (rc) { fprintf(stderr, "graph build (flags %u): %d\n", variants[v], rc); return 3; }
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> ms(variants.size());
+    const int32_t zero[4] = {0, 0, 0, 0};
+    for (int r = -1; r < rounds; ++r)          // round -1 = warm-up
+      for (size_t v = 0; v < variants.size(); ++v) {
+        CK(hipMemcpyAsync(d.state, zero, sizeof zero, hipMemcpyHostToDevice, st));
+        CK(hipEventRecord(e0, st));
+        const int rc = gloop(&d, &sp, 0, n, graphs[v], st);
+        if (rc) { fprintf(stderr, "generate_loop: %d\n", rc); return 3; }
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        if (r >= 0) ms[v].push_back(t);
+      }
+    static const char* kinds[8] = {"embed", "qkv", "attn", "wo", "w13", "w2", "heads", "sample"};
+    for (size_t v = 0; v < variants.size(); ++v) {
+      std::sort(ms[v].begin(), ms[v].end());
+      setf(variants[v]);
+      CK(hipMemcpy(d.state, zero, sizeof zero, hipMemcpyHostToDevice));
+      double tot[8]; int64_t cnt[8];
+      const int rc = prof(&d, &sp, n, 0xFF, tot, cnt, st);
+      if (rc) { fprintf(stderr, "profile_loop: %d\n", rc); return 3; }
+      printf("flags %u weights %s rows %d: loop of %d steps median %.3f ms min %.3f ms (%.1f us/step) |", variants[v],
+             wd == VAURA_W_F32 ? "f32" : "bf16", rows, n, ms[v][ms[v].size() / 2], ms[v][0], 1e3 * ms[v][ms[v].size() / 2] / n);
+      for (int k = 0; k < 8; ++k) printf(" %s %.2f", kinds[k], 1e3 * tot[k] / (cnt[k] ? cnt[k] : 1));
+      printf("\n");
+    }
+    setf(0);
+    return 0;
+  }
   const int32_t st0[4] = {pos0, 0, 0, 0};
   CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
   for (int i = 0; i < steps; ++i) {

@@ -88,6 +88,7 @@ SIGNATURES = {
     "vaura_dac_encode": (C.c_int, [C.POINTER(CodecEncoder), C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vaura_dac_encode_workspace_elems": (C.c_size_t, [C.POINTER(CodecEncoder), C.c_int, C.c_int64]),
     "vaura_version": (C.c_char_p, []),
+    "vaura_set_debug_flags": (None, [C.c_uint]),
     "vaura_struct_size": (C.c_size_t, [C.c_int]),
     "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),
     "vaura_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),

@@ -8,17 +8,36 @@ static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   return 0;
 }
 
+// measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split)
+unsigned va_debug_flags = 0;
+
+template <int WT, int G2, int EPI, int XB>
+static int launch3h(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
+  const int halves = (a.R == 1 && a.rows <= 8) ? 1 : 2;    // at most 8 live rows: the second half would multiply zeros
+  if (halves == 2 && (n_tiles % 8)) return VAURA_ERR_SHAPE;
+  VA_LAUNCH((gemv3h_kernel<G2, 8, EPI, XB, WT>), dim3((unsigned)(n_tiles * halves)), dim3(512), 0, s, a.W, a.XP, a, halves);
+  return 0;
+}
+
 template <int WT>
 static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
   // fp32 weights are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
   // flight) like the K = 4096 instances their four, so that the slice a wave holds fits the register file without spills
   constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
+  if constexpr (WT != 1) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
+    if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
+      if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1>(a, tiles, s);
+      if (K == 1536 && epilogue == E3_STORE) return launch3h<WT, 3, E3_STORE, 1>(a, tiles, s);
+      if (K == 4096 && epilogue == E3_RESID) return launch3h<WT, 8, E3_RESID, (WT == 2 ? 4 : 1)>(a, tiles, s);
+      if (K == 4096 && epilogue == E3_STORE) return launch3h<WT, 8, E3_STORE, (WT == 2 ? 4 : 1)>(a, tiles, s);
+    }
+  }
   if (K == 1536) {
     if (epilogue == E3_STORE && norm) return launch3<WT, 6, 8, 2, E3_STORE, true, XB2>(a, tiles, s);
     if (epilogue == E3_STORE && !norm) return launch3<WT, 6, 8, 1, E3_STORE, false>(a, tiles, s);
     if (epilogue == E3_RESID && !norm) return launch3<WT, 6, 8, 1, E3_RESID, false>(a, tiles, s);
     if (epilogue == E3_SWIGLU && norm) return launch3<WT, 6, 8, 2, E3_SWIGLU, true, XB2>(a, tiles, s);
-    if (epilogue == E3_LOGITS && norm) return launch3<WT, 6, 8, (WT == 2 ? 2 : 3), E3_LOGITS, true, XB2>(a, tiles, s);
+    if (epilogue == E3_LOGITS && norm) return launch3<WT, 6, 8, 3, E3_LOGITS, true, XB2>(a, tiles, s);
   } else if (K == 4096) {
     if (epilogue == E3_RESID && !norm) return launch3<WT, 16, 8, 1, E3_RESID, false, XB4>(a, tiles, s);
     if (epilogue == E3_STORE && !norm) return launch3<WT, 16, 8, 1, E3_STORE, false, XB4>(a, tiles, s);
@@ -150,6 +169,8 @@ __global__ void split_rows_kernel(const float* __restrict__ src, uint16_t* __res
 }
 
 extern "C" {
+
+void vaura_set_debug_flags(unsigned flags) { va_debug_flags = flags; }
 
 int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* ss, int64_t rows, int64_t C, vaura_stream_t s) {
   if (!src || !dst || rows <= 0 || C <= 0 || (C % 16)) return VAURA_ERR_ARG;

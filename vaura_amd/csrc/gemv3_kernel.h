@@ -149,8 +149,30 @@ __device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a))
 
 // Epilogue shared by the decode GEMV and the prefill GEMM: lane (m = lane & 15, q = lane >> 4) holds columns
 // 4q..4q+3 of row m of each of the T consecutive 16-column tiles starting at tile0 (already scaled by rinv).
+// Operands of the residual epilogue that do not depend on this kernel's own sums: requested at kernel start by the wave
+// that will need them (the residual rows were written by the PREVIOUS kernel: a cold read of ~1 us if it only starts
+// after the reduction barrier).
+struct EpiPre {
+  f32x4 res, gain;
+  bool have;
+};
+template <int EPI>
+__device__ __forceinline__ EpiPre gemv3_epilogue_prefetch(const Gemv3Args& a, int rb, int tile, int lane) {
+  EpiPre p;
+  p.have = false;
+  p.res = p.gain = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == E3_RESID) {
+    const int q = lane >> 4;
+    p.res = reinterpret_cast<const f32x4*>(a.res)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane];
+    if (a.outp && a.gain_out) p.gain = *reinterpret_cast<const f32x4*>(a.gain_out + tile * 16 + 4 * q);
+    p.have = true;
+  }
+  return p;
+}
+
 template <int T, int EPI>
-__device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int tile0, int lane, const f32x4* v) {
+__device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int tile0, int lane, const f32x4* v,
+                                               const EpiPre* pre = nullptr) {
   const int m = lane & 15, q = lane >> 4;
   const int row = rb * 16 + m;
   if constexpr (EPI == E3_SWIGLU) {
@@ -174,7 +196,7 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
       } else {
         const size_t idx = ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane;
         f32x4 o = v[t];
-        if constexpr (EPI == E3_RESID) o += reinterpret_cast<const f32x4*>(a.res)[idx];
+        if constexpr (EPI == E3_RESID) o += (pre && pre->have && T == 1) ? pre->res : reinterpret_cast<const f32x4*>(a.res)[idx];
         if (a.out) reinterpret_cast<f32x4*>(a.out)[idx] = o;
         if (a.ss_out) {
           float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
@@ -184,7 +206,7 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
         }
         if (a.outp) {
           f32x4 u = o;
-          if (a.gain_out) u *= *reinterpret_cast<const f32x4*>(a.gain_out + c0);
+          if (a.gain_out) u *= (pre && pre->have && T == 1) ? pre->gain : *reinterpret_cast<const f32x4*>(a.gain_out + c0);
           store_split4(a.outp, row, c0, a.N, u);
         }
       }
@@ -300,6 +322,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       }
     }
 
+    // residual / gain of the epilogue wave's tile: behind the stream loads in issue order, landed long before the barrier
+    EpiPre pre;
+    pre.have = false;
+    if constexpr (EPI == E3_RESID && T == 1) {
+      if (wid == 0) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile0, lane);
+    }
+
     f32x4 acc[T][NACC];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -370,7 +399,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
         v[e] = sacc * rinv;
       }
-      gemv3_epilogue<ET, EPI>(a, rb, (EPI == E3_SWIGLU) ? tile0 : tile0 + wid, lane, v);
+      gemv3_epilogue<ET, EPI>(a, rb, (EPI == E3_SWIGLU) ? tile0 : tile0 + wid, lane, v, &pre);
     }
   };
 
@@ -378,6 +407,126 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   for (int rb = 1; rb < a.R; ++rb) {
     __syncthreads();
     row_block(rb, false);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row-split GEMV for the narrow outputs (wo, w2: N = 1536 -> only 96 column tiles).  With one workgroup per tile every
+// workgroup streams the activation planes of ALL 16 rows (147 KB at K = 1536, 393 KB at K = 4096) next to 49 / 131 KB of
+// weights, on 96 of 256 CUs: the planes, not the weights, set the time (DESIGN.md "per-CU bytes").  Here TWO workgroups share a
+// tile, 8 rows each, so a workgroup reads half the planes — without half-empty load instructions: one MFMA covers a PAIR of
+// 32-deep k-groups,
+//      A row  i = (n8, s)  = weight row n8 (+ 8 nh) of the tile, k-group 2 gp + s          (16 rows = 8 n x 2 k-groups)
+//      B col  j = (r8, s') = batch row r8 (+ 8 h) of the block, k-group 2 gp + s'          (16 cols = 8 rows x 2 k-groups)
+//      D[i][j] = sum_k A[i][k] B[k][j]  is a wanted partial product where s == s' (half of the tile; the matrix pipe is idle anyway)
+// and the two k-groups of a pair are added with one cross-lane exchange (lane ^ 40) before the usual LDS reduction over the 8
+// waves.  Every load instruction still moves 64 x 16 B in 128-byte runs.  Weight bytes per workgroup are unchanged (the two
+// workgroups of a tile read the same tiles: ids b and b + 8, i.e. the same XCD's L2 under round-robin placement — speed only).
+// G2 = k-group pairs per wave, XB = batches (weights and planes together, two in flight), WT = 0 bf16 | 2 fp32 weights.
+template <int G2, int NW, int EPI, int XB = 1, int WT = 0>
+__global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a, int halves) {
+  a.W = Wq;
+  a.XP = XPq;
+  static_assert(WT == 0 || WT == 2, "bf16 or fp32 weights");
+  static_assert(EPI == E3_RESID || EPI == E3_STORE, "independent output tiles only");
+  constexpr bool F32 = WT == 2;
+  constexpr int WH = F32 ? 2 : 1;
+  constexpr int NACC = F32 ? 4 : 3;
+  constexpr int K = 64 * G2 * NW;
+  constexpr int KG = K / 32;
+  constexpr int GB = G2 / XB;
+  static_assert(G2 % XB == 0, "batches must divide the pairs");
+  constexpr int NB = XB > 1 ? 2 : 1;          // batches in flight
+  constexpr int BS = 1024 * WH;               // bytes of one (tile, k-group) block
+  __shared__ f32x4 red[NW][2][64];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // blocks b and b + 8 share a tile (same XCD under round-robin dispatch): h = bit 3 of the block id
+  const int bid = blockIdx.x;
+  const int h = halves == 2 ? (bid >> 3) & 1 : 0;
+  const int tile = halves == 2 ? (bid & 7) + 8 * (bid >> 4) : bid;
+  const int w = (wid + tile) % NW;            // de-phase the k-slices across workgroups
+  const int la = lane & 7, sb = (lane >> 3) & 1, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, -16, 0x00020000);
+  const int voffw0 = (la + 16 * q) * 16 + sb * BS;          // weight rows 0..7 of the tile; + 128 bytes for rows 8..15
+  const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;
+
+  u32x4 wb[NB][GB][2][WH];
+  u32x4 xb[NB][GB][3];
+  auto load_w = [&](int b) {
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int soff = (tile * KG + 2 * (w * G2 + b * GB + g)) * BS;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int hh = 0; hh < WH; ++hh)
+          wb[b % NB][g][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
+    }
+  };
+  auto load_x = [&](int rb, int b) {
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        xb[b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voffx, ((rb * 3 + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
+  };
+
+  for (int rb = 0; rb < a.R; ++rb) {
+    if (rb > 0) __syncthreads();
+    if (rb == 0 || XB > 1) load_w(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(rb, 0);
+    EpiPre pre;
+    pre.have = false;
+    if (wid == 0 && ((lane >> 3) & 1) == h) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile, lane);
+
+    f32x4 acc[2][NACC];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < XB; ++b) {
+      if (b + 1 < XB) { load_w(b + 1); load_x(rb, b + 1); }
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          bf16x8 wf[F32 ? 3 : 1];
+          if constexpr (F32) split3_w8(wb[b % NB][g][nh][0], wb[b % NB][g][nh][WH - 1], wf[0], wf[1], wf[2]);
+          else wf[0] = __builtin_bit_cast(bf16x8, wb[b % NB][g][nh][0]);
+          mfma_group<WT>(wf, xb[b % NB][g], acc[nh]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the two k-groups of a pair sit in lanes (s' = 0, q < 2) and (s' = 1, q >= 2) of the same (n, row): lane ^ 40
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      f32x4 v = acc_sum<WT>(acc[nh]);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = v[r];
+        o[r] = x + __shfl_xor(x, 40, 64);
+      }
+      red[wid][nh][lane] = o;
+    }
+    __syncthreads();
+    if (wid == 0) {
+      // epilogue lane (m = lane & 15, q' = lane >> 4) = row m, columns 4 q' .. 4 q' + 3 of the tile: weight rows n = 4 q' + r
+      // -> nh = q' >> 1, source lane (s' = 0 copy) = (m & 7) + 16 (q' & 1); rows of the other half are not this workgroup's
+      const int m = lane & 15;
+      const bool mine = (m >> 3) == h;
+      const int src = (m & 7) + 16 * (q & 1);
+      f32x4 v = red[0][q >> 1][src];
+#pragma unroll
+      for (int i = 1; i < NW; ++i) v += red[i][q >> 1][src];
+      if (mine) gemv3_epilogue<1, EPI>(a, rb, tile, lane, &v, &pre);
+    }
   }
 }
 
