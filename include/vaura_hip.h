@@ -317,13 +317,51 @@ int vaura_audio_normalize(const float* wav, float* out, int n_clips, int64_t n_s
                           float peak_clip_headroom_db, float rms_headroom_db, float* scratch, vaura_stream_t s);
 size_t vaura_audio_scratch_elems(int n_clips);
 
+/* -------------------------------------------------------------------------------------------
+ * f2 (the step before the path) Segment-AVCLIP visual features: MotionFormer.forward
+ * (models/modules/feature_extractors/avclip/motionformer.py:252-364) for the generate_*.yaml configuration: divided space-time
+ * ViT-B/16 ('divided_224_16x4': motionformer_src/video_model_builder.py:174-268, vit_helper.py:392-472, 80-172, 523-557) + one
+ * spatial nn.TransformerEncoderLayer per frame (motionformer.py:366-512), eval mode, no content mask.
+ * Linear weights ("*_w") are in the codec's (hi, lo) fp16 PAIR layout [Cout][Cin/8][hi|lo][8] halves (row-major (Cout, Cin) of
+ * nn.Linear.weight; the Conv3d weight flattened to (768, 1536)); everything else fp32.                                   */
+typedef struct vaura_vit_attn {      /* DividedAttention (vit_helper.py:80-96) */
+  const void* qkv_w; const float* qkv_b;      /* (3D, D) pair layout, (3D) */
+  const void* proj_w; const float* proj_b;    /* (D, D) pair layout, (D)   */
+} vaura_vit_attn;
+typedef struct vaura_vit_block {     /* DividedSpaceTimeBlock (vit_helper.py:392-441) */
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;      /* norm1 (space), norm2 (mlp), norm3 (time) */
+  vaura_vit_attn space, time;                                       /* .attn, .timeattn */
+  const void* fc1_w; const float* fc1_b; const void* fc2_w; const float* fc2_b;   /* mlp.fc1 (hidden, D), mlp.fc2 (D, hidden) */
+} vaura_vit_block;
+typedef struct vaura_vit {
+  int32_t depth, dim, heads, hidden;           /* 12, 768, 12, 3072 */
+  int32_t n_patches, n_frames;                 /* 196 tokens per frame, 8 token frames */
+  int32_t in_chans, frames, img, patch, patch_t, patch_k;   /* 3, 16, 224, 16, 2, 1536 = 3*2*16*16 */
+  float eps; int32_t _pad;                     /* 1e-6 */
+  const void* pe_w; const float* pe_b;         /* patch_embed_3d.proj (D, patch_k) pair layout, (D) */
+  const float *cls_token, *pos_embed, *temp_embed;     /* (D), (1 + n_patches, D), (n_frames, D) */
+  const vaura_vit_block* blocks_host;          /* HOST array [depth] of device pointers */
+  const float *norm_w, *norm_b;                /* final LayerNorm */
+  const float* agg_cls;                        /* spatial_attn_agg.cls_token (D) */
+  const float *agg_ln1_w, *agg_ln1_b, *agg_ln2_w, *agg_ln2_b;
+  const void* agg_in_w; const float* agg_in_b;         /* self_attn.in_proj (3D, D) */
+  const void* agg_out_w; const float* agg_out_b;       /* self_attn.out_proj (D, D) */
+  const void* agg_l1_w; const float* agg_l1_b;         /* linear1 (hidden, D) */
+  const void* agg_l2_w; const float* agg_l2_b;         /* linear2 (D, hidden) */
+  /* workspaces, sizes from vaura_avclip_workspace_bytes(v, n_seg, i), i = 0..6 in this order */
+  float* ws_x; float* ws_qkv; uint16_t* ws_a; uint16_t* ws_h; uint16_t* ws_p; float* ws_z; float* ws_s;
+} vaura_vit;
+/* frames (n_seg, 3, 16, 224, 224) fp32 (the (B, S) segments flattened) -> feats (n_seg, 8, 768) fp32 */
+int vaura_avclip_forward(const vaura_vit* v, const float* frames, int n_seg, float* feats, vaura_stream_t s);
+size_t vaura_avclip_workspace_bytes(const vaura_vit* v, int n_seg, int which);
+
 /* Measurement aid (tools/pmc_driver, A/B timing): selects kernel variants for launches enqueued (or graphs captured) afterwards.
  * bit 0: wo / w2 GEMVs as one workgroup per column tile instead of the row-split pair.  0 = the product configuration.   */
 void vaura_set_debug_flags(unsigned flags);
 
 const char* vaura_version(void);
 /* sizeof() of the descriptor structs as compiled into the library (0 dims, 1 layer_weights, 2 sampling, 3 decoder,
- * 4 conv, 5 codec, 6 codec_encoder): a binding checks its mirrored struct layouts against these before the first call.            */
+ * 4 conv, 5 codec, 6 codec_encoder, 7 vit, 8 vit_block): a binding checks its mirrored struct layouts against these before the first call.            */
 size_t vaura_struct_size(int which);
 
 #ifdef __cplusplus

@@ -4,6 +4,7 @@
     python tests/golden/make_golden.py full_greedy   # 24-layer model, B=2, T=220, greedy   (~4 min)
     python tests/golden/make_golden.py full_sample   # 24-layer, B=2, cfg 6, top-k 250      (~8 min)
     python tests/golden/make_golden.py full_greedy_raw   # full_greedy on the UN-rounded checkpoint (~4 min)
+    python tests/golden/make_golden.py avclip        # Segment-AVCLIP extractor (row f2), reference classes, 1 + 4 segments (~1 min)
     python tests/golden/make_golden.py full_c4       # configs[3]: block_size 1024, Tv=128, B=1, T=880 (~30 min)
     python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
     python tests/golden/make_golden.py post          # post-codec audio scaling (row f3)    (seconds)
@@ -337,6 +338,35 @@ def gold_codec_enc():
          encoder_dim=np.int64(ccfg.encoder_dim), latent_dim=np.int64(ccfg.latent_dim))
 
 
+def gold_avclip():
+    """Row f2: the reference's own MotionFormer (divided space-time ViT-B/16 + spatial aggregation layer) on ONE seeded
+    16-frame segment at full width with seeded weights (synth.avclip_state_dict): the (1, 1, 8, 768) features plus three
+    intermediate token tensors (sub-sampled) for stage-level checks.  Inputs are regenerated from seeds, not stored."""
+    sd = synth.avclip_state_dict(seed=0)
+    m = rh.build_reference_motionformer(sd)
+    frames = synth.video_frames(1, 1, seed=0)
+    taps = {}
+    hooks = [m.blocks[0].register_forward_hook(lambda _m, _i, o: taps.__setitem__("block0", o.detach().clone())),
+             m.blocks[-1].register_forward_hook(lambda _m, _i, o: taps.__setitem__("block11", o.detach().clone())),
+             m.pos_drop.register_forward_hook(lambda _m, _i, o: taps.__setitem__("tokens", o.detach().clone()))]
+    t = time.time()
+    with torch.no_grad():
+        feats, glob = m(frames)
+    dt = time.time() - t
+    for h in hooks:
+        h.remove()
+    assert glob is None and feats.shape == (1, 1, 8, 768)
+    rows = np.array([0, 1, 2, 197, 198, 785, 1568])
+    save("avclip.npz", feats=feats.numpy(), rows=rows, tokens=taps["tokens"][0, rows].numpy(), block0=taps["block0"][0, rows].numpy(),
+         block11=taps["block11"][0, rows].numpy(), weight_seed=np.int64(0), frame_seed=np.int64(0), ref_seconds=np.float64(dt))
+    # two segments of two clips through the batched path (for_loop=False) for the layout of (B, S)
+    frames2 = synth.video_frames(2, 2, seed=1)
+    with torch.no_grad():
+        f2, _ = m(frames2)
+    save("avclip_b2s2.npz", feats=f2.numpy(), frame_seed=np.int64(1), weight_seed=np.int64(0))
+    print(f"reference MotionFormer: {dt:.1f}s per segment")
+
+
 def gold_post():
     """Post-codec scaling: the reference's own normalize_audio (utils/data_utils.py:407-466)
     on seeded waveforms: loud (peaks > 1), nominal, quiet; 'clip' (the configs' default), 'peak' and 'rms'
@@ -377,6 +407,8 @@ if __name__ == "__main__":
         gold_full_greedy_raw()
     elif what == "full_c4":
         gold_full_c4()
+    elif what == "avclip":
+        gold_avclip()
     elif what == "full_sample":
         gold_full_sample()
     elif what == "codec":

@@ -119,6 +119,80 @@ def _install_dac_placeholder():
     sys.modules.update({"dac": dac, "dac.model": dac_model, "dac.nn": dac_nn, "dac.nn.layers": dac_layers})
 
 
+def _install_avclip_placeholders():
+    """What the Segment-AVCLIP extractor (models/modules/feature_extractors/avclip/) imports from packages this image lacks.
+    None of it takes part in the eval-mode arithmetic: ``trunc_normal_`` only initialises parameters (the goldens load seeded
+    weights over them), ``DropPath`` is the identity in eval mode (the standard stochastic-depth module, restated below), and
+    ``to_2tuple`` turns 16 into (16, 16).  ``OmegaConf.load`` only has to read the backbone YAML into an object with attribute
+    access and assignment (motionformer.py:124-137)."""
+    import itertools
+    import yaml
+
+    class DropPath(nn.Module):
+        def __init__(self, drop_prob: float = 0.0):
+            super().__init__()
+            self.drop_prob = drop_prob
+
+        def forward(self, x):
+            if self.drop_prob == 0.0 or not self.training:
+                return x
+            keep = 1.0 - self.drop_prob
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            return x * mask / keep
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else tuple(itertools.repeat(x, 2))
+
+    layers = types.ModuleType("timm.models.layers")
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    layers.DropPath = DropPath
+    layers.to_2tuple = to_2tuple
+    timm = _PlaceholderModule("timm"); timm.__path__ = []
+    models = _PlaceholderModule("timm.models"); models.__path__ = []
+    timm.models, models.layers = models, layers
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+
+    class _Node(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+    def _wrap(o):
+        if isinstance(o, dict):
+            return _Node({k: _wrap(v) for k, v in o.items()})
+        return [_wrap(v) for v in o] if isinstance(o, list) else o
+
+    class OmegaConf:
+        @staticmethod
+        def load(path):
+            with open(path) as f:
+                return _wrap(yaml.safe_load(f))
+
+    import omegaconf  # placeholder module
+    omegaconf.OmegaConf = OmegaConf
+
+
+def build_reference_motionformer(sd: dict):
+    """The reference's own ``MotionFormer`` in the configuration of configs/modules/feature_extractors/avclip_vggsound.yaml
+    (no checkpoint file: the class then builds the 'divided_224_16x4' backbone, motionformer.py:112-114) with a seeded
+    state dict loaded over its parameters."""
+    install()
+    _install_avclip_placeholders()
+    import models.modules.feature_extractors.avclip  # noqa: F401  (appends the avclip dir to sys.path)
+    from models.modules.feature_extractors.avclip.motionformer import MotionFormer as RefMotionFormer
+    m = RefMotionFormer(extract_features=True, ckpt_path=None, factorize_space_time=True,
+                        agg_space_module="TransformerEncoderLayer", agg_time_module="torch.nn.Identity", add_global_repr=False)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("patch_embed.proj.") for k in missing), missing      # the 2-D patch embedding is never used (:246-248)
+    return m.eval()
+
+
 _installed = False
 
 

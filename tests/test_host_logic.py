@@ -112,14 +112,32 @@ def test_pattern_metadata_matches_reference(golden, T, Tp):
         pat.build_pattern_sequence(torch.zeros(1, 9, T, dtype=torch.long), 1024)
 
 
-def test_feature_extractor_slot_rejects_non_features():
+def test_feature_extractor_plugin_surface():
+    """Row f2 plugin: the reference's class name / constructor keywords / state-dict keys; pre-extracted features pass
+    through; frames need weights and a HIP device (no CPU path); other aggregation configurations are refused."""
     from vaura_amd.feature_extractor import MotionFormer
-    fe = MotionFormer(ckpt_path=None)
+    fe = MotionFormer(extract_features=True, ckpt_path=None, factorize_space_time=True, agg_space_module="TransformerEncoderLayer",
+                      agg_time_module="torch.nn.Identity", add_global_repr=False)
+    assert type(fe).__name__ == "MotionFormer"
     x = torch.zeros(2, 4, 8, 768)
     y, g = fe(x)
     assert y is x and g is None
     with pytest.raises(ValueError):
-        fe(torch.zeros(2, 4, 3, 16, 224, 224))
+        fe(torch.zeros(2, 4, 3, 16, 224))
+    with pytest.raises(L.VauraHipError, match="no weights"):
+        fe(torch.zeros(1, 1, 3, 16, 224, 224))
+    keys = set(fe.state_dict())
+    assert {"cls_token", "pos_embed", "temp_embed", "patch_embed_3d.proj.weight", "blocks.11.timeattn.qkv.weight", "blocks.0.norm3.bias",
+            "norm.weight", "spatial_attn_agg.cls_token", "spatial_attn_agg.self_attn.in_proj_weight",
+            "spatial_attn_agg.linear2.bias"} <= keys and len(keys) == 236
+    assert fe.state_dict()["patch_embed_3d.proj.weight"].shape == (768, 3, 2, 16, 16)
+    fe.load_state_dict(synth.avclip_state_dict(seed=0), strict=True)
+    with pytest.raises(L.VauraHipError, match="HIP device only"):
+        fe(torch.zeros(1, 1, 3, 16, 224, 224))
+    with pytest.raises(L.VauraHipError):
+        MotionFormer(extract_features=True, add_global_repr=True)
+    with pytest.raises(L.VauraHipError, match="does not exist"):
+        MotionFormer(extract_features=True, ckpt_path="/nonexistent/epoch_best.pt")
 
 
 def test_shard_covers_every_clip_once():

@@ -95,3 +95,37 @@ def test_dac_encode_oracle_matches_hf_cross_check(golden):
     # preprocess pads on the right to a multiple of the hop
     assert dac_oracle.preprocess(torch.zeros(1, 1, 1000), 512).shape[-1] == 1024
     assert dac_oracle.encode(sd, wav[..., :-100], ccfg.encoder_rates).shape == (2, 9, 6)
+
+
+@pytest.mark.slow
+def test_unrounded_checkpoint_golden_first_frames(golden, full_sampler_sd_raw):
+    """The reference's run on the UN-rounded checkpoint (make_golden.py full_greedy_raw): the cached oracle reproduces its
+    recorded first-forward logits and the first 12 frames of tokens (bounded: the whole run is the GPU suite's job)."""
+    g = golden("full_greedy_raw_B2_T220.npz")
+    cfg = synth.FULL_SAMPLER
+    dec = DecoderOracle(full_sampler_sd_raw, cfg.num_layers, cfg.nhead)
+    feats = synth.video_features(2, seed=int(g["feat_seed"]))
+    trace = {}
+    tok = go.generate(dec, feats, 21, mode="cached", trace=trace)       # positions <= 12 do not depend on T
+    assert torch.equal(tok[..., :12], torch.from_numpy(g["tokens"].astype(np.int64))[..., :12])
+    for L, ref in zip(g["logits_steps"], g["logits"]):
+        if int(L) in trace["logits"] and int(L) <= 10:
+            assert (trace["logits"][int(L)] - torch.from_numpy(ref)).abs().max() < 5e-5
+
+
+@pytest.mark.slow
+def test_configs3_golden_first_frames(golden):
+    """BASELINE configs[3] golden (reference built with block_size_audio=1024, Tv=128, B=1, T=880): the cached oracle with a
+    1024-row rope table reproduces the first forwards' logits and the first 20 frames (bounded; GPU suite runs all 880)."""
+    g = golden("full_c4_greedy_B1_T880.npz")
+    cfg = synth.SamplerCfg(block_size_audio=int(g["block_size_audio"]))
+    sd = synth.sampler_state_dict(cfg, seed=int(g["weight_seed"]), round_bf16=True)
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead, block_size=1024)
+    feats = synth.video_features(1, tokens=128, seed=int(g["feat_seed"]))
+    trace = {}
+    tok = go.generate(dec, feats, 29, mode="cached", trace=trace)
+    assert torch.equal(tok[..., :20], torch.from_numpy(g["tokens"].astype(np.int64))[..., :20])
+    for L, ref in zip(g["logits_steps"], g["logits"]):
+        if int(L) in trace["logits"] and int(L) <= 10:
+            assert (trace["logits"][int(L)] - torch.from_numpy(ref)).abs().max() < 5e-5
+    assert g["tokens"].shape == (1, 9, 880) and float(g["margins"].min()) > 0

@@ -42,6 +42,9 @@ def stage_of(name):
             return "w13"
         if epi == 4:
             return "heads"
+    m = re.match(r"gemv3h_kernel<(\d+), ", name)      # row-split pair kernels: G2 = k-group pairs per wave
+    if m:
+        return "w2" if int(m.group(1)) == 8 else "wo"
     if name.startswith("sample_kernel"):
         return "sample"
     if name.startswith("embed_kernel"):

@@ -80,6 +80,31 @@ class CodecEncoder(C.Structure):
                 ("ws", C.c_void_p * 4), ("ws_elems", C.c_size_t)]
 
 
+class VitAttn(C.Structure):
+    _fields_ = [("qkv_w", C.c_void_p), ("qkv_b", C.c_void_p), ("proj_w", C.c_void_p), ("proj_b", C.c_void_p)]
+
+
+class VitBlock(C.Structure):
+    _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
+                ("ln3_w", C.c_void_p), ("ln3_b", C.c_void_p), ("space", VitAttn), ("time", VitAttn),
+                ("fc1_w", C.c_void_p), ("fc1_b", C.c_void_p), ("fc2_w", C.c_void_p), ("fc2_b", C.c_void_p)]
+
+
+class Vit(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("dim", C.c_int32), ("heads", C.c_int32), ("hidden", C.c_int32),
+                ("n_patches", C.c_int32), ("n_frames", C.c_int32),
+                ("in_chans", C.c_int32), ("frames", C.c_int32), ("img", C.c_int32), ("patch", C.c_int32), ("patch_t", C.c_int32),
+                ("patch_k", C.c_int32), ("eps", C.c_float), ("_pad", C.c_int32),
+                ("pe_w", C.c_void_p), ("pe_b", C.c_void_p), ("cls_token", C.c_void_p), ("pos_embed", C.c_void_p),
+                ("temp_embed", C.c_void_p), ("blocks_host", C.POINTER(VitBlock)), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p),
+                ("agg_cls", C.c_void_p), ("agg_ln1_w", C.c_void_p), ("agg_ln1_b", C.c_void_p), ("agg_ln2_w", C.c_void_p),
+                ("agg_ln2_b", C.c_void_p), ("agg_in_w", C.c_void_p), ("agg_in_b", C.c_void_p), ("agg_out_w", C.c_void_p),
+                ("agg_out_b", C.c_void_p), ("agg_l1_w", C.c_void_p), ("agg_l1_b", C.c_void_p), ("agg_l2_w", C.c_void_p),
+                ("agg_l2_b", C.c_void_p),
+                ("ws_x", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_a", C.c_void_p), ("ws_h", C.c_void_p), ("ws_p", C.c_void_p),
+                ("ws_z", C.c_void_p), ("ws_s", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/vaura_hip.h
 SIGNATURES = {
     "vaura_audio_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -87,6 +112,8 @@ SIGNATURES = {
     "vaura_audio_scratch_elems": (C.c_size_t, [C.c_int]),
     "vaura_dac_encode": (C.c_int, [C.POINTER(CodecEncoder), C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vaura_dac_encode_workspace_elems": (C.c_size_t, [C.POINTER(CodecEncoder), C.c_int, C.c_int64]),
+    "vaura_avclip_forward": (C.c_int, [C.POINTER(Vit), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "vaura_avclip_workspace_bytes": (C.c_size_t, [C.POINTER(Vit), C.c_int, C.c_int]),
     "vaura_version": (C.c_char_p, []),
     "vaura_set_debug_flags": (None, [C.c_uint]),
     "vaura_struct_size": (C.c_size_t, [C.c_int]),
@@ -145,7 +172,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        for which, cls in enumerate([Dims, LayerWeights, Sampling, Decoder, Conv, Codec, CodecEncoder]):
+        for which, cls in enumerate([Dims, LayerWeights, Sampling, Decoder, Conv, Codec, CodecEncoder, Vit, VitBlock]):
             if C.sizeof(cls) != handle.vaura_struct_size(which):
                 raise VauraHipError(f"{LIB_PATH} was built from a different include/vaura_hip.h: sizeof({cls.__name__}) is "
                                     f"{handle.vaura_struct_size(which)} there, {C.sizeof(cls)} here (rebuild the library)")

@@ -230,6 +230,8 @@ size_t vaura_struct_size(int which) {
     case 4: return sizeof(vaura_conv);
     case 5: return sizeof(vaura_codec);
     case 6: return sizeof(vaura_codec_encoder);
+    case 7: return sizeof(vaura_vit);
+    case 8: return sizeof(vaura_vit_block);
     default: return 0;
   }
 }

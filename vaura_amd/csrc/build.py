@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac.hip", "post.hip"]
+SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac.hip", "post.hip", "vit.hip"]
 HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", os.path.join("..", "..", "include", "vaura_hip.h")]
 LIB = os.path.join(HERE, "libvaura_hip.so")
 ARCH = "gfx950"

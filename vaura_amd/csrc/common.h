@@ -79,5 +79,7 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
                      int noise_rows_per_step, const int32_t* state, int64_t step_host, int32_t* tokens_out,
                      int32_t* seq, int T, int S, int32_t* state_rw, hipStream_t s);
 int va_launch_advance(int32_t* state, int set_to, hipStream_t s);
+int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bias, const float* res, float* out_raw,
+                          uint16_t* out_act, int act, int B, int Lin, int Lout, int oshift, int Cin, int Cout, hipStream_t s);
 int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);
 int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);

@@ -155,7 +155,10 @@ struct ConvPArgs {
   uint16_t* out_act;     // pair layout, Snake applied
   int Lin, Lout, Cin, Cout, NT;
   int off_base, off_step, ostride, oshift0, jcount;
+  int act;               // activation written to out_act: 0 Snake(alpha) (the codec), 1 exact GELU, 2 identity (row f2's linears)
 };
+
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, int C, const f32x4 v) {
   // 4 consecutive channels c0..c0+3 (c0 % 4 == 0) of one row
@@ -321,11 +324,13 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
       *reinterpret_cast<f32x4*>(a.out_raw + o + 4) = v1;
     }
     if (a.out_act) {
-      const f32x4 al0 = *reinterpret_cast<const f32x4*>(a.alpha + co), al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4);
+      f32x4 al0 = f32x4{0.f, 0.f, 0.f, 0.f}, al1 = al0;
+      if (a.act == 0) { al0 = *reinterpret_cast<const f32x4*>(a.alpha + co); al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4); }
       f16x8 hi, lo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s0 = snake_f(v0[r], al0[r]), s1 = snake_f(v1[r], al1[r]);
+        const float s0 = a.act == 0 ? snake_f(v0[r], al0[r]) : (a.act == 1 ? gelu_erf_f(v0[r]) : v0[r]);
+        const float s1 = a.act == 0 ? snake_f(v1[r], al1[r]) : (a.act == 1 ? gelu_erf_f(v1[r]) : v1[r]);
         hi[r] = (_Float16)s0; lo[r] = (_Float16)(s0 - (float)hi[r]);
         hi[r + 4] = (_Float16)s1; lo[r + 4] = (_Float16)(s1 - (float)hi[r + 4]);
       }
@@ -411,7 +416,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
     ConvPArgs p;
     p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(cv.w); p.bias = cv.bias; p.res = res;
     p.alpha = alpha; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
-    p.Lin = Lin; p.Cin = cv.cin; p.Cout = cv.cout;
+    p.Lin = Lin; p.Cin = cv.cin; p.Cout = cv.cout; p.act = 0;
     int ph = 1;
     if (cv.stride > 1) {
       if (cv.stride % 2) return VAURA_ERR_SHAPE;
@@ -449,6 +454,19 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
   return 0;
 }
 
+
+// Plain linear layer on the pair GEMM (row f2, vit.hip): out[b][row + oshift][:] = act( in[b][row][:] . W^T + bias (+ res) ).
+// in: pair layout (B, Lin, Cin); w: pair layout (Cout, Cin); out rows live in sequences of Lout rows per b.
+int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bias, const float* res, float* out_raw,
+                          uint16_t* out_act, int act, int B, int Lin, int Lout, int oshift, int Cin, int Cout, hipStream_t s) {
+  if (!in || !w || !bias || (Cin % BK) || (Cout % BN) || B <= 0 || Lin <= 0) return VAURA_ERR_SHAPE;
+  ConvPArgs p;
+  p.in = in; p.w = w; p.bias = bias; p.res = res; p.alpha = nullptr; p.out_raw = out_raw; p.out_act = out_act;
+  p.Lin = Lin; p.Lout = Lout; p.Cin = Cin; p.Cout = Cout; p.NT = 1; p.off_base = 0; p.off_step = 1; p.ostride = 1;
+  p.oshift0 = oshift; p.jcount = Lin; p.act = act;
+  VA_LAUNCH((conv_pair_kernel<3, false>), dim3((Lin + BM - 1) / BM, Cout / BN, B), dim3(256), 0, s, p);
+  return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Encode side (DacModelWrapper.encode, models/modules/dac/model.py:30-39).

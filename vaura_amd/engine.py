@@ -573,3 +573,98 @@ class CodecEncoderEngine:
         if caller is not None:
             out.record_stream(caller)
         return out
+
+
+class AvclipEngine:
+    """Segment-AVCLIP visual features on the HIP path: weights from a state dict with the reference
+    MotionFormer's key names (``synth.avclip_state_dict`` lists them), frames (B, S, 3, 16, 224, 224) -> (B, S, 8, 768)."""
+
+    def __init__(self, cfg, sd: Dict[str, torch.Tensor], device="cuda:0"):
+        _require_cuda(device)
+        self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
+        self._keep = []
+        D, Hd = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+        v = L.Vit()
+        v.depth, v.dim, v.heads, v.hidden = cfg.depth, D, cfg.num_heads, Hd
+        v.n_patches, v.n_frames = cfg.n, cfg.t
+        v.in_chans, v.frames, v.img, v.patch, v.patch_t = cfg.in_chans, cfg.frames, cfg.img, cfg.patch, cfg.patch_t
+        v.patch_k = cfg.in_chans * cfg.patch_t * cfg.patch * cfg.patch
+        v.eps = 1e-6
+        f, p = self._f32, self._pair
+        v.pe_w, v.pe_b = p(sd["patch_embed_3d.proj.weight"].reshape(D, -1)), f(sd["patch_embed_3d.proj.bias"])
+        v.cls_token, v.pos_embed, v.temp_embed = f(sd["cls_token"]), f(sd["pos_embed"]), f(sd["temp_embed"])
+        blocks = (L.VitBlock * cfg.depth)()
+        for i in range(cfg.depth):
+            b, q = blocks[i], f"blocks.{i}."
+            b.ln1_w, b.ln1_b = f(sd[q + "norm1.weight"]), f(sd[q + "norm1.bias"])
+            b.ln2_w, b.ln2_b = f(sd[q + "norm2.weight"]), f(sd[q + "norm2.bias"])
+            b.ln3_w, b.ln3_b = f(sd[q + "norm3.weight"]), f(sd[q + "norm3.bias"])
+            for att, name in ((b.space, "attn."), (b.time, "timeattn.")):
+                att.qkv_w, att.qkv_b = p(sd[q + name + "qkv.weight"]), f(sd[q + name + "qkv.bias"])
+                att.proj_w, att.proj_b = p(sd[q + name + "proj.weight"]), f(sd[q + name + "proj.bias"])
+            b.fc1_w, b.fc1_b = p(sd[q + "mlp.fc1.weight"]), f(sd[q + "mlp.fc1.bias"])
+            b.fc2_w, b.fc2_b = p(sd[q + "mlp.fc2.weight"]), f(sd[q + "mlp.fc2.bias"])
+        self._blocks = blocks
+        v.blocks_host = C.cast(blocks, C.POINTER(L.VitBlock))
+        v.norm_w, v.norm_b = f(sd["norm.weight"]), f(sd["norm.bias"])
+        a = "spatial_attn_agg."
+        v.agg_cls = f(sd[a + "cls_token"])
+        v.agg_ln1_w, v.agg_ln1_b = f(sd[a + "norm1.weight"]), f(sd[a + "norm1.bias"])
+        v.agg_ln2_w, v.agg_ln2_b = f(sd[a + "norm2.weight"]), f(sd[a + "norm2.bias"])
+        v.agg_in_w, v.agg_in_b = p(sd[a + "self_attn.in_proj_weight"]), f(sd[a + "self_attn.in_proj_bias"])
+        v.agg_out_w, v.agg_out_b = p(sd[a + "self_attn.out_proj.weight"]), f(sd[a + "self_attn.out_proj.bias"])
+        v.agg_l1_w, v.agg_l1_b = p(sd[a + "linear1.weight"]), f(sd[a + "linear1.bias"])
+        v.agg_l2_w, v.agg_l2_b = p(sd[a + "linear2.weight"]), f(sd[a + "linear2.bias"])
+        self.v = v
+        self._ws_segs = 0
+
+    def _f32(self, t) -> int:
+        d = t.detach().to(self.dev, torch.float32).contiguous()
+        self._keep.append(d)
+        return L.ptr(d)
+
+    def _pair(self, w) -> int:
+        """(Cout, Cin) fp32 -> (hi, lo) fp16 pair layout [Cout][Cin/8][plane][8] (the codec's weight layout, one tap)."""
+        w = w.detach().to(self.dev, torch.float32).contiguous()
+        cout, cin = w.shape
+        hi = w.half()
+        lo = (w - hi.float()).half()
+        pr = torch.stack([hi.reshape(cout, cin // 8, 8), lo.reshape(cout, cin // 8, 8)], dim=-2).contiguous()
+        self._keep.append(pr)
+        return L.ptr(pr)
+
+    # segments per pass: bounds the workspaces (a pass of 32 segments = 8 clips holds ~1.7 GB)
+    MAX_SEGMENTS = 32
+
+    def _workspaces(self, n_seg: int):
+        if n_seg <= self._ws_segs:
+            return
+        names = ["ws_x", "ws_qkv", "ws_a", "ws_h", "ws_p", "ws_z", "ws_s"]
+        self._ws = []
+        for i, nm in enumerate(names):
+            nbytes = self.lib.vaura_avclip_workspace_bytes(C.byref(self.v), n_seg, i)
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self._ws.append(t)
+            setattr(self.v, nm, L.ptr(t))
+        self._ws_segs = n_seg
+
+    @torch.no_grad()
+    def forward(self, frames: torch.Tensor) -> torch.Tensor:
+        """frames (B, S, 3, 16, 224, 224) on the device -> features (B, S, 8, 768) fp32."""
+        c = self.cfg
+        B, S = frames.shape[:2]
+        if tuple(frames.shape[2:]) != (c.in_chans, c.frames, c.img, c.img):
+            raise L.VauraHipError(f"AvclipEngine: segments must be ({c.in_chans}, {c.frames}, {c.img}, {c.img}), got {tuple(frames.shape[2:])}")
+        with off_null_stream(self.dev) as caller:
+            x = frames.to(self.dev, torch.float32).reshape(B * S, *frames.shape[2:]).contiguous()
+            out = torch.empty(B * S, c.t, c.embed_dim, dtype=torch.float32, device=self.dev)
+            step = min(self.MAX_SEGMENTS, B * S)
+            self._workspaces(step)
+            for s0 in range(0, B * S, step):
+                n = min(step, B * S - s0)
+                L.check(self.lib.vaura_avclip_forward(C.byref(self.v), L.ptr(x[s0:]), n, L.ptr(out[s0:]), L.current_stream(self.dev)),
+                        "vaura_avclip_forward")
+            self._frames_keepalive = x
+        if caller is not None:
+            out.record_stream(caller)
+        return out.view(B, S, c.t, c.embed_dim)

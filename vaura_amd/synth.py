@@ -249,6 +249,82 @@ def codec_encoder_state_dict(cfg: CodecCfg = FULL_CODEC, seed: int = 0) -> Dict[
     return sd
 
 
+# ----------------------------------------------------------------------------- Segment-AVCLIP extractor (row f2)
+@dataclass(frozen=True)
+class AvclipCfg:
+    """Motionformer ViT-B/16 'divided_224_16x4' + spatial aggregation layer
+    (models/modules/feature_extractors/avclip/motionformer_src/divided_224_16x4.yaml VIT section; motionformer.py:166-184)."""
+
+    depth: int = 12
+    embed_dim: int = 768
+    num_heads: int = 12
+    mlp_ratio: int = 4
+    patch: int = 16
+    patch_t: int = 2
+    frames: int = 16
+    img: int = 224
+    in_chans: int = 3
+
+    @property
+    def t(self) -> int:
+        return self.frames // self.patch_t
+
+    @property
+    def n(self) -> int:
+        return (self.img // self.patch) ** 2
+
+
+FULL_AVCLIP = AvclipCfg()
+
+
+def avclip_state_dict(cfg: AvclipCfg = FULL_AVCLIP, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """State dict with the reference MotionFormer's key names for the generation-time configuration.  NOT the reference's
+    default initialisation: DividedAttention starts at qkv = 0 / proj = 1 and the 3-D patch embedding at 0
+    (vit_helper.py:88-93, video_model_builder.py:62) — degenerate; everything here is seeded N(0, 0.02) / jittered gains."""
+    D, Hd = cfg.embed_dim, cfg.embed_dim * cfg.mlp_ratio
+    sd: Dict[str, torch.Tensor] = {}
+    sd["cls_token"] = normal("avclip.cls_token", (1, 1, D), 0.02, seed)
+    sd["pos_embed"] = normal("avclip.pos_embed", (1, cfg.n + 1, D), 0.02, seed)
+    sd["temp_embed"] = normal("avclip.temp_embed", (1, cfg.t, D), 0.02, seed)
+    sd["patch_embed_3d.proj.weight"] = normal("avclip.pe3d.w", (D, cfg.in_chans, cfg.patch_t, cfg.patch, cfg.patch), 0.02, seed)
+    sd["patch_embed_3d.proj.bias"] = normal("avclip.pe3d.b", (D,), 0.02, seed)
+
+    def lin(p, out, inp):
+        sd[p + "weight"] = normal("avclip." + p + "weight", (out, inp), 0.02, seed)
+        sd[p + "bias"] = normal("avclip." + p + "bias", (out,), 0.02, seed)
+
+    def ln(p):
+        sd[p + "weight"] = uniform("avclip." + p + "weight", (D,), 0.8, 1.2, seed)
+        sd[p + "bias"] = normal("avclip." + p + "bias", (D,), 0.02, seed)
+
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        for nm in ("norm1.", "norm2.", "norm3."):
+            ln(b + nm)
+        for att in ("attn.", "timeattn."):
+            lin(b + att + "qkv.", 3 * D, D)
+            lin(b + att + "proj.", D, D)
+        lin(b + "mlp.fc1.", Hd, D)
+        lin(b + "mlp.fc2.", D, Hd)
+    ln("norm.")
+    a = "spatial_attn_agg."
+    sd[a + "cls_token"] = normal("avclip." + a + "cls_token", (1, 1, D), 0.02, seed)
+    sd[a + "self_attn.in_proj_weight"] = normal("avclip." + a + "in_proj_weight", (3 * D, D), 0.02, seed)
+    sd[a + "self_attn.in_proj_bias"] = normal("avclip." + a + "in_proj_bias", (3 * D,), 0.02, seed)
+    lin(a + "self_attn.out_proj.", D, D)
+    lin(a + "linear1.", Hd, D)
+    lin(a + "linear2.", D, Hd)
+    ln(a + "norm1.")
+    ln(a + "norm2.")
+    return sd
+
+
+def video_frames(batch: int, segments: int = 4, cfg: AvclipCfg = FULL_AVCLIP, seed: int = 0, first_clip: int = 0) -> torch.Tensor:
+    """(B, S, 3, 16, 224, 224) N(0, 1) "normalised RGB" segments, keyed per clip index like ``video_features``."""
+    return torch.stack([normal(f"frames.{first_clip + b}", (segments, cfg.in_chans, cfg.frames, cfg.img, cfg.img), 1.0, seed)
+                        for b in range(batch)])
+
+
 def fold_weight_norm(g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """w = g * v / ||v||, norm over every dim but 0 (torch.nn.utils.weight_norm, dim=0)."""
     dims = tuple(range(1, v.dim()))
