@@ -9,6 +9,7 @@
     python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
     python tests/golden/make_golden.py post          # post-codec audio scaling (row f3)    (seconds)
     python tests/golden/make_golden.py codec_enc     # DAC encode, transformers' DacModel   (seconds)
+    python tests/golden/make_golden.py codec_full    # both at the 44.1 kHz model's FULL width (~1 min)
 
 Inputs are never stored when they can be regenerated: weights and features come from
 ``vaura_amd.synth`` (name-keyed seeds), sampling noise from ``synth.exp_noise(seed)``.
@@ -247,12 +248,13 @@ def gold_full_sample():
 
 
 # ------------------------------------------------------------------------------------- codec
-def gold_codec():
+def gold_codec(full: bool = False):
     """DAC decode golden from transformers' independent DacModel (NOT the reference's dependency:
-    structure cross-check only — see oracle/__init__.py 'parity unpinned')."""
+    structure cross-check only — see oracle/__init__.py 'parity unpinned').  full=True: the 44.1 kHz model's real
+    width (decoder 1536 -> 96 channels, 54 M parameters), where the HIP kernels take their full-size tile paths."""
     from transformers import DacConfig, DacModel
     from transformers.models.dac import modeling_dac  # noqa: F401
-    ccfg = synth.CodecCfg(decoder_dim=192, decoder_rates=(8, 8, 4, 2))
+    ccfg = synth.FULL_CODEC if full else synth.CodecCfg(decoder_dim=192, decoder_rates=(8, 8, 4, 2))
     hf = DacConfig(sampling_rate=44100, decoder_hidden_size=ccfg.decoder_dim, upsampling_ratios=list(ccfg.decoder_rates),
                    n_codebooks=9, codebook_size=1024, codebook_dim=8, hidden_size=ccfg.latent_dim)
     m = DacModel(hf).eval()
@@ -284,19 +286,24 @@ def gold_codec():
         q.codebook.weight.data.copy_(sd[p + "codebook.weight"])
         put(q.out_proj, p + "out_proj.")
     g = torch.Generator().manual_seed(21)
-    codes = torch.randint(0, 1024, (2, 9, 24), generator=g)
+    codes = torch.randint(0, 1024, (2, 9, 12 if full else 24), generator=g)
     with torch.no_grad():
         z = m.quantizer.from_codes(codes)[0]
         wav = m.decoder(z)
-    save("codec_hf.npz", codes=codes.numpy().astype(np.int16), z=z.numpy(), wav=wav.numpy(),
-         decoder_dim=np.int64(ccfg.decoder_dim), codec_seed=np.int64(1))
+    if full:   # the latent is not stored at full width (regenerable; 100 KB of waveform is the evidence)
+        save("codec_hf_full.npz", codes=codes.numpy().astype(np.int16), wav=wav.numpy(), decoder_dim=np.int64(ccfg.decoder_dim),
+             codec_seed=np.int64(1))
+    else:
+        save("codec_hf.npz", codes=codes.numpy().astype(np.int16), z=z.numpy(), wav=wav.numpy(),
+             decoder_dim=np.int64(ccfg.decoder_dim), codec_seed=np.int64(1))
 
 
-def gold_codec_enc():
-    """DAC encode cross-check with transformers' independent DacModel (reduced width: encoder 8 -> 128 = latent):
-    encoder latent + codes.  Structure check only, like gold_codec (the reference's own dependency is absent)."""
+def gold_codec_enc(full: bool = False):
+    """DAC encode cross-check with transformers' independent DacModel (reduced width: encoder 8 -> 128 = latent; full=True:
+    the real 64 -> 1024 encoder): encoder latent + codes.  Structure check only, like gold_codec (the reference's own
+    dependency is absent)."""
     from transformers import DacConfig, DacModel
-    ccfg = synth.CodecCfg(latent_dim=128, encoder_dim=8, encoder_rates=(2, 4, 8, 8), decoder_dim=192)
+    ccfg = synth.FULL_CODEC if full else synth.CodecCfg(latent_dim=128, encoder_dim=8, encoder_rates=(2, 4, 8, 8), decoder_dim=192)
     hf = DacConfig(sampling_rate=44100, encoder_hidden_size=ccfg.encoder_dim, downsampling_ratios=list(ccfg.encoder_rates),
                    decoder_hidden_size=ccfg.decoder_dim, upsampling_ratios=list(ccfg.decoder_rates),
                    n_codebooks=9, codebook_size=1024, codebook_dim=8, hidden_size=ccfg.latent_dim)
@@ -334,8 +341,8 @@ def gold_codec_enc():
     with torch.no_grad():
         z = enc(wav)
         codes = m.quantizer(z)[1]
-    save("codec_enc_hf.npz", wav=wav.numpy(), z=z.numpy(), codes=codes.numpy().astype(np.int16), codec_seed=np.int64(2),
-         encoder_dim=np.int64(ccfg.encoder_dim), latent_dim=np.int64(ccfg.latent_dim))
+    save("codec_enc_hf_full.npz" if full else "codec_enc_hf.npz", wav=wav.numpy(), z=z.numpy(), codes=codes.numpy().astype(np.int16),
+         codec_seed=np.int64(2), encoder_dim=np.int64(ccfg.encoder_dim), latent_dim=np.int64(ccfg.latent_dim))
 
 
 def gold_avclip():
@@ -413,6 +420,8 @@ if __name__ == "__main__":
         gold_full_sample()
     elif what == "codec":
         gold_codec()
+    elif what == "codec_full":
+        gold_codec(full=True); gold_codec_enc(full=True)
     elif what == "post":
         gold_post()
     elif what == "codec_enc":

@@ -25,6 +25,27 @@ def _ref(g, k):
     return torch.from_numpy(g[k].astype(np.int64))
 
 
+def assert_tokens_or_recorded_near_tie(tok, ref, margins, tol=2e-5):
+    """Greedy tokens must equal the reference's.  The one admissible exception: the FIRST differing token sits on a step where
+    the reference's own top-1 / top-2 logit margin (recorded in the golden for every step) is below `tol` — fp32 summation order
+    alone decides such an argmax (the reference's logits wobble by ~3e-6 across prefix lengths), and every later
+    token then legitimately differs.  Returns the number of identical frames."""
+    if torch.equal(tok, ref):
+        return tok.shape[-1]
+    K = tok.shape[1]
+    bad = (tok != ref)
+    steps = torch.arange(tok.shape[-1])[None, None, :] + 1 + torch.arange(K)[None, :, None]      # step that produced (k, t)
+    first_step = int(steps[bad].min())
+    at = [(b, k, t) for b, k, t in torch.nonzero(bad).tolist() if t + 1 + k == first_step]
+    for b, k, t in at:
+        m = float(margins[first_step - 1, b, k])
+        assert m < tol, f"first mismatch at step {first_step} (clip {b}, codebook {k}, frame {t}) has reference margin {m:.3e} >= {tol}"
+    before = steps < first_step
+    assert torch.equal(tok[before.expand_as(tok)], ref[before.expand_as(ref)])
+    print(f"tokens identical up to step {first_step}: recorded near-tie there (reference margin < {tol})")
+    return first_step - K
+
+
 def test_cond_projection_matches_oracle(tiny_engine, tiny_sampler_sd, golden):
     from oracle.decoder_oracle import DecoderOracle
     g = golden("tiny_model.npz")
@@ -225,7 +246,9 @@ def test_configs3_long_context_matches_reference(golden, wdtype):
     tok = eng.generate_codes(feats, 880).cpu()
     ref = _ref(g, "tokens")
     assert eng.max_len >= 896
-    assert torch.equal(tok, ref), f"token agreement {float((tok == ref).float().mean()):.4f}"
+    # the reference run holds ONE genuinely tight step (margin 5.5e-6 at step 578; the next smallest is 6.2e-5)
+    same = assert_tokens_or_recorded_near_tie(tok, ref, g["margins"])
+    assert same >= 560, same
 
 
 def test_full_size_sampled_tokens_match_reference(golden, full_sampler_sd):

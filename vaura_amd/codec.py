@@ -26,6 +26,24 @@ from .sampler import _tree
 MODEL_SR = [16000, 24000, 44000, 44100]
 
 
+class _WNConvHolder(nn.Module):
+    """Parameter holder of one weight-normed conv (``weight_g`` / ``weight_v`` / ``bias``) that also answers what the
+    REFERENCE sampler's ``initialize_embeddings`` reads from a codec's projections (llama.py:403-408): the folded
+    ``weight`` and ``in_channels`` / ``out_channels``."""
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return synth.fold_weight_norm(self.weight_g.detach().float(), self.weight_v.detach().float())
+
+    @property
+    def out_channels(self) -> int:
+        return int(self.weight_v.shape[0])
+
+    @property
+    def in_channels(self) -> int:
+        return int(self.weight_v.shape[1])
+
+
 class _Holder(nn.Module):
     """``dac.DAC``-shaped parameter tree (encoder, quantizer, decoder)."""
 
@@ -34,6 +52,9 @@ class _Holder(nn.Module):
         self.cfg = cfg
         self.sample_rate = cfg.sample_rate
         _tree(self, {k: tuple(v.shape) for k, v in sd.items()})
+        for m in self.modules():
+            if type(m) is nn.Module and "weight_g" in m._parameters and "weight_v" in m._parameters:
+                m.__class__ = _WNConvHolder
         self.load_state_dict(sd, strict=True)
 
 

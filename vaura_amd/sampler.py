@@ -58,6 +58,7 @@ class Transformer(nn.Module):
                  use_visual_conditioning: bool = True, use_delay_strategy: bool = False,
                  cond_feature_channel_scaler: int = 2, weight_dtype: str = "auto"):
         super().__init__()
+        layer_norm_eps = float(layer_norm_eps)      # PyYAML reads the reference's `layer_norm_eps: 1e-5` as a string (OmegaConf does not)
         self.cfg = SamplerCfg(num_layers=num_layers, d_model=d_model, nhead=nhead, d_codebook=d_codebook,
                               num_codebooks=num_codebooks, block_size_audio=block_size_audio,
                               block_size_video=block_size_video,
