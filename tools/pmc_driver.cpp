@@ -104,6 +104,7 @@ int main(int argc, char** argv) {
   d.ws_ffn_split = dev_zero<uint16_t>((size_t)rp * 3 * F); d.ws_ss = dev_zero<float>((size_t)(rp / 16) * (D / 16) * 16);
   d.first_norm = lw[0].attn_norm;
   d.ws_attn_part = nullptr;
+  d.ws_sync = dev_zero<uint32_t>(1025);
   vaura_sampling sp{1, 1.0f, 250, 0.0f, 6.0f, 1234ull, 0ull};
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CK(hipDeviceSynchronize());
@@ -122,9 +123,10 @@ int main(int argc, char** argv) {
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<std::vector<float>> ms(variants.size());
-    const int32_t zero[4] = {0, 0, 0, 0};
+    int32_t zero[4] = {0, 0, 0, 0};
     for (int r = -1; r < rounds; ++r)          // round -1 = warm-up
       for (size_t v = 0; v < variants.size(); ++v) {
+        zero[3] = (zero[3] + 1) & 0x7FF;       // new sequence id per loop (epochs of the in-launch hand-offs)
         CK(hipMemcpyAsync(d.state, zero, sizeof zero, hipMemcpyHostToDevice, st));
         CK(hipEventRecord(e0, st));
         const int rc = gloop(&d, &sp, 0, n, graphs[v], st);
@@ -138,6 +140,7 @@ int main(int argc, char** argv) {
     for (size_t v = 0; v < variants.size(); ++v) {
       std::sort(ms[v].begin(), ms[v].end());
       setf(variants[v]);
+      zero[3] = (zero[3] + 1) & 0x7FF;
       CK(hipMemcpy(d.state, zero, sizeof zero, hipMemcpyHostToDevice));
       double tot[8]; int64_t cnt[8];
       const int rc = prof(&d, &sp, n, 0xFF, tot, cnt, st);
@@ -148,9 +151,12 @@ int main(int argc, char** argv) {
       printf("\n");
     }
     setf(0);
-    return 0;
+    uint32_t tmo = 0;
+    CK(hipMemcpy(&tmo, d.ws_sync + 1024, 4, hipMemcpyDeviceToHost));
+    printf("hand-off timeout word: %u\n", tmo);
+    return tmo ? 5 : 0;
   }
-  const int32_t st0[4] = {pos0, 0, 0, 0};
+  const int32_t st0[4] = {pos0, 0, 0, 1};
   CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
   for (int i = 0; i < steps; ++i) {
     const int rc = step(&d, &sp, 1, st);
@@ -159,6 +165,9 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(st));
   int32_t st1[4];
   CK(hipMemcpy(st1, d.state, sizeof st1, hipMemcpyDeviceToHost));
-  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wd == VAURA_W_F32 ? "f32" : "bf16", rows, pos0, st1[0] - 1);
-  return st1[0] == pos0 + steps ? 0 : 4;
+  uint32_t tmo = 0;
+  CK(hipMemcpy(&tmo, d.ws_sync + 1024, 4, hipMemcpyDeviceToHost));
+  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d, hand-off timeout word %u\n", steps, wd == VAURA_W_F32 ? "f32" : "bf16",
+         rows, pos0, st1[0] - 1, tmo);
+  return st1[0] == pos0 + steps && !tmo ? 0 : 4;
 }

@@ -48,7 +48,7 @@ class Decoder(C.Structure):
                 ("ws_h", C.c_void_p), ("ws_qkv", C.c_void_p), ("ws_qkv2", C.c_void_p), ("ws_attn", C.c_void_p), ("ws_ffn", C.c_void_p),
                 ("ws_logits", C.c_void_p),
                 ("ws_h_split", C.c_void_p), ("ws_attn_split", C.c_void_p), ("ws_ffn_split", C.c_void_p),
-                ("ws_ss", C.c_void_p), ("first_norm", C.c_void_p), ("ws_attn_part", C.c_void_p)]
+                ("ws_ss", C.c_void_p), ("first_norm", C.c_void_p), ("ws_attn_part", C.c_void_p), ("ws_sync", C.c_void_p)]
 
 
 class Conv(C.Structure):

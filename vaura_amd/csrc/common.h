@@ -72,6 +72,9 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
                         float* part, int n_split, hipStream_t s);
 struct Gemv3Args;
+struct MlpFusedArgs;
+bool va_mlp_fused_available();
+int va_launch_mlp_fused(const MlpFusedArgs& a, hipStream_t s);
 int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s);
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t s);

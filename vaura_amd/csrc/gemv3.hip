@@ -1,5 +1,7 @@
 // Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
 #include "gemv3_kernel.h"
+#include "mlp_fused.h"
+#include <cstdlib>
 
 template <int WT, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
@@ -10,12 +12,13 @@ static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
 
 // measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split)
 unsigned va_debug_flags = 0;
+unsigned va_debug_flags_get() { return va_debug_flags; }
 
-template <int WT, int G2, int EPI, int XB>
+template <int WT, int G2, int EPI, int XB, int NBF = 2>
 static int launch3h(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   const int halves = (a.R == 1 && a.rows <= 8) ? 1 : 2;    // at most 8 live rows: the second half would multiply zeros
   if (halves == 2 && (n_tiles % 8)) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((gemv3h_kernel<G2, 8, EPI, XB, WT>), dim3((unsigned)(n_tiles * halves)), dim3(512), 0, s, a.W, a.XP, a, halves);
+  VA_LAUNCH((gemv3h_kernel<G2, 8, EPI, XB, WT, NBF>), dim3((unsigned)(n_tiles * halves)), dim3(512), 0, s, a.W, a.XP, a, halves);
   return 0;
 }
 
@@ -28,6 +31,8 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
     if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
       if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1>(a, tiles, s);
       if (K == 1536 && epilogue == E3_STORE) return launch3h<WT, 3, E3_STORE, 1>(a, tiles, s);
+      // fp32 weights at K = 4096: four batches of two k-group pairs, two in flight.  (Three in flight measured the same 11.4 us:
+      // this instance is bound by the bytes through each CU — 262 KB of weights + 196 KB of planes per workgroup — not by latency.)
       if (K == 4096 && epilogue == E3_RESID) return launch3h<WT, 8, E3_RESID, (WT == 2 ? 4 : 1)>(a, tiles, s);
       if (K == 4096 && epilogue == E3_STORE) return launch3h<WT, 8, E3_STORE, (WT == 2 ? 4 : 1)>(a, tiles, s);
     }
@@ -166,6 +171,28 @@ __global__ void split_rows_kernel(const float* __restrict__ src, uint16_t* __res
   }
   if (gain) v *= *reinterpret_cast<const f32x4*>(gain + cq * 4);
   store_split4(dst, row, cq * 4, C, v);
+}
+
+// ---------------------------------------------------------------------------- fused MLP (mlp_fused.h)
+// EXPERIMENT, off by default: measured no faster than the two launches it replaces (profiles/r02_ab_fused_mlp.txt).  Enabled by
+// VAURA_FUSED_MLP=1 (read once) or debug flag bit 2.  Usable only when every workgroup of the 256-wide grid is resident at once:
+// the device must have exactly that many CUs and the decode loop must be the only spinning kernel on it (one decode loop per GPU).
+bool va_mlp_fused_available() {
+  static int cus = -1, env_on = 0;
+  if (cus < 0) {
+    int dev = 0;
+    const char* on = getenv("VAURA_FUSED_MLP");
+    env_on = on && on[0] == '1';
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+  }
+  return cus == 256 && (env_on || (va_debug_flags & 4u));
+}
+
+int va_launch_mlp_fused(const MlpFusedArgs& a, hipStream_t s) {
+  if (!a.W13 || !a.XP || !a.ss_in || !a.ffnp || !a.W2 || !a.res || !a.out || !a.flags || !a.tmo || !a.state) return VAURA_ERR_ARG;
+  if (a.rows <= 0 || a.rows > 16 || a.n_ss_in != 96) return VAURA_ERR_SHAPE;
+  VA_LAUNCH((mlp_fused_kernel<0>), dim3(256), dim3(512), 0, s, a.W13, a.XP, a);
+  return 0;
 }
 
 extern "C" {

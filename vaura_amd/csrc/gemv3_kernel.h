@@ -423,7 +423,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
 // waves.  Every load instruction still moves 64 x 16 B in 128-byte runs.  Weight bytes per workgroup are unchanged (the two
 // workgroups of a tile read the same tiles: ids b and b + 8, i.e. the same XCD's L2 under round-robin placement — speed only).
 // G2 = k-group pairs per wave, XB = batches (weights and planes together, two in flight), WT = 0 bf16 | 2 fp32 weights.
-template <int G2, int NW, int EPI, int XB = 1, int WT = 0>
+template <int G2, int NW, int EPI, int XB = 1, int WT = 0, int NBF = 2>
 __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a, int halves) {
   a.W = Wq;
   a.XP = XPq;
@@ -436,7 +436,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   constexpr int KG = K / 32;
   constexpr int GB = G2 / XB;
   static_assert(G2 % XB == 0, "batches must divide the pairs");
-  constexpr int NB = XB > 1 ? 2 : 1;          // batches in flight
+  constexpr int NB = XB > 1 ? NBF : 1;        // batches in flight (buffers)
+  static_assert(NBF >= 2 && NBF <= XB + 1, "two or three batches in flight");
   constexpr int BS = 1024 * WH;               // bytes of one (tile, k-group) block
   __shared__ f32x4 red[NW][2][64];
 
@@ -479,6 +480,10 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
     if (rb == 0 || XB > 1) load_w(0);
     __builtin_amdgcn_sched_barrier(0);
     load_x(rb, 0);
+    if constexpr (XB > 1 && NB > 2) {       // a third batch in flight from the start
+#pragma unroll
+      for (int b = 1; b < NB - 1; ++b) { load_w(b); load_x(rb, b); }
+    }
     EpiPre pre;
     pre.have = false;
     if (wid == 0 && ((lane >> 3) & 1) == h) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile, lane);
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
-      if (b + 1 < XB) { load_w(b + 1); load_x(rb, b + 1); }
+      if (b + NB - 1 < XB) { load_w(b + NB - 1); load_x(rb, b + NB - 1); }
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
 #pragma unroll

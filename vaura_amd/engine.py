@@ -86,6 +86,8 @@ def _require_cuda(dev: torch.device):
 
 
 class DecoderEngine:
+    _sequence_id = 0
+
     def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
                  f32_kernels: str = "planes"):
         """wdtype: storage of the streamed matrices — "auto" (bf16 iff lossless for this checkpoint, else f32; see
@@ -203,6 +205,7 @@ class DecoderEngine:
             self.ws_ffn_split = torch.zeros(rp * 3 * c.ffn_dim, **i16)
             self.ws_ss = torch.zeros((rp // 16) * (c.d_model // 16) * 16, **f32)
             self.ws_attn_part = torch.zeros(rows * c.nhead * 8 * (c.d_model // c.nhead + 8), **f32)
+            self.ws_sync = torch.zeros(1025, dtype=torch.int32, device=self.dev)     # fused-MLP hand-off flags + timeout word
             crp = self._rows_padded(rows * n_cond_tokens)
             self.cond_in = torch.zeros(crp * c.cond_in, **f32)
             self.cond_tmp = torch.zeros(crp * c.cond_dim, **f32)
@@ -231,6 +234,7 @@ class DecoderEngine:
             d.ws_h_split = d.ws_attn_split = d.ws_ffn_split = d.ws_ss = 0
         d.first_norm = self.layers[0].attn_norm
         d.ws_attn_part = L.ptr(self.ws_attn_part)
+        d.ws_sync = L.ptr(self.ws_sync) if self.planes else 0
         self.dec = d
         self._shape = key
         self._graph_key = None
@@ -284,7 +288,7 @@ class DecoderEngine:
             self.codes_i32[..., :Tp] = prompt.to(self.dev, torch.int32)
         L.check(self.lib.vaura_pattern_build(L.ptr(self.codes_i32), L.ptr(self.seq), self.batch, K, T,
                                              self.cfg.d_codebook, L.current_stream(self.dev)), "vaura_pattern_build")
-        self.state.zero_()
+        self._reset_state()
         return Tp
 
     def run(self, n_prefill: int, n_steps: int, sp: L.Sampling, noise: Optional[torch.Tensor] = None,
@@ -319,6 +323,21 @@ class DecoderEngine:
             self._free_graph()
         except Exception:
             pass
+
+    def _reset_state(self):
+        """position / arrivals / step back to 0 and a NEW sequence id in state[3]: the epochs of the in-launch hand-offs
+        (mlp_fused.h) are derived from (sequence id, position, layer) and must never repeat on live flag words."""
+        DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x7FF
+        self.state.copy_(torch.tensor([0, 0, 0, DecoderEngine._sequence_id], dtype=torch.int32), non_blocking=False)
+
+    def check_sync_timeouts(self):
+        """Raise if a fused launch gave up waiting for its peers (bounded spin: it never hangs, but that step's numbers are
+        wrong).  Only the experimental fused MLP launch (VAURA_FUSED_MLP=1) spins; it times out when its 256 workgroups were not
+        resident together — e.g. a second decode loop on the same GPU.  Synchronises (reads one device word)."""
+        if getattr(self, "ws_sync", None) is not None and int(self.ws_sync[1024].item()) != 0:
+            self.ws_sync[1024] = 0
+            raise L.VauraHipError("a fused decode launch timed out waiting for its peer workgroups (another spinning kernel on this "
+                                  "GPU?): results are invalid; unset VAURA_FUSED_MLP when GPUs are shared")
 
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T
@@ -358,7 +377,7 @@ class DecoderEngine:
         self.set_condition(feats)
         self.seq.zero_()
         self.seq[:, :, :Lq] = idx.to(self.dev, torch.int32)
-        self.state.zero_()
+        self._reset_state()
         out = torch.empty(Bs, K, Lq, self.cfg.d_codebook, dtype=torch.float32, device=self.dev)
         sp = self._sampling(False, 1.0, 0, 0.0, 1.0, 0, 0)
         st = L.current_stream(self.dev)

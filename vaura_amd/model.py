@@ -142,6 +142,7 @@ class VAURAModel(nn.Module):
         # the reference's post-conditions (:550-572), checked once on the finished tensor
         bad = (codes < 0) | (codes > self.sampler.d_codebook)
         assert not bool(bad.any()), "generated sequence is incomplete or out of range"
+        eng.check_sync_timeouts()
         return codes[..., (Tp if remove_prompts else 0):max_new_tokens]
 
     @torch.no_grad()
