@@ -354,7 +354,8 @@ def test_pattern_round_trip_full_size():
 def test_sampler_randomised_against_oracle():
     """40 random (logit scale, temperature, top-k / top-p / plain, CFG on/off, batch) settings with recorded Exp(1)
     noise: the kernel's tokens against the oracle's (which is pinned to the reference's sample_top_k / sample_top_p /
-    multinomial by sampling.npz).  Random floats hold no exact ties, so top-p is compared in full."""
+    multinomial by sampling.npz).  Random floats hold no exact ties, so top-p is compared in full.  The bar is EQUALITY; a
+    differing draw must come with a proof (in fp64) that it sits on a near-tie."""
     from oracle import sampling_oracle as so
     rng = np.random.default_rng(7)
     bad = 0
@@ -375,12 +376,28 @@ def test_sampler_randomised_against_oracle():
         ref = so.next_token(mixed, use_sampling=True, temp=temp, top_k=top_k, top_p=top_p, noise=noise)
         got = ops.sample(logits.to(DEV), B, use_sampling=True, temp=temp, top_k=top_k, top_p=top_p, cfg_scale=cfg_scale,
                          noise=noise.to(DEV)).cpu()
-        bad += int((got != ref).sum())
         total += got.numel()
         assert got.shape == ref.shape == (B, 9, 1)
-    # softmax / renormalisation differ from torch by an ulp here and there (different exp / reduction order); a draw can
-    # flip only when two candidates' p/q ratios are within that ulp: allow at most one such flip in ~1000 draws
-    assert bad <= 1, f"{bad} of {total} draws differ from the oracle"
+        # Equality is the bar.  A differing draw is admitted only with a PROOF that fp32 rounding alone decides it: in fp64, either
+        # the two tokens' p/q ratios tie to 1e-5 relative (the argmax of the draw), or one of them sits within 1e-5 relative of
+        # the top-k threshold / the top-p cut (membership of the kept set).  Anything else fails.
+        for b, k, _ in torch.nonzero(got != ref).tolist():
+            bad += 1
+            p64 = torch.softmax(mixed[b, k].double() / temp, -1)
+            q64 = noise.reshape(B, 9, 1024)[b, k].double()
+            tg, tr = int(got[b, k, 0]), int(ref[b, k, 0])
+            rg, rr = float(p64[tg] / q64[tg]), float(p64[tr] / q64[tr])
+            near = abs(rg - rr) <= 1e-5 * max(rg, rr)
+            if top_p > 0.0:
+                ps, _ = torch.sort(p64, descending=True)
+                cut = torch.cumsum(ps, 0) - ps
+                near |= bool(((cut - top_p).abs() <= 1e-5).any())
+            elif top_k > 0:
+                kth = float(torch.topk(p64, min(top_k, 1024)).values[-1])
+                near |= min(abs(float(p64[tg]) - kth), abs(float(p64[tr]) - kth)) <= 1e-5 * kth
+            assert near, (trial, b, k, tg, tr, rg, rr)
+    print(f"sampler: {bad} of {total} draws differ from the oracle, each on a proven near-tie")
+    assert bad <= 3, f"{bad} of {total} draws differ from the oracle"
 
 
 def test_pattern_kernels_randomised_against_oracle():

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "../include/vaura_hip.h"
@@ -122,23 +123,30 @@ int main(int argc, char** argv) {
       if (rc) { fprintf(stderr, "graph build (flags %u): %d\n", variants[v], rc); return 3; }
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    std::vector<std::vector<float>> ms(variants.size());
+    std::vector<std::vector<float>> ms(variants.size()), host_ms(variants.size());
+    const bool eager = getenv("PMC_EAGER") != nullptr;     // time eager launches instead of graph replays
     int32_t zero[4] = {0, 0, 0, 0};
     for (int r = -1; r < rounds; ++r)          // round -1 = warm-up
       for (size_t v = 0; v < variants.size(); ++v) {
         zero[3] = (zero[3] + 1) & 0x7FF;       // new sequence id per loop (epochs of the in-launch hand-offs)
         CK(hipMemcpyAsync(d.state, zero, sizeof zero, hipMemcpyHostToDevice, st));
+        CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
-        const int rc = gloop(&d, &sp, 0, n, graphs[v], st);
+        const auto h0 = std::chrono::steady_clock::now();
+        if (eager) setf(variants[v]);
+        const int rc = gloop(&d, &sp, 0, n, eager ? nullptr : graphs[v], st);
+        const auto h1 = std::chrono::steady_clock::now();
         if (rc) { fprintf(stderr, "generate_loop: %d\n", rc); return 3; }
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
-        if (r >= 0) ms[v].push_back(t);
+        if (r >= 0) { ms[v].push_back(t); host_ms[v].push_back(std::chrono::duration<float, std::milli>(h1 - h0).count()); }
       }
     static const char* kinds[8] = {"embed", "qkv", "attn", "wo", "w13", "w2", "heads", "sample"};
     for (size_t v = 0; v < variants.size(); ++v) {
       std::sort(ms[v].begin(), ms[v].end());
+      std::sort(host_ms[v].begin(), host_ms[v].end());
+      printf("host enqueue of the loop (%s): median %.3f ms\n", eager ? "eager launches" : "graph replays", host_ms[v][host_ms[v].size() / 2]);
       setf(variants[v]);
       zero[3] = (zero[3] + 1) & 0x7FF;
       CK(hipMemcpy(d.state, zero, sizeof zero, hipMemcpyHostToDevice));

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
-      if (b + NB - 1 < XB) { load_w(b + NB - 1); load_x(rb, b + NB - 1); }
+      if (XB > 1 && b + NB - 1 < XB) { load_w(b + NB - 1); load_x(rb, b + NB - 1); }
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
 #pragma unroll

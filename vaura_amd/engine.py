@@ -328,7 +328,8 @@ class DecoderEngine:
         """position / arrivals / step back to 0 and a NEW sequence id in state[3]: the epochs of the in-launch hand-offs
         (mlp_fused.h) are derived from (sequence id, position, layer) and must never repeat on live flag words."""
         DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x7FF
-        self.state.copy_(torch.tensor([0, 0, 0, DecoderEngine._sequence_id], dtype=torch.int32), non_blocking=False)
+        self.state.zero_()                                   # two tiny device fills: no host-device synchronisation
+        self.state[3:4].fill_(DecoderEngine._sequence_id)
 
     def check_sync_timeouts(self):
         """Raise if a fused launch gave up waiting for its peers (bounded spin: it never hangs, but that step's numbers are
