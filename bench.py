@@ -171,15 +171,22 @@ def main():
     s_loop = torch.cuda.Stream(dev)
     s_post = torch.cuda.Stream(dev) if args.overlap else s_loop
 
+    marks = []      # (start, loop done, codec done) events of every step: the split of the TIMED steps themselves
+
     def step():
         with torch.cuda.stream(s_loop):
+            e_a = torch.cuda.Event(enable_timing=True)
+            e_a.record(s_loop)
             codes = eng.generate_codes(feats, T_FRAMES, **kw)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=True)
             done.record(s_loop)
         with torch.cuda.stream(s_post):
             s_post.wait_event(done)
             codes.record_stream(s_post)
             wav = codec.decode(codes)
+            e_c = torch.cuda.Event(enable_timing=True)
+            e_c.record(s_post)
+            marks.append((e_a, done, e_c))
             if world > 1:  # the single exchange of the job: final gather of tokens + waveform over RCCL
                 vdist.gather_clips(codes.to(torch.int32), counts)
                 vdist.gather_clips(wav, counts)
@@ -198,6 +205,9 @@ def main():
         return vdist.max_over_ranks(time.perf_counter() - t0, dev), res
 
     elapsed, (codes, wav) = timed(step)
+    main_marks = marks[-args.steps:]
+    t_loop = sum(a.elapsed_time(b) for a, b, _ in main_marks) / args.steps
+    t_codec = sum(b.elapsed_time(c) for _, b, c in main_marks) / args.steps
 
     assert codes.shape == (B, K_CB, T_FRAMES) and int(codes.min()) >= 0 and int(codes.max()) < 1024
     assert wav.shape == (B, 1, T_FRAMES * HOP) and bool(torch.isfinite(wav).all())
@@ -236,9 +246,14 @@ def main():
         assert eng.wdtype == "f32", eng.wdtype
         del sd_raw
         el32, (codes32, wav32) = timed(step)
+        t_loop32 = sum(a.elapsed_time(b) for a, b, _ in marks[-args.steps:]) / args.steps
         assert int(codes32.min()) >= 0 and int(codes32.max()) < 1024 and bool(torch.isfinite(wav32).all())
         out["value_f32_storage"] = round(tokens / el32, 1)
         out["ms_per_step_f32_storage"] = round(1e3 * el32 / args.steps, 3)
+        lb32 = decode_loop_bytes(cfg, 4, 2 * B if args.cfg_scale > 1 else B, T_FRAMES + K_CB - 1)
+        out["decode_loop_roofline_f32_storage"] = {"bound": "hbm", "achieved": round(lb32 / (t_loop32 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                   "unit": "GB/s", "frac": round(lb32 / (t_loop32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                   "bytes": lb32, "decode_loop_ms": round(t_loop32, 3)}
         out["f32_storage_checkpoint"] = ("un-rounded synthetic checkpoint (fp32 weights, not bf16-representable: real-checkpoint-shaped); "
                                          "storage chosen by weight_dtype='auto'; fp32 weights split into exact bf16 planes in registers")
         del eng
@@ -246,20 +261,10 @@ def main():
         eng = eng_main
 
     if rank == 0 and not args.no_extras:
-        # ---- split of one step + dominant-kernel roofline, measured live with HIP events
+        # ---- split of the timed steps (HIP events recorded inside them, on the streams the work ran on) + per-kernel roofline
         torch.cuda.synchronize(dev)
-        torch.cuda.set_stream(s_loop)    # same stream as the timed region; the events below are recorded on it
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.set_stream(s_loop)    # same stream as the timed region; the per-launch events below are recorded on it
         reps = max(2, args.steps)
-        e0.record()
-        for _ in range(reps):
-            cd = eng.generate_codes(feats, T_FRAMES, **kw)
-        e1.record()
-        for _ in range(reps):
-            codec.decode(cd)
-        e2.record()
-        torch.cuda.synchronize(dev)
-        t_loop, t_codec = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
         n_steps = T_FRAMES + K_CB - 1
         lb = decode_loop_bytes(cfg, wbytes, rows, n_steps)
         out["split_ms"] = {"decode_loop": round(t_loop, 3), "codec": round(t_codec, 3)}
