@@ -362,7 +362,8 @@ size_t vaura_avclip_workspace_bytes(const vaura_vit* v, int n_seg, int which);
 /* Measurement aid (tools/pmc_driver, A/B timing): selects kernel variants for launches enqueued (or graphs captured) afterwards.
  * bit 0: wo / w2 GEMVs as one workgroup per column tile instead of the row-split pair; bit 2: the MLP as ONE fused launch with an
  * in-launch hand-off (experiment, also env VAURA_FUSED_MLP=1; needs ws_sync and a 256-CU device with no other spinning kernel);
- * bit 3: that launch without its acquire fence (timing experiment only).  0 = the product configuration.                             */
+ * bit 3: that launch without its acquire fence (timing experiment only); bit 4: prefill attention as one workgroup per position
+ * instead of the MFMA kernel.  0 = the product configuration.                             */
 void vaura_set_debug_flags(unsigned flags);
 
 const char* vaura_version(void);

@@ -199,3 +199,46 @@ def test_sliding_window_caller_against_oracle_loop(model, tiny_sampler_sd):
     assert torch.equal(got["sampled_indices"].cpu(), ref)
     assert got["generated_audio"].shape == (B, 1, ref.shape[-1] * 512)
     assert bool(torch.isfinite(got["generated_audio"]).all())
+
+
+def test_reference_host_call_pattern_is_served_from_a_cache(tiny_sampler_sd, golden):
+    """The reference host re-feeds the whole prefix every step and keeps only the last position's logits
+    (models/vaura_model.py:504-506, 798-808).  The sampler plugin serves that pattern incrementally: a greedy loop written
+    exactly like the reference's (grow the prefix by one, call sampler(tgt, memory), argmax of [..., -1]) reproduces the
+    reference's tokens with ONE decode step per call; the returned (Bs, K, L, V) logits equal the uncached teacher-forced pass;
+    a call that does not extend the prefix (other clip / changed condition / shorter prefix) starts over."""
+    from vaura_amd.sampler import Transformer
+    g = golden("tiny_model.npz")
+    cfg = synth.tiny_sampler(2)
+    s = Transformer(**cfg.yaml_params())
+    s.load_state_dict(tiny_sampler_sd, strict=True)
+    s.audio_tokens_per_video_frame = 7
+    s = s.to(DEV)
+    feats = synth.video_features(2, seed=int(g["feat_seed"])).to(DEV)
+    ref = torch.from_numpy(g["greedy_T20"].astype(np.int64))              # (2, 9, 20)
+    T, K = 20, 9
+    S = T + K
+    seq = torch.full((2, K, S), -1, dtype=torch.long, device=DEV)
+    seq[:, :, 0] = 1024
+    eng = s.engine()
+    eng.cached_forward_steps = 0
+    for off in range(1, S):                                                # vaura_model.py:502: for offset in range(start, S)
+        logits, _, _ = s(tgt=seq[..., :off], memory=feats.detach().clone(), tgt_is_causal=True)
+        assert logits.shape == (2, K, off, 1024)
+        nxt = logits[:, :, -1].argmax(-1)
+        t = off - 1 - torch.arange(K, device=DEV)                          # timestep each codebook holds at this step
+        valid = (t >= 0) & (t < T)
+        seq[:, :, off] = torch.where(valid[None], nxt, torch.full_like(nxt, 1024))
+    assert eng.cached_forward_steps == S - 1                               # linear, not quadratic
+    codes = torch.stack([seq[:, k, k + 1:k + 1 + T] for k in range(K)], dim=1).cpu()
+    assert torch.equal(codes, ref)
+    # the whole (Bs, K, L, V) tensor equals the uncached pass
+    full = s.engine().logits_all_positions(seq[..., :S - 1], feats)
+    again, _, _ = s(tgt=seq[..., :S - 1], memory=feats)
+    assert float((again - full).abs().max()) < 1e-5
+    # a prefix that does not extend the cache, and a changed condition, start over (and still give the right numbers)
+    eng.cached_forward_steps = 0
+    short, _, _ = s(tgt=seq[..., :5], memory=feats)
+    assert eng.cached_forward_steps == 5 and float((short - full[:, :, :5]).abs().max()) < 1e-5
+    other, _, _ = s(tgt=seq[..., :6], memory=feats * 1.5)
+    assert eng.cached_forward_steps == 11 and float((other[:, :, :5] - full[:, :, :5]).abs().max()) > 1e-4

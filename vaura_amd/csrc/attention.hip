@@ -597,6 +597,140 @@ __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qk
   if (which == 2) reinterpret_cast<f32x4*>(vcache + cbase)[cq] = x;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Prefill attention on the matrix cores (round 2): a teacher-forced chunk of n positions (the prompt of the sliding-window
+// caller) attends causally over the cache.  The per-(row, head, position) workgroups of attention_step_kernel's prefill mode
+// re-read the K / V rows of a (row, head) once per query (191 us per layer for 166 positions x 16 rows); here a workgroup owns 64
+// consecutive queries of one (row, head), stages 64-key blocks of K and V in LDS once and every wave runs 16 queries through
+//     S^T (16 keys x 16 queries) = K_tile . Q^T     24 x v_mfma_f32_16x16x4_f32   (exact fp32 FMA chains, like the reference's fp32)
+//     online softmax per query (running max / sum; 4 lanes per query, two shuffles)
+//     O (16 queries x 96) += P . V_tile             24 x v_mfma_f32_16x16x4_f32
+// Operand maps are chosen so that nothing is transposed: the k index of the first product is (24 g + s) for MFMA step s and lane
+// group g (a lane reads 24 CONSECUTIVE floats of its K row: 6 ds_read_b128), and key (4 g + s) of the second product is the
+// accumulator register s the lane already holds.  q was rotated in place and k / v appended by rope_append_kernel.
+#define APF_Q 64
+#define APF_STRIDE 100      // floats per staged K / V row: 16 keys x 4-bank reads land on 64 distinct banks (36 k mod 64)
+template <int HD>
+__global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ kcache,
+                                                                const float* __restrict__ vcache, float* __restrict__ out,
+                                                                uint16_t* __restrict__ outp, int n_head, int max_len, int p0, int n_pos,
+                                                                int rows16) {
+  static_assert(HD == 96, "24 k-steps of 4");
+  constexpr int KS = HD / 4;        // 24 MFMA steps per S^T tile
+  constexpr int DT = HD / 16;       // 6 output column tiles
+  __shared__ __attribute__((aligned(16))) float Ks[64 * APF_STRIDE];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * APF_STRIDE];
+  const int h = blockIdx.x, row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int D = n_head * HD;
+  const int q0 = (int)blockIdx.z * APF_Q + wv * 16;            // first query (index in the chunk) of this wave
+  const int ql = lane & 15, g = lane >> 4;
+  const int qi = q0 + ql;                                       // this lane's query as B-operand column / softmax owner
+  const int qpos = p0 + qi;
+  const float scale = 1.0f / sqrtf((float)HD);
+  const float* kc = kcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  const float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  // Q^T operand: lane (q, g) holds Q[q][24 g + s], s = 0..23 (queries past the chunk read the last valid row; never stored)
+  float qreg[KS];
+  {
+    const int qc = min(qi, n_pos - 1);
+    const int vrow = qc * rows16 + row;
+#pragma unroll
+    for (int c = 0; c < KS / 4; ++c) {
+      const f32x4 t = reinterpret_cast<const f32x4*>(qkv)[packed_quad(vrow, (h * HD + 24 * g) / 4 + c, 3 * D)];
+      qreg[4 * c] = t[0]; qreg[4 * c + 1] = t[1]; qreg[4 * c + 2] = t[2]; qreg[4 * c + 3] = t[3];
+    }
+  }
+  f32x4 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const int last_q = p0 + min((int)blockIdx.z * APF_Q + APF_Q - 1, n_pos - 1);     // last key position any query of the block sees
+  const int wave_last = p0 + min(q0 + 15, n_pos - 1);
+  for (int kb = 0; kb <= last_q; kb += 64) {
+    __syncthreads();                                                              // previous block fully consumed
+    for (int u = tid; u < 64 * (HD / 4); u += 256) {
+      const int j = u / (HD / 4), c = u % (HD / 4);
+      const int kp = min(kb + j, last_q);
+      *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(kc + (size_t)kp * HD)[c];
+      *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(vc + (size_t)kp * HD)[c];
+    }
+    __syncthreads();
+    if (q0 < n_pos) {
+#pragma unroll 1
+      for (int t = 0; t < 4; ++t) {
+        const int key0 = kb + 16 * t;
+        if (key0 > wave_last) break;                                              // causal: no query of this wave sees the tile
+        // ---- S^T tile
+        float ak[KS];
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(Ks + (16 * t + ql) * APF_STRIDE + 24 * g + 4 * c);
+          ak[4 * c] = v4[0]; ak[4 * c + 1] = v4[1]; ak[4 * c + 2] = v4[2]; ak[4 * c + 3] = v4[3];
+        }
+        f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) st = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[s], qreg[s], st, 0, 0, 0);
+        // lane (q = ql, g) holds S[q][key0 + 4 g + r]
+        float sc[4];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = st[r];
+          sc[r] = (key0 + 4 * g + r <= qpos) ? x * scale : -INFINITY;
+          tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);                 // finite from the first tile on: key 0 is visible to every query
+        const float f = expf(m - mn);
+        float p[4], rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[r] = expf(sc[r] - mn); rs += p[r]; }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * f + rs;
+        m = mn;
+        // ---- rescale O (lane holds O[q' = 4 g + r][d]) by the factor of query q', then O += P . V
+        float fr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fr[r] = __shfl(f, 4 * g + r, 64);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[dt][r] *= fr[r];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float* vr = Vs + (16 * t + 4 * g + s) * APF_STRIDE + ql;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[s], vr[16 * dt], o[dt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();                                                                 // K / V staging is free: reuse Ks as the output stage
+  if (q0 >= n_pos) return;
+  float li[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) li[r] = 1.0f / __shfl(l, 4 * g + r, 64);
+  float* os = Ks + (size_t)wv * 16 * APF_STRIDE;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) os[(4 * g + r) * APF_STRIDE + 16 * dt + ql] = o[dt][r] * li[r];
+  // wave-local exchange through LDS (each wave reads only what it wrote): 16 queries x 24 quads -> packed + split rows
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < (16 * (HD / 4)) / 64; ++it) {
+    const int idx = lane + 64 * it, qq = idx / (HD / 4), cq = idx % (HD / 4);
+    if (q0 + qq >= n_pos) continue;
+    const f32x4 v4 = *reinterpret_cast<const f32x4*>(os + qq * APF_STRIDE + 4 * cq);
+    const int vrow = (q0 + qq) * rows16 + row;
+    reinterpret_cast<f32x4*>(out)[packed_quad(vrow, (h * HD) / 4 + cq, D)] = v4;
+    if (outp) store_split4(outp, vrow, h * HD + 4 * cq, D, v4);
+  }
+}
+
 int va_attention_splits(int rows, int n_head, int max_len) {
   if (max_len <= 256) return 1;
   const int pairs = rows * n_head;
@@ -635,10 +769,17 @@ int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, 
   return 0;
 }
 
+extern unsigned va_debug_flags;   // gemv3.hip; bit 4: the per-position prefill attention (A/B of the MFMA kernel)
 int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s) {
   const int H = d->dims.n_head, hd = d->dims.d_model / H;
   if (hd != 96) return VAURA_ERR_SHAPE;
   const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
+  if (!(va_debug_flags & 16u)) {
+    VA_LAUNCH(attention_prefill_kernel<96>, dim3(H, d->rows, (n_pos + APF_Q - 1) / APF_Q), dim3(256), 0, s, (const float*)d->ws_qkv,
+              (const float*)(d->kcache + layer * kv_layer), (const float*)(d->vcache + layer * kv_layer), d->ws_attn, d->ws_attn_split, H,
+              d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16);
+    return 0;
+  }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + d->max_len + 4);
   VA_LAUNCH(attention_step_kernel<96>, dim3(H, d->rows, n_pos), dim3(ATT_THREADS), smem, s, d->ws_qkv, (const float*)nullptr, d->rope,
             d->kcache + layer * kv_layer, d->vcache + layer * kv_layer, d->ws_attn, d->ws_attn_split, H, d->max_len, nullptr,

@@ -156,5 +156,7 @@ class Transformer(nn.Module):
         — llama.py:520-539.  The extra keywords are accepted and ignored, as in the reference."""
         if self.audio_tokens_per_video_frame is None:
             raise L.VauraHipError("audio_tokens_per_video_frame must be set (scripts/generate.py:216 sets 7)")
-        logits = self.engine().logits_all_positions(tgt, memory.float(), self.audio_tokens_per_video_frame)
+        # the reference host re-feeds the whole prefix every step (vaura_model.py:504-506); positions already seen with the same
+        # condition are served from the engine's K/V + logits cache (DecoderEngine.forward_cached)
+        logits = self.engine().forward_cached(tgt, memory.float(), self.audio_tokens_per_video_frame)
         return logits, None, None
