@@ -16,9 +16,9 @@ prompt = torch.randint(0, 1024, (8, 9, 166), generator=torch.Generator().manual_
 res = {}
 PASSES = tuple(int(x) for x in os.environ.get("VAURA_PREFILL_PASSES", "32,64,192,0").split(","))
 from vaura_amd import _lib as L
-OLD_ATTN = os.environ.get("VAURA_OLD_PREFILL_ATTN") == "1"       # A/B: one workgroup per position instead of the MFMA kernel
-L.lib().vaura_set_debug_flags(16 if OLD_ATTN else 0)
-print("prefill attention:", "per-position workgroups (old)" if OLD_ATTN else "MFMA kernel")
+FLAGS = int(os.environ.get("VAURA_DEBUG_FLAGS", "0"))    # A/B: 16 = per-position prefill attention, 32 = 64-row prefill GEMM only
+L.lib().vaura_set_debug_flags(FLAGS)
+print("debug flags:", FLAGS)
 for pp in PASSES:
     DecoderEngine.PREFILL_POSITIONS = pp if pp else 1
     eng = DecoderEngine(cfg, sd, dev, wdtype="bf16")

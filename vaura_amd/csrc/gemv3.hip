@@ -3,6 +3,11 @@
 #include "mlp_fused.h"
 #include <cstdlib>
 
+// measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split),
+// bit 5 = 64-row prefill GEMM workgroups only
+unsigned va_debug_flags = 0;
+unsigned va_debug_flags_get() { return va_debug_flags; }
+
 template <int WT, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   if (n_tiles % T) return VAURA_ERR_SHAPE;
@@ -10,9 +15,6 @@ static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   return 0;
 }
 
-// measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split)
-unsigned va_debug_flags = 0;
-unsigned va_debug_flags_get() { return va_debug_flags; }
 
 template <int WT, int G2, int EPI, int XB, int NBF = 2>
 static int launch3h(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
@@ -53,9 +55,18 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
 template <int EPI, bool NORM>
 static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
   const dim3 grid((unsigned)(tiles / (G3M_NW * G3M_T)), (unsigned)((a.R + G3M_RB - 1) / G3M_RB));
-  if (a.wq == 1) VA_LAUNCH((gemm3_kernel<EPI, NORM, 1>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
-  else if (a.wq == 2) VA_LAUNCH((gemm3_kernel<EPI, NORM, 2>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
-  else VA_LAUNCH((gemm3_kernel<EPI, NORM, 0>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  // 128-row workgroups once there are enough rows to keep the chip busy with them (a prompt of >= 64 positions x 16 rows)
+  const bool big = a.R >= 64 && !(va_debug_flags & 32u);
+  const dim3 grid8(grid.x, (unsigned)((a.R + 7) / 8));
+  if (a.wq == 1) {
+    if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 1, 8>), grid8, dim3(G3M_NW * 64), 0, s, a, (int)K);
+    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 1>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  } else if (a.wq == 2) {
+    VA_LAUNCH((gemm3_kernel<EPI, NORM, 2>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  } else {
+    if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 0, 8>), grid8, dim3(G3M_NW * 64), 0, s, a, (int)K);
+    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 0>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+  }
   return 0;
 }
 

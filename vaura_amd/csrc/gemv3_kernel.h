@@ -546,31 +546,39 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 #define G3M_RB 4
 #define G3M_T 2
 #define G3M_NW 8
-template <int EPI, bool NORM, int WT = 0>
+// RBT = row blocks per workgroup: 4 (64 rows) or 8 (128 rows: every weight tile is re-read by half as many workgroups and a
+// k-group carries twice the matrix work per barrier; bf16 / fp8 weights — the fp32-weight accumulators do not fit)
+template <int EPI, bool NORM, int WT = 0, int RBT = G3M_RB>
 __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) {
-  constexpr int RB = G3M_RB, T = G3M_T, NW = G3M_NW;
+  constexpr int RB = RBT, T = G3M_T, NW = G3M_NW;
   constexpr bool FP8 = WT == 1, F32 = WT == 2;
   constexpr int WH = F32 ? 2 : 1;
   constexpr int NACC = F32 ? 4 : 3;
   __shared__ u32x4 xs[2][RB * 3 * 64];
   __shared__ float rinv_s[RB * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rb0 = blockIdx.y * RB;
   const int tile0 = ((int)blockIdx.x * NW + wid) * T;
   const int KG = K / 32;
-  const u32x4* Wp = reinterpret_cast<const u32x4*>(a.W);
-  const u32x4* Xp = reinterpret_cast<const u32x4*>(a.XP);
-  constexpr int XL = (RB * 3 * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group (2)
+  constexpr int XL = (RB * 3 * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group
+  // buffer loads (see gemv3_kernel): SGPR descriptor + uniform offset, one VGPR offset per load; the activation descriptor
+  // ends with the last row block, so row blocks past a.R read zeros without a branch
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * 3 * (K / 8) * 256, 0x00020000);
+  int xvoff[XL];
+#pragma unroll
+  for (int i = 0; i < XL; ++i) {
+    const int idx = tid + i * NW * 64;                 // (rbi, plane, lane') with lane' = q * 16 + m
+    const int rbi = idx / 192, p = (idx / 64) % 3, l = idx & 63;
+    xvoff[i] = idx < RB * 192 ? ((rbi * 3 + p) * (K / 8) * 16 + l) * 16 : 0x7ffffff0;     // past the tile: out of range -> 0
+  }
+  const int xsoff0 = rb0 * 3 * (K / 8) * 256;
 
   u32x4 xr[XL], wr[T][WH];
   auto load_x = [&](int kg) {
 #pragma unroll
-    for (int i = 0; i < XL; ++i) {
-      const int idx = tid + i * NW * 64;                 // (rbi, plane, lane') with lane' = q * 16 + m
-      const int rbi = idx / 192, p = (idx / 64) % 3, l = idx & 63;
-      xr[i] = (idx < RB * 192 && rb0 + rbi < a.R) ? Xp[split_index16(rb0 + rbi, p, kg * 4 + (l >> 4), l & 15, K)]
-                                                  : u32x4{0u, 0u, 0u, 0u};
-    }
+    for (int i = 0; i < XL; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i], xsoff0 + kg * 1024, 0);
   };
   auto store_x = [&](int buf) {
 #pragma unroll
@@ -585,7 +593,8 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int hh = 0; hh < WH; ++hh)
-        wr[t][hh] = __builtin_nontemporal_load(Wp + ((FP8 ? (size_t)(tile0 + t) * (KG / 2) + (kg >> 1) : (size_t)(tile0 + t) * KG + kg) * WH + hh) * 64 + lane);
+        wr[t][hh] = __builtin_amdgcn_raw_buffer_load_b128(
+            wrs, lane * 16, (int)(((FP8 ? (size_t)(tile0 + t) * (KG / 2) + (kg >> 1) : (size_t)(tile0 + t) * KG + kg) * WH + hh) * 1024), 2);
   };
 
   load_x(0);
