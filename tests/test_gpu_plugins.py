@@ -48,7 +48,7 @@ def test_generate_greedy_and_cfg_like_the_reference_caller(model, golden):
     assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "greedy_T20"))
     assert r["generated_audio"].shape == (2, 1, 20 * 512) and r["s_attn_weights"] is None
     r = model.generate(frames=frames, audio=None, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
-                       prompt_is_encoded=True, cfg_scale=6.0)
+                       prompt_is_encoded=True, cfg_scale=6.0, check=True)      # check: vaura_model.py:508-515
     assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "greedy_cfg6_T20"))
 
 
@@ -71,7 +71,7 @@ def test_generate_with_prompt_and_remove_prompts(model, golden):
     frames = synth.video_features(2, seed=int(g["feat_seed"])).reshape(2, 4, 8, 768).to(DEV)
     prompt = _ref(g, "greedy_T20")[:, :, 5:13].to(DEV)
     r = model.generate(frames=frames, audio=prompt, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
-                       prompt_is_encoded=True, remove_prompts=False)
+                       prompt_is_encoded=True, remove_prompts=False, check=True)
     assert torch.equal(r["sampled_indices"].cpu(), _ref(g, "prompt8_greedy_T20"))
     r2 = model.generate(frames=frames, audio=prompt, max_new_tokens=20, return_sampled_indices=True, use_sampling=False,
                         prompt_is_encoded=True, remove_prompts=True)

@@ -115,7 +115,10 @@ class VAURAModel(nn.Module):
         decodes the concatenated tokens once, as the reference's script does (scripts/generate.py:366-369)."""
         assert not self.training, "do not use generation in training mode"
         if return_attention_weights:
-            raise NotImplementedError("attention-weight dumps are not produced by the fused decode path")
+            # the reference's own llama sampler returns (logits, None, None) (llama.py:520-539), so its generate() fails on
+            # `sa_w[-1, -1, :]` (vaura_model.py:529-531) with this flag: there is no behaviour to reproduce
+            raise NotImplementedError("attention-weight dumps are not produced by the fused decode path (nor by the reference's "
+                                      "llama sampler, which returns None for them)")
         if audio is not None and not prompt_is_encoded:
             # vaura_model.py:463-469 encodes the prompt here.  (Its unpacking `cat([encoded[0] for encoded in audio])`
             # expects EnCodec's frame list and breaks on DacModelWrapper's (B, 9, T) tensor; the tensor is used as is.)
@@ -142,6 +145,15 @@ class VAURAModel(nn.Module):
         # the reference's post-conditions (:550-572), checked once on the finished tensor
         bad = (codes < 0) | (codes > self.sampler.d_codebook)
         assert not bool(bad.any()), "generated sequence is incomplete or out of range"
+        if check:
+            # vaura_model.py:508-515 checks, every step, that the prefix is coherent with the pattern mask and holds no unknown
+            # token; the device loop fills the sequence in place, so the same two properties are checked on the finished one
+            # (they are monotone: a violation at any step is still there at the end).  :550-558 are these asserts, always on.
+            seq = eng.seq[:B].to(torch.int64)
+            _, mask = self.pattern_provider.get_pattern(max_new_tokens)._build_indexes(max_new_tokens, seq.device)
+            special = torch.full_like(seq, self.special_token_id)
+            assert not bool((seq == -1).any()), "unknown tokens left in the generated sequence"
+            assert bool((seq == torch.where(mask[None].expand_as(seq), seq, special)).all()), "sequence and pattern mask disagree"
         eng.check_sync_timeouts()
         return codes[..., (Tp if remove_prompts else 0):max_new_tokens]
 
