@@ -242,6 +242,8 @@ int vaura_attention_splits(int rows, int n_head, int max_len);
 typedef struct vaura_conv {
   const float* w;     /* conv: [taps][Cout][Cin]; transposed (stride r, k = 2r, pad r/2): [r][2][Cout][Cin] */
   const float* bias;  /* (Cout) */
+  const float* wscale;/* codec precision 3 only, else NULL: (Cout) power-of-two scale of the layer's e4m3 weights; `w` is then the
+                         packed fp8 stream [phase][step][Cout][4][32] described at vaura_codec.precision */
   int32_t cin, cout, taps, dilation, stride, _pad;
 } vaura_conv;
 
@@ -267,7 +269,16 @@ typedef struct vaura_codec {
                                           [.. Cout][Cin/8][hi|lo][8] halves instead of [.. Cout][Cin] floats;
                                        2: as 1 with single-plane weights (the caller guarantees every lo plane is zero, e.g.
                                           fp8-quantised weights: e4m3 x power-of-two scale is exact in fp16): the lo-plane
-                                          product is skipped, 2 MFMAs per product (BASELINE configs[4] codec part)        */
+                                          product is skipped, 2 MFMAs per product (BASELINE configs[4] codec part);
+                                       3: block-scaled fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE configs[4]
+                                          "fp8 MFMA ... codec conv"): activations are e4m3 with one power-of-two scale per
+                                          32 channels of a row (quantised by the producing kernel), weights e4m3 with one
+                                          power-of-two scale per output channel (`wscale`).  conv_in keeps the layout of 2
+                                          (its input comes from the quantizer); conv_out stays fp32.  Weight stream of
+                                          every other conv: per phase, input channels in super-chunks of 128 (the last may
+                                          hold nch = 1..3 blocks of 32); inside a super-chunk the k-blocks kb = tap*nch + ch
+                                          are taken four per step, so step s holds, for every output channel, 4 x 32 bytes
+                                          (kb = 4s .. 4s+3; zeros past the last k-block): [phase][step][Cout][4][32].     */
   int32_t _pad1;
 } vaura_codec;
 
@@ -275,6 +286,12 @@ typedef struct vaura_codec {
 int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, float* wav, vaura_stream_t s);
 /* floats each of the 4 workspaces must hold for (B, T) */
 size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T);
+/* Op-level access for parity tests: ONE convolution of the decoder (WNConv1d / WNConvTranspose1d of descript-audio-codec's
+ * DecoderBlock / ResidualUnit) in the arithmetic of `precision` (vaura_codec.precision; weights laid out for it).
+ * in (B, Lin, Cin) fp32 channels-last, already activated -> out (B, Lout, Cout) fp32 = conv(in) + bias,
+ * Lout = Lin * stride.  `scratch` (>= B*Lin*Cin floats) receives the input in the precision's activation format.   */
+int vaura_dac_conv(const vaura_conv* cv, int precision, const float* in, float* out, float* scratch, int B, int Lin,
+                   vaura_stream_t s);
 
 /* -------------------------------------------------------------------------------------------
  * f4 DacModelWrapper.encode (models/modules/dac/model.py:30-39): DAC encoder + residual VQ (descript-audio-codec

@@ -482,6 +482,38 @@ def test_dac_decode_fp8_weights_against_oracle_on_dequantised_checkpoint():
     assert rms_model > 1e-4        # it IS a different model
 
 
+def test_dac_decode_block_scaled_fp8_against_its_emulation():
+    """BASELINE configs[4], codec part on the fp8 matrix instruction (codec precision 3, csrc/dac.hip::conv_mx8_kernel): e4m3
+    weights (per-output-channel power-of-two scale) AND e4m3 activations (one power-of-two scale per 32 channels of a row,
+    quantised by the producing kernel).  The arithmetic of the kernel is pinned layer by layer in
+    test_gpu_ops.py::test_codec_convolution_per_precision (5e-5 of the exact result on the same quantised numbers).  End to end
+    the model is the CPU emulation — the oracle's decode of the dequantised checkpoint with every Snake output passed through
+    ``quant.mx8_effective_activation`` — but with synthetic Gaussian weights that emulation is itself discontinuous: a relative
+    perturbation of 1e-7 of its activations (fp32 sum order) moves ITS output by 4e-3 RMS and one of 2e-5 (the fp8 MFMA's
+    accumulation error) by 1.3e-2, because an e4m3 rounding flip is a 6 % step that the random network does not damp.  So the
+    end-to-end bar is: finite, and no farther from the emulation than the emulation is from the unquantised codec; both
+    distances are printed (the second is the "tol vs bf16" configs[4] asks for)."""
+    from oracle import dac_oracle
+    from vaura_amd import quant
+    ccfg = synth.FULL_CODEC
+    sd = synth.codec_state_dict(ccfg, seed=1)
+    codes = torch.randint(0, 1024, (2, 9, 12), generator=torch.Generator().manual_seed(3))
+    sd_q = quant.fp8_effective_codec_state_dict(sd)
+    emu = dac_oracle.decode(sd_q, codes, ccfg.decoder_rates, act_quant=quant.mx8_effective_activation)
+    ref = dac_oracle.decode(sd, codes, ccfg.decoder_rates)
+    got = CodecEngine(ccfg, sd, DEV, precision="mx8").decode(codes.to(DEV)).cpu()
+    rms = float(((got - emu) ** 2).mean().sqrt())
+    rms_model = float(((emu - ref) ** 2).mean().sqrt())
+    rms_ref = float(((got - ref) ** 2).mean().sqrt())
+    sig = float((ref ** 2).mean().sqrt())
+    print(f"codec mx8: rms vs its emulation {rms:.3e}; emulation vs unquantised codec {rms_model:.3e}; kernel vs unquantised codec "
+          f"{rms_ref:.3e} (signal rms {sig:.3e})")
+    assert torch.isfinite(got).all()
+    assert rms <= rms_model, (rms, rms_model)
+    assert rms_ref <= 1.5 * rms_model, (rms_ref, rms_model)      # the same model error, not a broken decode
+    assert rms_model > 1e-4
+
+
 def test_fused_mlp_launch_is_token_exact(tiny_sampler_sd):
     """The experimental one-launch MLP (csrc/mlp_fused.h: in-launch hand-off between w1|w3 and w2, debug flag bit 2; measured no
     faster than two launches, profiles/r02_ab_fused_mlp.txt) computes the same numbers: tokens identical to the product path for

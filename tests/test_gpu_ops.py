@@ -417,3 +417,53 @@ def test_pattern_kernels_randomised_against_oracle():
         rev_ref = po.revert_sequence(filled, T, -1)[0]
         rev = ops.pattern_revert(torch.from_numpy(filled).to(DEV), T, -1).cpu().numpy()
         assert np.array_equal(rev, rev_ref), (B, T, Tp)
+
+
+# ----------------------------------------------------------------------------- one codec convolution per precision
+_CONV_SHAPES = [  # (Cin, Cout, k, dilation, stride)  — the decoder's layer geometries (DAC 44.1 kHz)
+    (1536, 768, 16, 1, 8), (768, 768, 7, 9, 1), (768, 768, 1, 1, 1), (384, 384, 7, 3, 1), (384, 192, 8, 1, 4),
+    (192, 192, 7, 1, 1), (192, 192, 1, 1, 1), (192, 96, 4, 1, 2), (96, 96, 7, 9, 1), (96, 96, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("shape", _CONV_SHAPES, ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("precision", ["f16pair", "mx8"])
+def test_codec_convolution_per_precision(shape, precision):
+    """vaura_dac_conv against torch fp64 on the SAME numbers the kernel multiplies: for "mx8" the input is rounded by
+    quant.mx8_effective_activation (what the producing kernel stores) and the weight by quant.fp8_effective_weight (what the
+    packed e4m3 stream holds), so what is left is accumulation — every layer geometry of the decoder, ragged lengths, both
+    ends of the sequence (halo rows outside [0, L) are zeros).  Tolerances, relative to max |ref|: 2e-6 for the fp16-pair
+    path (fp32 accumulation order); 5e-5 for mx8 — v_mfma_scale_f32_16x16x128_f8f6f4 does not accumulate its 128 products
+    to fp32 accuracy (measured 1.5e-5 .. 2.5e-5 on every geometry, one-tap layers included; a wrong k order, scale or
+    layout gives errors of order 1)."""
+    import torch.nn.functional as F
+    from vaura_amd import quant
+    from vaura_amd.engine import CodecConvOp
+    cin, cout, k, dil, stride = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + k + dil)
+    B, Lin = 2, 150 if stride == 1 else 37
+    x = torch.randn(B, Lin, cin, generator=g) * torch.rand(B, Lin, 1, generator=g) * 3
+    bias = torch.randn(cout, generator=g) * 0.1
+    if stride > 1:
+        w = torch.randn(cin, cout, k, generator=g) / (cin * 2) ** 0.5
+        flat = lambda t: t.permute(1, 0, 2).reshape(cout, -1)
+        unflat = lambda t: t.reshape(cout, cin, k).permute(1, 0, 2)
+    else:
+        w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+        flat = lambda t: t.reshape(cout, -1)
+        unflat = lambda t: t.reshape(cout, cin, k)
+    if precision == "mx8":
+        w = unflat(quant.fp8_effective_weight(flat(w))).contiguous()
+        xe = quant.mx8_effective_activation(x)
+    else:
+        xe = x
+    xd, wd = xe.double().transpose(1, 2), w.double()
+    if stride > 1:
+        ref = F.conv_transpose1d(xd, wd, bias.double(), stride=stride, padding=(stride + 1) // 2)
+    else:
+        ref = F.conv1d(xd, wd, bias.double(), dilation=dil, padding=(k - 1) // 2 * dil)
+    ref = ref.transpose(1, 2)
+    got = CodecConvOp(w, bias, dil, stride, precision, DEV)(x.to(DEV)).cpu().double()
+    assert got.shape == ref.shape
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"codec conv {shape} {precision}: max err / max |ref| = {err:.2e}")
+    assert err <= (5e-5 if precision == "mx8" else 2e-6), err

@@ -283,3 +283,45 @@ def test_generate_loop_refuses_to_run_past_the_sequence():
     assert lib.vaura_generate_loop(C.byref(d), C.byref(sp), -1, 5, None, None) == -1
     d.max_len = 128
     assert lib.vaura_generate_loop(C.byref(d), C.byref(sp), 0, 200, None, None) == -1      # K/V rows would not exist
+
+
+def test_mx8_weight_stream_and_activation_rule():
+    """Codec precision 3 (include/vaura_hip.h): the packed e4m3 weight stream walks k as conv_mx8_kernel does — super-chunks
+    of 128 input channels, k-blocks kb = tap * nch + ch, four per step in the instruction's lane order, zeros past the end — and
+    unpacking it gives back the
+    fp8-effective weight exactly; the activation rule is idempotent, keeps |x| <= 448 * scale and is exact on zeros."""
+    from vaura_amd import quant
+    g = torch.Generator().manual_seed(5)
+    for P, NT, cout, cin in ((1, 7, 96, 96), (1, 7, 96, 192), (2, 2, 96, 384), (1, 1, 96, 96), (1, 7, 192, 1536)):
+        w = torch.randn(P, NT, cout, cin, generator=g) * 0.05
+        stream, scale = quant.mx8_pack_conv_weight(w)
+        eff = quant.fp8_effective_weight(w.permute(2, 0, 1, 3).reshape(cout, -1)).reshape(cout, P, NT, cin).permute(1, 2, 0, 3)
+        nsc = (cin + 127) // 128
+        steps = sum(((min(4, (cin - 128 * sc) // 32)) * NT + 3) // 4 for sc in range(nsc))
+        assert stream.shape == (P, steps, cout, 4, 32) and stream.dtype == torch.uint8
+        deq = stream.view(torch.float8_e4m3fn).float() * scale[None, None, :, None, None]
+        back = torch.zeros_like(w)
+        kt = 0
+        seen = 0
+        for sc in range(nsc):
+            nch = min(4, (cin - 128 * sc) // 32)
+            for st in range((nch * NT + 3) // 4):
+                for G in range(4):              # lane group G: [half G&1 of block G>>1 | half G&1 of block 2 + (G>>1)]
+                    for quad in range(2):
+                        kb = 4 * st + 2 * quad + (G >> 1)
+                        piece = slice(16 * quad, 16 * quad + 16)
+                        if kb < nch * NT:
+                            t, ch = divmod(kb, nch)
+                            c0 = 128 * sc + 32 * ch + 16 * (G & 1)
+                            back[:, t, :, c0:c0 + 16] = deq[:, kt, :, G, piece]
+                            seen += 1
+                        else:
+                            assert not bool(stream[:, kt, :, G, piece].any())
+                kt += 1
+        assert seen == NT * cin // 16 and torch.equal(back, eff)
+    x = torch.randn(50, 192, generator=g) * torch.logspace(-6, 3, 50)[:, None]
+    x[3] = 0
+    q = quant.mx8_effective_activation(x)
+    assert torch.equal(quant.mx8_effective_activation(q), q) and bool((q[3] == 0).all())
+    rel = ((q - x).abs().reshape(-1, 32).amax(1) / x.abs().reshape(-1, 32).amax(1).clamp_min(1e-30))
+    assert float(rel.max()) <= 2.0 ** -4 + 1e-6           # half an e4m3 step (3 mantissa bits) of the block maximum

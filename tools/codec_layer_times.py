@@ -8,7 +8,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 f = sorted(glob.glob(f"gpurun_out/prof_{tag}/stats/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))
-NAMES = ("conv_pair_kernel", "conv_out_kernel", "from_codes_kernel", "conv_mfma_kernel", "enc_conv_in_kernel", "rvq_stage_kernel")
+NAMES = ("conv_pair_kernel", "conv_mx8_kernel", "conv_out_kernel", "from_codes_kernel", "conv_mfma_kernel", "enc_conv_in_kernel", "rvq_stage_kernel")
 conv = [r for r in rows if any(n in r["Kernel_Name"] for n in NAMES)]
 conv.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(conv) if "from_codes" in r["Kernel_Name"]]

@@ -38,4 +38,16 @@ with torch.cuda.stream(s):
     e8[1].record()
 torch.cuda.synchronize()
 print(f"B={B}: decode with fp8-quantised conv weights (single fp16 weight plane) {e8[0].elapsed_time(e8[1]) / 5:.2f} ms")
+mx = CodecEngine(cfg, sd, dev, precision="mx8")
+with torch.cuda.stream(s):
+    wav_mx = mx.decode(codes)
+    em = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    em[0].record()
+    for _ in range(5):
+        mx.decode(codes)
+    em[1].record()
+torch.cuda.synchronize()
+d = (wav_mx - wav).float()
+print(f"B={B}: decode on the block-scaled fp8 MFMA (mx8) {em[0].elapsed_time(em[1]) / 5:.2f} ms; rms vs the f16-pair decode "
+      f"{float((d ** 2).mean().sqrt()):.3e} (signal rms {float((wav ** 2).mean().sqrt()):.3e})")
 print(f"B={B} clips of 2.56 s: decode {ev[0].elapsed_time(ev[1]) / 5:.2f} ms, encode {ev[1].elapsed_time(ev[2]) / 5:.2f} ms")

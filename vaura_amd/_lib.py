@@ -52,7 +52,7 @@ class Decoder(C.Structure):
 
 
 class Conv(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32),
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("wscale", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32),
                 ("taps", C.c_int32), ("dilation", C.c_int32), ("stride", C.c_int32), ("_pad", C.c_int32)]
 
 
@@ -147,6 +147,7 @@ SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vaura_dac_decode": (C.c_int, [C.POINTER(Codec), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vaura_dac_workspace_elems": (C.c_size_t, [C.POINTER(Codec), C.c_int, C.c_int]),
+    "vaura_dac_conv": (C.c_int, [C.POINTER(Conv), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

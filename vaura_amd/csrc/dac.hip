@@ -32,6 +32,9 @@ struct ConvArgs {
   int jcount;               // j in [0, jcount)
 };
 
+// mx8 activation buffers keep their scale words behind the e4m3 bytes of the whole (B, L, C) tensor
+__host__ __device__ __forceinline__ size_t mx8_scale_offset(size_t elems) { return (elems + 15) & ~(size_t)15; }
+
 __device__ __forceinline__ float snake_f(float v, float al) {
   const float sn = sinf(al * v);
   return v + (1.0f / (al + 1e-9f)) * (sn * sn);
@@ -156,6 +159,11 @@ struct ConvPArgs {
   int Lin, Lout, Cin, Cout, NT;
   int off_base, off_step, ostride, oshift0, jcount;
   int act;               // activation written to out_act: 0 Snake(alpha) (the codec), 1 exact GELU, 2 identity (row f2's linears)
+  // --- block-scaled fp8 ("mx8") activations (codec precision 3, conv_mx8_kernel below)
+  int act_fmt;           // out_act format: 0 (hi, lo) fp16 pairs, 1 mx8 = e4m3 bytes (B, Lout, Cout) + out_scale
+  uint8_t* out_scale;    // (B, Lout, ceil(Cout/128)) words of four E8M0 bytes: one power-of-two scale per 32 channels of a row
+  const uint32_t* in_scale;   // the same for an mx8 input
+  const float* wscale;   // (Cout) power-of-two scale of each output channel's e4m3 weights
 };
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -173,6 +181,98 @@ __device__ __forceinline__ void store_pair4(uint16_t* base, size_t row, int c0, 
   f16x4* p = reinterpret_cast<f16x4*>(base + ((row * (size_t)(C >> 3) + (size_t)(c0 >> 3)) * 2) * 8 + (c0 & 7));
   p[0] = f16x4{h[0], h[1], h[2], h[3]};
   p[2] = f16x4{l[0], l[1], l[2], l[3]};   // +8 halves = the lo plane of the same octet
+}
+
+// E8M0 byte of the smallest power of two s with amax <= 448 * s (448 = 1.75 * 2^8 = the e4m3 maximum); same rule as
+// vaura_amd/quant.py::fp8_row_scales, clamped to the bytes whose reciprocal is a normal float.
+__device__ __forceinline__ int mx8_scale_byte(float amax) {
+  const uint32_t bits = __builtin_bit_cast(uint32_t, amax);
+  const int ea = (int)((bits >> 23) & 0xffu);
+  const int e8 = ea - ((bits & 0x7fffffu) <= 0x600000u ? 8 : 7);
+  return e8 < 1 ? 1 : (e8 > 253 ? 253 : e8);
+}
+
+// One octet (8 consecutive channels co..co+7 of global row `grow`) of an activated tensor in the next layer's input format.
+// mx8: the 4 threads of a 32-channel block must be consecutive lanes, all active.
+__device__ __forceinline__ void store_act_octet(void* out_act, uint8_t* out_scale, int fmt, size_t grow, int co, int C,
+                                                const float (&sv)[8]) {
+  if (fmt == 0) {
+    f16x8 hi, lo;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { hi[r] = (_Float16)sv[r]; lo[r] = (_Float16)(sv[r] - (float)hi[r]); }
+    f16x8* dst = reinterpret_cast<f16x8*>(reinterpret_cast<uint16_t*>(out_act) + ((grow * (size_t)(C >> 3) + (size_t)(co >> 3)) * 2) * 8);
+    dst[0] = hi;
+    dst[1] = lo;
+  } else {
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) amax = fmaxf(amax, fabsf(sv[r]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    const int e8 = mx8_scale_byte(amax);
+    const float inv = __builtin_bit_cast(float, (uint32_t)(254 - e8) << 23);
+    int q0 = 0, q1 = 0;
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(sv[0] * inv, sv[1] * inv, q0, false);
+    q0 = __builtin_amdgcn_cvt_pk_fp8_f32(sv[2] * inv, sv[3] * inv, q0, true);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(sv[4] * inv, sv[5] * inv, q1, false);
+    q1 = __builtin_amdgcn_cvt_pk_fp8_f32(sv[6] * inv, sv[7] * inv, q1, true);
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<i32x2*>(reinterpret_cast<uint8_t*>(out_act) + grow * (size_t)C + co) = i32x2{q0, q1};
+    if (((co >> 3) & 3) == 0) out_scale[(grow * (size_t)((C + 127) >> 7) + (co >> 7)) * 4 + ((co >> 5) & 3)] = (uint8_t)e8;
+  }
+}
+
+// Second half of the conv epilogue, shared by the pair and the mx8 kernel: `stage` holds the BM x BN_ fp32 tile (bias
+// added), every thread owns whole octets of a row: + residual, raw store, activation, and the activated copy in the next
+// layer's input format.
+// Snake for an fp8 consumer: hardware sine (v_sin_f32, argument in revolutions) and reciprocal — absolute error ~1e-6 of a
+// value that is about to be rounded to 3 mantissa bits; the library sinf (argument reduction + polynomial, ~10x the
+// instructions) costs more than the layer's matrix instructions once those run at the fp8 rate.
+__device__ __forceinline__ float snake_fast(float v, float al) {
+  const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(al * v * 0.15915494309189535f));   // v_sin_f32's domain is +-256 revolutions
+  return v + __builtin_amdgcn_rcpf(al + 1e-9f) * (sn * sn);
+}
+
+template <int BN_, int SP, bool FAST = false>
+__device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float* stage, int b, int ph, int j0, int n0, int tid) {
+  constexpr int OCT = BN_ / 8;              // octets per tile row
+  static_assert(OCT % 4 == 0, "a 32-channel scale block = 4 consecutive threads of one row");
+  const size_t obase = (size_t)b * a.Lout;
+  for (int u = tid; u < BM * OCT; u += 256) {
+    const int row = u / OCT, oc = u - row * OCT;
+    const int jr = j0 + row;
+    if (jr >= a.jcount) continue;
+    const int orow = jr * a.ostride + a.oshift0 + ph;
+    if (orow < 0 || orow >= a.Lout) continue;
+    const int co = n0 + oc * 8;
+    const size_t o = (obase + (size_t)orow) * a.Cout + co;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8 + 4);
+    if (a.res) {
+      v0 = *reinterpret_cast<const f32x4*>(a.res + o) + v0;
+      v1 = *reinterpret_cast<const f32x4*>(a.res + o + 4) + v1;
+    }
+    if (a.out_raw) {
+      *reinterpret_cast<f32x4*>(a.out_raw + o) = v0;
+      *reinterpret_cast<f32x4*>(a.out_raw + o + 4) = v1;
+    }
+    if (a.out_act) {
+      f32x4 al0 = f32x4{0.f, 0.f, 0.f, 0.f}, al1 = al0;
+      if (a.act == 0) { al0 = *reinterpret_cast<const f32x4*>(a.alpha + co); al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4); }
+      float sv[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (FAST) {
+          sv[r] = snake_fast(v0[r], al0[r]);
+          sv[r + 4] = snake_fast(v1[r], al1[r]);
+        } else {
+          sv[r] = a.act == 0 ? snake_f(v0[r], al0[r]) : (a.act == 1 ? gelu_erf_f(v0[r]) : v0[r]);
+          sv[r + 4] = a.act == 0 ? snake_f(v1[r], al1[r]) : (a.act == 1 ? gelu_erf_f(v1[r]) : v1[r]);
+        }
+      }
+      store_act_octet(a.out_act, a.out_scale, a.act_fmt, obase + (size_t)orow, co, a.Cout, sv);
+    }
+  }
 }
 
 // Loop order: input-channel chunk (32 channels) outermost, taps inside.  The activation block of a chunk is staged in
@@ -303,42 +403,165 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
       *reinterpret_cast<f32x4*>(stage + row * SP + col) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + n0 + col);
     }
   __syncthreads();
-  constexpr int OCT = BN_ / 8;              // octets per tile row
-  const size_t obase = (size_t)b * a.Lout;
-  for (int u = tid; u < BM * OCT; u += 256) {
-    const int row = u / OCT, oc = u - row * OCT;
-    const int jr = j0 + row;
-    if (jr >= a.jcount) continue;
-    const int orow = jr * a.ostride + a.oshift0 + ph;
-    if (orow < 0 || orow >= a.Lout) continue;
-    const int co = n0 + oc * 8;
-    const size_t o = (obase + (size_t)orow) * a.Cout + co;
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8);
-    f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8 + 4);
-    if (a.res) {
-      v0 = *reinterpret_cast<const f32x4*>(a.res + o) + v0;
-      v1 = *reinterpret_cast<const f32x4*>(a.res + o + 4) + v1;
-    }
-    if (a.out_raw) {
-      *reinterpret_cast<f32x4*>(a.out_raw + o) = v0;
-      *reinterpret_cast<f32x4*>(a.out_raw + o + 4) = v1;
-    }
-    if (a.out_act) {
-      f32x4 al0 = f32x4{0.f, 0.f, 0.f, 0.f}, al1 = al0;
-      if (a.act == 0) { al0 = *reinterpret_cast<const f32x4*>(a.alpha + co); al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4); }
-      f16x8 hi, lo;
+  conv_tile_store<BN_, SP>(a, stage, b, ph, j0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-scaled fp8 variant (codec precision 3; BASELINE configs[4] "fp8 MFMA ... codec conv"): activations are e4m3 bytes
+// with one power-of-two (E8M0) scale per 32 channels of a row — written by the producer's epilogue above — weights are
+// e4m3 with one power-of-two scale per output channel, and a product is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 128 k
+// (2x the bf16 MFMA rate; the activation's block scale rides on the instruction, the weight's is applied to the
+// accumulator).  Staging geometry is the pair kernel's — 128 B per row per step, there 32 channels x (hi, lo) x 2 B, here
+// 128 channels x 1 B — so a step covers 4x the channels in 2/3 of the matrix-pipe time.
+//   k order.  A "super-chunk" is 128 input channels (the last one of a layer may hold 32/64/96: C = 96, 192); its k-blocks
+//   (32 channels of one tap) are numbered kb = tap * nch + ch and MFMA step s takes kb = 4s .. 4s+3 (one scale block of
+//   the instruction each): with nch = 4 a step is one tap (every lane the same row shift, like the pair kernel), with
+//   nch < 4 the blocks of a step come from different taps.  The weight stream is packed by the caller in the lane order
+//   of the instruction (32 bytes per lane group, see the main loop), zero where kb >= nch * taps (those lanes re-read the
+//   last valid activation block so that no NaN byte meets the zero).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int NI>
+__global__ __launch_bounds__(256, 2) void conv_mx8_kernel(ConvPArgs a) {
+  constexpr int BN_ = 32 * NI;
+  constexpr int WS_ELEMS = 2 * 8 * (BN_ + 1), XS_ELEMS = 2 * 8 * (XROWS + 1);
+  constexpr int SP = BN_ + 4;
+  static_assert((WS_ELEMS + XS_ELEMS) * 16 >= BM * SP * 4, "the output tile must fit in the main loop's LDS");
+  __shared__ u32x4 smem[WS_ELEMS + XS_ELEMS];
+  __shared__ uint32_t xsc[2][XROWS];
+  auto Ws = [&](int buf, int kq, int row) -> u32x4& { return smem[(buf * 8 + kq) * (BN_ + 1) + row]; };
+  auto Xs = [&](int buf, int kq, int row) -> u32x4& { return smem[WS_ELEMS + (buf * 8 + kq) * (XROWS + 1) + row]; };
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wn = wv & 1, wm = wv >> 1;
+  const int j0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN_;
+  const int phases = a.ostride;
+  const int b = blockIdx.z / phases, ph = blockIdx.z % phases;
+  const int cq = a.Cin / 16;                // 16-B quads per row
+  const int NT = a.NT;
+  const int nsc = (a.Cin + 127) >> 7;
+  const int nch_last = (a.Cin - 128 * (nsc - 1)) >> 5;
+  const int steps_last = (nch_last * NT + 3) >> 2;
+  const int nk = (nsc - 1) * NT + steps_last;
+  const u32x4* in = reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.Lin * cq;
+  const uint32_t* insc = a.in_scale + (size_t)b * a.Lin * nsc;
+  const u32x4* wbase = reinterpret_cast<const u32x4*>(a.w) + (size_t)ph * nk * a.Cout * 8;
+  const int span = (NT - 1) * (a.off_step < 0 ? -a.off_step : a.off_step);
+  const int lo_off = a.off_base + (a.off_step < 0 ? (NT - 1) * a.off_step : 0);
+  const int xrows = BM + span;
+  constexpr int XL = (XROWS * 8 + 255) / 256;
+
+  u32x4 wreg[NI], xreg[XL];
+  uint32_t screg = 0;
+  auto load_w = [&](int kt) {
+    const u32x4* wt = wbase + (size_t)kt * a.Cout * 8;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s0 = a.act == 0 ? snake_f(v0[r], al0[r]) : (a.act == 1 ? gelu_erf_f(v0[r]) : v0[r]);
-        const float s1 = a.act == 0 ? snake_f(v1[r], al1[r]) : (a.act == 1 ? gelu_erf_f(v1[r]) : v1[r]);
-        hi[r] = (_Float16)s0; lo[r] = (_Float16)(s0 - (float)hi[r]);
-        hi[r + 4] = (_Float16)s1; lo[r + 4] = (_Float16)(s1 - (float)hi[r + 4]);
+    for (int i = 0; i < NI; ++i) {
+      const int qd = tid + 256 * i;
+      wreg[i] = wt[(size_t)(n0 + (qd >> 3)) * 8 + (qd & 7)];
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int qd = tid + 256 * i; Ws(buf, qd & 7, qd >> 3) = wreg[i]; }
+  };
+  auto load_x = [&](int sc) {
+    const int q0 = sc * 8, nq = (sc == nsc - 1 ? nch_last : 4) * 2;
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      const int jr = j0 + lo_off + row;
+      xreg[i] = (row < xrows && kq < nq && jr >= 0 && jr < a.Lin) ? in[(size_t)jr * cq + q0 + kq] : u32x4{0u, 0u, 0u, 0u};
+    }
+    const int jr = j0 + lo_off + tid;
+    screg = (tid < xrows && jr >= 0 && jr < a.Lin) ? insc[(size_t)jr * nsc + sc] : 0u;
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int qd = tid + 256 * i;
+      if ((qd >> 3) < XROWS) Xs(buf, qd & 7, qd >> 3) = xreg[i];
+    }
+    if (tid < XROWS) xsc[buf][tid] = screg;
+  };
+
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_w(0);
+  load_x(0);
+  store_w(0);
+  store_x(0);
+  __syncthreads();
+  const int g = lane >> 4, r16 = lane & 15;
+  int kt = 0;
+  for (int sc = 0; sc < nsc; ++sc) {
+    const int xb = sc & 1;
+    const int nch = sc == nsc - 1 ? nch_last : 4;
+    const int nsteps = sc == nsc - 1 ? steps_last : NT;
+    const int nkb = nch * NT;
+    const float rnch = 1.0f / (float)nch;
+    for (int st = 0; st < nsteps; ++st, ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_w(kt + 1);
+      if (st == 0 && sc + 1 < nsc) load_x(sc + 1);
+      // operand layout of the instruction (tools/microbench/mfma_mx8_probe.hip): bytes 0..15 of lane group G are
+      // k = 16G .. 16G+15, bytes 16..31 are k = 64 + 16G ..; the scale of lane group G covers k = 32G .. 32G+31.  So the
+      // lane's first quad is half (G & 1) of k-block G >> 1, its second quad the same half of k-block 2 + (G >> 1), and
+      // its scale is k-block G's.
+      const int h = g & 1;
+      int chA = g >> 1, chB = 2 + (g >> 1), chS = g;
+      int shA = a.off_base + st * a.off_step - lo_off, shB = shA, shS = shA;
+      if (nch != 4) {
+        auto split = [&](int kb, int& ch) {
+          kb = kb < nkb ? kb : nkb - 1;
+          const int t = (int)(((float)kb + 0.5f) * rnch);     // kb / nch, exact for these small integers
+          ch = kb - t * nch;
+          return a.off_base + t * a.off_step - lo_off;
+        };
+        shA = split(4 * st + (g >> 1), chA);
+        shB = split(4 * st + 2 + (g >> 1), chB);
+        shS = split(4 * st + g, chS);
       }
-      f16x8* dst = reinterpret_cast<f16x8*>(a.out_act + (((obase + (size_t)orow) * (size_t)(a.Cout >> 3) + (size_t)(co >> 3)) * 2) * 8);
-      dst[0] = hi;
-      dst[1] = lo;
+      i32x8 wf[NI], xf[4];
+      int xs[4];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const u32x4 q0 = Ws(buf, 2 * g, wn * (NI * 16) + i * 16 + r16), q1 = Ws(buf, 2 * g + 1, wn * (NI * 16) + i * 16 + r16);
+        wf[i] = i32x8{(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wm * 64 + j * 16 + r16;
+        const u32x4 q0 = Xs(xb, 2 * chA + h, shA + row), q1 = Xs(xb, 2 * chB + h, shB + row);
+        xf[j] = i32x8{(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+        xs[j] = (int)((xsc[xb][shS + row] >> (8 * chS)) & 0xffu);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[i], xf[j], acc[i][j], 0, 0, 0, 127, 0, xs[j]);
+      if (kt + 1 < nk) store_w(buf ^ 1);
+      if (st == nsteps - 1 && sc + 1 < nsc) store_x(xb ^ 1);
+      __syncthreads();
     }
   }
+
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = wm * 64 + j * 16 + r16, col = wn * (NI * 16) + i * 16 + 4 * g;
+      *reinterpret_cast<f32x4*>(stage + row * SP + col) =
+          acc[i][j] * *reinterpret_cast<const f32x4*>(a.wscale + n0 + col) + *reinterpret_cast<const f32x4*>(a.bias + n0 + col);
+    }
+  __syncthreads();
+  conv_tile_store<BN_, SP, true>(a, stage, b, ph, j0, n0, tid);
 }
 
 // z[b][t][c] = sum_k ( W_k[c][:] . codebook_k[code] + b_k[c] )   — quantizer.from_codes
@@ -387,7 +610,17 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
     if (r < 0 || r >= L || l >= L) continue;
     for (int cq = sub; cq < C / 4; cq += 8) {
       f32x4 x;
-      if (pairs) {
+      if (pairs == 3) {          // mx8: e4m3 bytes + one E8M0 scale byte per 32 channels, scales behind the bytes
+        const uint8_t* q = reinterpret_cast<const uint8_t*>(act) + (size_t)b * L * C;
+        const uint8_t* sc = reinterpret_cast<const uint8_t*>(act) + mx8_scale_offset((size_t)gridDim.y * L * C) +
+                            (size_t)b * L * ((C + 127) >> 7) * 4;
+        const int w4 = *reinterpret_cast<const int*>(q + (size_t)r * C + 4 * cq);
+        const int e8 = sc[((size_t)r * ((C + 127) >> 7) + (cq >> 5)) * 4 + ((cq >> 3) & 3)];
+        const float scl = __builtin_bit_cast(float, (uint32_t)e8 << 23);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo2 = __builtin_amdgcn_cvt_pk_f32_fp8(w4, false), hi2 = __builtin_amdgcn_cvt_pk_f32_fp8(w4, true);
+        x = f32x4{lo2.x * scl, lo2.y * scl, hi2.x * scl, hi2.y * scl};
+      } else if (pairs) {
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         const f16x4* pp = reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(in) +
                                                           (((size_t)r * (C >> 3) + (cq >> 1)) * 2) * 8 + (cq & 1) * 4);
@@ -407,6 +640,19 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
   if (sub == 0 && l < L) wav[(size_t)b * L + l] = tanhf(d + bias[0]);
 }
 
+// fp32 (rows, C) -> the activation format of a codec precision (op-level entry vaura_dac_conv below)
+__global__ __launch_bounds__(256) void act_convert_kernel(const float* __restrict__ in, void* out, uint8_t* out_scale, size_t rows,
+                                                          int C, int fmt) {
+  const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int oct = C >> 3;
+  const size_t row = u / oct;
+  if (row >= rows) return;                      // C % 32 == 0: the 4 threads of a block leave together
+  const int co = (int)(u - row * oct) * 8;
+  const f32x4 v0 = *reinterpret_cast<const f32x4*>(in + row * C + co), v1 = *reinterpret_cast<const f32x4*>(in + row * C + co + 4);
+  const float sv[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  store_act_octet(out, out_scale, fmt, row, co, C, sv);
+}
+
 static int launch_conv(const vaura_conv& cv, const float* in, const float* res, const float* alpha, float* out_raw,
                        float* out_act, int B, int Lin, int pairs, hipStream_t s) {
   if (!cv.w || !cv.bias || (cv.cin % BK)) return VAURA_ERR_SHAPE;
@@ -417,6 +663,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
     p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(cv.w); p.bias = cv.bias; p.res = res;
     p.alpha = alpha; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
     p.Lin = Lin; p.Cin = cv.cin; p.Cout = cv.cout; p.act = 0;
+    p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
     int ph = 1;
     if (cv.stride > 1) {
       if (cv.stride % 2) return VAURA_ERR_SHAPE;
@@ -426,6 +673,20 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       p.NT = cv.taps; p.off_base = -((cv.taps - 1) / 2) * cv.dilation; p.off_step = cv.dilation;
       p.ostride = 1; p.oshift0 = 0; p.Lout = Lin; p.jcount = Lin;
       if ((cv.taps - 1) * cv.dilation > XHALO) return VAURA_ERR_SHAPE;
+    }
+    if (pairs == 3) {   // mx8 activations out; in as well when the layer's weights are mx8 (everything but conv_in)
+      if (out_act) {
+        p.act_fmt = 1;
+        p.out_scale = reinterpret_cast<uint8_t*>(out_act) + mx8_scale_offset((size_t)B * p.Lout * cv.cout);
+      }
+      if (cv.wscale) {
+        if (cv.cout % BN) return VAURA_ERR_SHAPE;
+        p.wscale = cv.wscale;
+        p.in_scale = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(in) + mx8_scale_offset((size_t)B * Lin * cv.cin));
+        VA_LAUNCH((conv_mx8_kernel<3>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+        return 0;
+      }
+      pairs = 2;        // conv_in: fp8-valued weights in one fp16 plane, pair input from the quantizer
     }
     if (cv.cout % BN == 0) {
       if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
@@ -464,6 +725,7 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
   p.in = in; p.w = w; p.bias = bias; p.res = res; p.alpha = nullptr; p.out_raw = out_raw; p.out_act = out_act;
   p.Lin = Lin; p.Lout = Lout; p.Cin = Cin; p.Cout = Cout; p.NT = 1; p.off_base = 0; p.off_step = 1; p.ostride = 1;
   p.oshift0 = oshift; p.jcount = Lin; p.act = act;
+  p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
   VA_LAUNCH((conv_pair_kernel<3, false>), dim3((Lin + BM - 1) / BM, Cout / BN, B), dim3(256), 0, s, p);
   return 0;
 }
@@ -604,11 +866,11 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   for (int i = 0; i < 4; ++i) if (!c->ws[i]) return VAURA_ERR_ARG;
   hipStream_t s = as_stream(s_);
   const int pr = c->precision;
-  if (pr != 0 && pr != 1 && pr != 2) return VAURA_ERR_DTYPE;
+  if (pr < 0 || pr > 3) return VAURA_ERR_DTYPE;
   float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
 
   VA_LAUNCH(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
-                     c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim, pr);
+                     c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim, pr ? 1 : 0);
   // conv_in: only the activated output is consumed (by the first transposed conv)
   int rc = launch_conv(c->conv_in, Y, nullptr, c->alpha_up[0], nullptr, A, B, T, pr, s);
   if (rc) return rc;
@@ -633,6 +895,22 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
   VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
   return 0;
+}
+
+int vaura_dac_conv(const vaura_conv* cv, int precision, const float* in, float* out, float* scratch, int B, int Lin,
+                   vaura_stream_t s_) {
+  if (!cv || !in || !out || !scratch || B <= 0 || Lin <= 0 || precision < 0 || precision > 3) return VAURA_ERR_ARG;
+  if (cv->cin % 32) return VAURA_ERR_SHAPE;
+  hipStream_t s = as_stream(s_);
+  const float* x = in;
+  if (precision) {
+    const bool mx = precision == 3 && cv->wscale;
+    const size_t rows = (size_t)B * Lin, n = rows * (cv->cin / 8);
+    uint8_t* sc = reinterpret_cast<uint8_t*>(scratch) + mx8_scale_offset(rows * cv->cin);
+    VA_LAUNCH(act_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, scratch, sc, rows, cv->cin, mx ? 1 : 0);
+    x = scratch;
+  }
+  return launch_conv(*cv, x, nullptr, nullptr, out, nullptr, B, Lin, precision, s);
 }
 
 size_t vaura_dac_encode_workspace_elems(const vaura_codec_encoder* c, int B, int64_t n_samples) {

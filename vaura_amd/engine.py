@@ -438,12 +438,14 @@ class CodecEngine:
         """precision: "f16pair" (default; activations/weights as (hi, lo) fp16 pairs on the fp16 MFMA, error
         ~1e-6 RMS), "f32" (exact fp32 MFMA), or "f16pair_w8" (BASELINE configs[4]: conv weights quantised to fp8 e4m3 with
         a power-of-two scale per output channel — a different model, ``quant.fp8_effective_codec_state_dict`` says which;
-        such weights are exact in one fp16 plane, so a product costs two MFMAs instead of three)."""
+        such weights are exact in one fp16 plane, so a product costs two MFMAs instead of three), or "mx8" (configs[4] on the
+        fp8 matrix instruction: those fp8 weights AND e4m3 activations with one power-of-two scale per 32 channels of a row,
+        ``quant.mx8_effective_activation``; one block-scaled MFMA per 128 products — tolerance reported, not 1e-4)."""
         _require_cuda(device)
         self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
         self._keep = []
-        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2}[precision]
-        if self.pairs == 2:
+        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2, "mx8": 3}[precision]
+        if self.pairs >= 2:
             from .quant import fp8_effective_codec_state_dict
             sd = fp8_effective_codec_state_dict(sd)
         c = L.Codec()
@@ -460,7 +462,7 @@ class CodecEngine:
         c.codebooks = L.ptr(self._dev(torch.stack([sd[f"quantizer.quantizers.{k}.codebook.weight"].float() for k in range(K)])))
         c.out_proj_w = L.ptr(self._dev(torch.stack([f(f"quantizer.quantizers.{k}.out_proj.")[:, :, 0] for k in range(K)])))
         c.out_proj_b = L.ptr(self._dev(torch.stack([sd[f"quantizer.quantizers.{k}.out_proj.bias"].float() for k in range(K)])))
-        self._conv(c.conv_in, sd, "decoder.model.0.", 1, 1)
+        self._conv(c.conv_in, sd, "decoder.model.0.", 1, 1, mx8=False)
         for b, r in enumerate(cfg.decoder_rates):
             p = f"decoder.model.{b + 1}.block."
             c.alpha_up[b] = L.ptr(self._dev(sd[p + "0.alpha"].reshape(-1)))
@@ -482,8 +484,12 @@ class CodecEngine:
         self._keep.append(d)
         return d
 
-    def _conv(self, cv: L.Conv, sd, prefix: str, dilation: int, stride: int):
+    def _conv(self, cv: L.Conv, sd, prefix: str, dilation: int, stride: int, mx8: bool = True):
         w = fold_weight_norm(sd[prefix + "weight_g"].float(), sd[prefix + "weight_v"].float())
+        self._pack_conv(cv, w, sd[prefix + "bias"], dilation, stride, mx8)
+
+    def _pack_conv(self, cv: L.Conv, w: torch.Tensor, bias: torch.Tensor, dilation: int, stride: int, mx8: bool = True):
+        """Folded Conv1d (Cout, Cin, k) / ConvTranspose1d (Cin, Cout, 2r) weight -> the layout of self.pairs (= vaura_codec.precision)."""
         if stride > 1:   # ConvTranspose1d weight (Cin, Cout, 2r) -> [phase][tap][Cout][Cin]
             cin, cout, k = w.shape
             assert k == 2 * stride
@@ -493,7 +499,14 @@ class CodecEngine:
             cout, cin, k = w.shape
             wl = w.permute(2, 0, 1)
             taps = k
-        if self.pairs and cout > 1:   # (hi, lo) fp16 pair layout [.., Cout][Cin/8][plane][8]
+        if self.pairs == 3 and mx8 and cout > 1:   # packed e4m3 stream + per-output-channel scales (quant.mx8_pack_conv_weight)
+            from .quant import mx8_pack_conv_weight
+            wp = wl.reshape(stride, 2, cout, cin) if stride > 1 else wl.reshape(1, taps, cout, cin)
+            stream, scale = mx8_pack_conv_weight(wp.contiguous().to(self.dev))
+            self._keep.append(stream)
+            cv.w = L.ptr(stream)
+            cv.wscale = L.ptr(self._dev(scale))
+        elif self.pairs and cout > 1:   # (hi, lo) fp16 pair layout [.., Cout][Cin/8][plane][8]
             wl = wl.contiguous()
             hi = wl.half()
             lo = (wl - hi.float()).half()
@@ -503,7 +516,7 @@ class CodecEngine:
             cv.w = L.ptr(keep)
         else:
             cv.w = L.ptr(self._dev(wl))
-        cv.bias = L.ptr(self._dev(sd[prefix + "bias"]))
+        cv.bias = L.ptr(self._dev(bias))
         cv.cin, cv.cout, cv.taps, cv.dilation, cv.stride = cin, cout, taps, dilation, stride
 
     @torch.no_grad()
@@ -526,6 +539,39 @@ class CodecEngine:
         if caller is not None:
             wav.record_stream(caller)
         return wav
+
+
+class CodecConvOp:
+    """ONE decoder convolution through ``vaura_dac_conv`` (op-level parity tests): folded Conv1d (Cout, Cin, k) or
+    ConvTranspose1d (Cin, Cout, 2r; stride r) weight, in the arithmetic of a codec ``precision``.  For "f16pair_w8" / "mx8" the
+    caller passes weights that are already fp8-representable (``quant.fp8_effective_weight``)."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, dilation: int = 1, stride: int = 1, precision: str = "f16pair",
+                 device="cuda:0", mx8_weights: bool = True):
+        _require_cuda(device)
+        self.dev, self.lib, self._keep = torch.device(device), L.lib(), []
+        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2, "mx8": 3}[precision]
+        self.cv = L.Conv()
+        CodecEngine._pack_conv(self, self.cv, weight.float(), bias.float(), dilation, stride, mx8_weights)
+        self.stride = stride
+
+    _dev = CodecEngine._dev
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B, L, Cin) fp32, channels last, already activated -> (B, L * stride, Cout) fp32 = conv(x) + bias."""
+        B, Lin, cin = x.shape
+        assert cin == self.cv.cin
+        with off_null_stream(self.dev) as caller:
+            xi = x.to(self.dev, torch.float32).contiguous()
+            out = torch.empty(B, Lin * self.stride, self.cv.cout, dtype=torch.float32, device=self.dev)
+            scratch = torch.empty(B * Lin * cin + 64, dtype=torch.float32, device=self.dev)
+            L.check(self.lib.vaura_dac_conv(C.byref(self.cv), self.pairs, L.ptr(xi), L.ptr(out), L.ptr(scratch), B, Lin,
+                                            L.current_stream(self.dev)), "vaura_dac_conv")
+            self._keepalive = (xi, scratch)
+        if caller is not None:
+            out.record_stream(caller)
+        return out
 
 
 class CodecEncoderEngine:

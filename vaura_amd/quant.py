@@ -72,3 +72,48 @@ def fp8_effective_codec_state_dict(sd: dict) -> dict:
         out[k] = we
         out[p + "weight_g"] = we.norm(2, dim=tuple(range(1, we.dim())), keepdim=True)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Block-scaled fp8 ("mx8") codec convolutions — codec precision 3 (include/vaura_hip.h, csrc/dac.hip::conv_mx8_kernel)
+
+def mx8_effective_activation(x: torch.Tensor) -> torch.Tensor:
+    """What an mx8 consumer sees of an activation tensor (..., C), C % 32 == 0: every block of 32 channels of a row is
+    rounded to e4m3 under its own power-of-two scale (the same smallest-power-of-two rule as the weights)."""
+    shp = x.shape
+    blk = x.detach().float().reshape(-1, 32)
+    amax = blk.abs().amax(dim=1)
+    m, e = torch.frexp(amax)
+    exp = torch.where(m <= 0.875, e - 9, e - 8).clamp(min=-126, max=126)     # the kernel clamps the E8M0 byte to [1, 253]
+    s = torch.ldexp(torch.ones_like(amax), exp)[:, None]
+    return ((blk / s).to(torch.float8_e4m3fn).float() * s).reshape(shp)
+
+
+def mx8_pack_conv_weight(wl: torch.Tensor):
+    """(P, NT, Cout, Cin) fp32 taps of one conv (P output phases; 1 for a plain conv) -> (uint8 stream
+    [P][steps][Cout][4][32], (Cout) fp32 power-of-two scales) in the k order conv_mx8_kernel walks: input channels in
+    super-chunks of 128 (the last holds nch = Cin%128/32 blocks if that is not zero), k-blocks kb = tap*nch + ch, four
+    per step; inside a step the 32 bytes of lane group G are [half G&1 of block G>>1 | half G&1 of block 2 + (G>>1)] —
+    the operand layout of v_mfma_scale_f32_16x16x128_f8f6f4 (bytes 0..15 of group G: k = 16G.., bytes 16..31: k = 64+16G..;
+    measured by tools/microbench/mfma_mx8_probe.hip).  The scale is per output channel over (phases x taps x Cin) — fp8_row_scales' rule — so a weight that
+    fp8_effective_weight already rounded is represented exactly."""
+    P, NT, cout, cin = wl.shape
+    assert cin % 32 == 0
+    flat = wl.permute(2, 0, 1, 3).reshape(cout, -1)
+    scale = fp8_row_scales(flat)
+    q = (wl / scale[None, None, :, None]).to(torch.float8_e4m3fn).view(torch.uint8)      # (P, NT, Cout, Cin)
+    nsc = (cin + 127) // 128
+    steps = []
+    for sc in range(nsc):
+        nch = min(4, (cin - 128 * sc) // 32)
+        for st in range((nch * NT + 3) // 4):
+            blk = torch.zeros(P, cout, 4, 32, dtype=torch.uint8, device=wl.device)
+            for kbl in range(4):
+                kb = 4 * st + kbl
+                if kb < nch * NT:
+                    t, ch = divmod(kb, nch)
+                    c0 = 128 * sc + 32 * ch
+                    for h in range(2):           # 16-channel half h of the block -> lane group 2*(kbl%2)+h, quad kbl//2
+                        blk[:, :, 2 * (kbl % 2) + h, 16 * (kbl // 2):16 * (kbl // 2) + 16] = q[:, t, :, c0 + 16 * h:c0 + 16 * h + 16]
+            steps.append(blk)
+    return torch.stack(steps, dim=1).contiguous(), scale
