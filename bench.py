@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--cfg-scale", type=float, default=None)
     ap.add_argument("--top-k", type=int, default=250)
     ap.add_argument("--weights", choices=["bf16", "f32", "fp8"], default="bf16", help="storage of the streamed matrices")
+    ap.add_argument("--codec", choices=["f32", "f16pair", "f16pair_w8", "mx8"], default=None,
+                    help="codec conv precision (default: f16pair; f16pair_w8 with --weights fp8).  mx8 = block-scaled fp8 on "
+                         "the fp8 MFMA, BASELINE configs[4] together with --weights fp8 --batch 16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="experiment: codec + gather of batch i on a second stream (slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +161,9 @@ def main():
     # — fp32 weights bf16 cannot hold, i.e. what a real V-AURA checkpoint looks like: "auto" resolves to f32 storage there.
     sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
     eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights)
-    codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision="f16pair_w8" if args.weights == "fp8" else "f16pair")
+    if args.codec is None:
+        args.codec = "f16pair_w8" if args.weights == "fp8" else "f16pair"
+    codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision=args.codec)
     feats_cpu = synth.video_features(B, TV, cfg.cond_in, seed=0, first_clip=first)
     feats = feats_cpu.to(dev)
     kw = dict(use_sampling=True, temp=1.0, top_k=args.top_k, top_p=0.0, cfg_scale=args.cfg_scale, seed=1234,
@@ -220,7 +225,7 @@ def main():
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",   # dtype = the arithmetic type: fp32 products / accumulate (exact bf16-plane products), whatever the storage
-        "config": {"workload": (f"configs[{3 if long_ctx else 1}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
+        "config": {"workload": (f"configs[{3 if long_ctx else (4 if args.weights == 'fp8' and args.codec == 'mx8' else 1)}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
                    "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
@@ -228,7 +233,11 @@ def main():
                                 "f32": "fp32 storage of the streamed matrices",
                                 "fp8": "fp8 e4m3 + power-of-two row scales for the per-layer matrices and the codec's conv weights, "
                                        "bf16 heads (a different model than the bf16 one: not the headline configuration)"}[args.weights]
-                               + "; fp32 activations / accumulate / KV cache; codec activations on (hi, lo) fp16 pairs, fp32 accumulate"),
+                               + "; fp32 activations / accumulate / KV cache; codec: "
+                               + {"f32": "fp32 MFMA", "f16pair": "activations and weights on (hi, lo) fp16 pairs, fp32 accumulate",
+                                  "f16pair_w8": "fp8 weights in one fp16 plane, activations on (hi, lo) fp16 pairs",
+                                  "mx8": "fp8 weights and block-scaled fp8 activations on the fp8 MFMA (NOT inside the 1e-4 waveform "
+                                         "budget: BASELINE configs[4] option)"}[args.codec]),
                    "hipgraph": not args.no_graph,
                    "streams": "decode loop of batch i+1 overlaps codec+gather of batch i (two HIP streams)" if args.overlap
                               else "one non-null HIP stream"},
