@@ -50,7 +50,6 @@ void va_prof_events(hipEvent_t* a, hipEvent_t* b) {
 #define PROF_B(kind) do { if (g_prof) g_prof->before(kind); } while (0)
 #define PROF_A(kind) do { if (g_prof) g_prof->after(kind); } while (0)
 
-unsigned va_debug_flags_get();
 static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
                     const float* gain_out, float* ss_out, const vaura_decoder* d, int N, int n_pos = 1) {
   Gemv3Args a;

@@ -73,6 +73,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
                         float* part, int n_split, hipStream_t s);
 struct Gemv3Args;
 struct MlpFusedArgs;
+unsigned va_debug_flags_get();   // vaura_set_debug_flags (gemv3.hip): kernel-variant switches for A/B measurements
 bool va_mlp_fused_available();
 int va_launch_mlp_fused(const MlpFusedArgs& a, hipStream_t s);
 int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s);

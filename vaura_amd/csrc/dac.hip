@@ -716,6 +716,132 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Row f2's linear layers (vit.hip) are one-tap problems: no halo to reuse, so per k-step both operand tiles come through
+// L2 and the 128 x 96 conv tile above moves 28 KB per 2.4 MFLOP — it sat at the L2 rate (130 TFLOP/s-equivalent).  This
+// kernel is the same pair arithmetic on a 128 x 192 tile (wave tile 64 x 96: 20 fragment reads per 72 MFMAs instead of
+// 14 per 36; 40 KB per 4.7 MFLOP), ONE LDS stage of 40 KB (global -> registers runs ahead by one step, two barriers per
+// step) so that two workgroups share a CU and one's epilogue / barriers sit under the other's matrix instructions, and
+// an XCD-aware tile order: workgroup id % 8 is the XCD, and an XCD walks "its" row tiles with the column tiles fastest,
+// so an activation tile is fetched into one L2 only and reused there by every column tile.
+#define LBM 128
+#define LBN 192
+__global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mtiles, int ntiles) {
+  __shared__ u32x4 smem[8 * (LBN + LBM)];
+  // [kq][row ^ kq]: fragment reads (16 consecutive rows, one kq) and staging writes (one row, 8 kq) are both conflict-free
+  auto Ws = [&](int kq, int row) -> u32x4& { return smem[kq * LBN + (row ^ kq)]; };
+  auto Xs = [&](int kq, int row) -> u32x4& { return smem[8 * LBN + kq * LBM + (row ^ kq)]; };
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wn = wv & 1, wm = wv >> 1;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int nt = local % ntiles, mt = (local / ntiles) * 8 + xcd;
+  if (mt >= mtiles) return;
+  const int b = blockIdx.y;
+  const int j0 = mt * LBM, n0 = nt * LBN;
+  const int cq = a.Cin / 4;                 // 16-B quads per row (C/8 octets x 2 planes)
+  const u32x4* in = reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.Lin * cq;
+  const u32x4* wb = reinterpret_cast<const u32x4*>(a.w);
+  const int nk = a.Cin / BK;
+
+  u32x4 wreg[6], xreg[4];
+  auto load_regs = [&](int kt) {
+    const int q0 = kt * 8;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int qd = tid + 256 * i;
+      wreg[i] = wb[(size_t)(n0 + (qd >> 3)) * cq + q0 + (qd & 7)];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qd = tid + 256 * i, jr = j0 + (qd >> 3);
+      xreg[i] = jr < a.Lin ? in[(size_t)jr * cq + q0 + (qd & 7)] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const int qd = tid + 256 * i; Ws(qd & 7, qd >> 3) = wreg[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs(qd & 7, qd >> 3) = xreg[i]; }
+  };
+
+  f32x4 acc[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, r16 = lane & 15;
+  load_regs(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_lds();
+    __syncthreads();
+    if (kt + 1 < nk) load_regs(kt + 1);
+    f16x8 xh[4], xl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = __builtin_bit_cast(f16x8, Xs(2 * g, wm * 64 + j * 16 + r16));
+      xl[j] = __builtin_bit_cast(f16x8, Xs(2 * g + 1, wm * 64 + j * 16 + r16));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f16x8 wh = __builtin_bit_cast(f16x8, Ws(2 * g, wn * 96 + i * 16 + r16));
+      const f16x8 wl = __builtin_bit_cast(f16x8, Ws(2 * g + 1, wn * 96 + i * 16 + r16));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue, one 16-row slab of every wave per pass (32 rows x 192 columns staged in LDS, 25 KB): every thread then
+  // owns whole octets of a row (32 contiguous bytes per stream), like conv_tile_store
+  constexpr int SP = LBN + 4, OCT = LBN / 8;
+  float* stage = reinterpret_cast<float*>(smem);
+  const size_t obase = (size_t)b * a.Lout;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int col = wn * 96 + i * 16 + 4 * g;
+      *reinterpret_cast<f32x4*>(stage + (wm * 16 + r16) * SP + col) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + n0 + col);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32 * OCT / 256; ++it) {
+      const int u = tid + 256 * it, lr = u / OCT, oc = u - lr * OCT;
+      const int jr = j0 + (lr >> 4) * 64 + j * 16 + (lr & 15);
+      if (jr < a.Lin) {
+        const int co = n0 + oc * 8;
+        const size_t orow = obase + (size_t)(jr + a.oshift0);
+        const size_t o = orow * a.Cout + co;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + lr * SP + oc * 8);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + lr * SP + oc * 8 + 4);
+        if (a.res) {
+          v0 = *reinterpret_cast<const f32x4*>(a.res + o) + v0;
+          v1 = *reinterpret_cast<const f32x4*>(a.res + o + 4) + v1;
+        }
+        if (a.out_raw) {
+          *reinterpret_cast<f32x4*>(a.out_raw + o) = v0;
+          *reinterpret_cast<f32x4*>(a.out_raw + o + 4) = v1;
+        }
+        if (a.out_act) {
+          float sv[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sv[r] = a.act == 1 ? gelu_erf_f(v0[r]) : v0[r];
+            sv[r + 4] = a.act == 1 ? gelu_erf_f(v1[r]) : v1[r];
+          }
+          store_act_octet(a.out_act, nullptr, 0, orow, co, a.Cout, sv);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Plain linear layer on the pair GEMM (row f2, vit.hip): out[b][row + oshift][:] = act( in[b][row][:] . W^T + bias (+ res) ).
 // in: pair layout (B, Lin, Cin); w: pair layout (Cout, Cin); out rows live in sequences of Lout rows per b.
 int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bias, const float* res, float* out_raw,
@@ -726,6 +852,11 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
   p.Lin = Lin; p.Lout = Lout; p.Cin = Cin; p.Cout = Cout; p.NT = 1; p.off_base = 0; p.off_step = 1; p.ostride = 1;
   p.oshift0 = oshift; p.jcount = Lin; p.act = act;
   p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
+  if (Cout % LBN == 0 && act != 0 && !(va_debug_flags_get() & 64)) {     // debug flag bit 6: the 128 x 96 conv tile instead
+    const int mtiles = (Lin + LBM - 1) / LBM, ntiles = Cout / LBN;
+    VA_LAUNCH(linear_pair_kernel, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
+    return 0;
+  }
   VA_LAUNCH((conv_pair_kernel<3, false>), dim3((Lin + BM - 1) / BM, Cout / BN, B), dim3(256), 0, s, p);
   return 0;
 }
