@@ -12,7 +12,7 @@ from vaura_amd.engine import AvclipEngine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = "cuda:0"
-FLAGS = int(os.environ.get("VAURA_DEBUG_FLAGS", "0"))    # A/B: 64 = linears on the 128 x 96 conv tile
+FLAGS = int(os.environ.get("VAURA_DEBUG_FLAGS", "0"))    # A/B: 64 = linears on the 128 x 96 conv tile, 128 = one-thread-per-query space attention
 if FLAGS:
     from vaura_amd import _lib as L  # noqa: E402
     L.lib().vaura_set_debug_flags(FLAGS)

@@ -333,6 +333,110 @@ __global__ __launch_bounds__(256) void vit_space_attn_kernel(const float* __rest
   for (int oc = 0; oc < VHD / 8; ++oc) put_pair8(out_pair, qrow, h * (VHD / 8) + oc, D, o + 8 * oc);
 }
 
+// The same space attention on the matrix cores, exact fp32 (v_mfma_f32_16x16x4_f32 = an fmaf chain).  One workgroup per (head,
+// frame, segment) as above; K (stride 65 floats) and V (stride 68) of the frame in LDS, both bank-conflict-free for the fragment
+// reads below; a wave takes 16 queries at a time:
+//   S^T tile (16 keys x 16 queries) = K_tile . Q^T over d: A = K[key = lane&15][d], B = Q[q = lane&15][d] with the k slots of lane
+//     group g standing for d = 16g .. 16g+15 (any bijection will do, A and B use the same) -> a lane ends up with the scores of
+//     ITS query (lane&15) against keys 4g + reg of every tile: all 13 tiles stay in registers (52), so softmax is one pass —
+//     max and sum over a query's keys are two lane shuffles (xor 16, xor 32) plus register work;
+//   O^T tile (16 d x 16 queries) = V^T . P^T over keys: A = V[key = 4g + s][d = lane&15], B = P[q = lane&15][key = 4g + s] — exactly
+//     the register the lane already holds (the accumulator-as-operand idiom): no transposition, no LDS round trip for P.
+#define VSK 65
+#define VSV 68
+#define VS_NKT 13                                // key tiles: np + 1 <= 208
+__global__ __launch_bounds__(256) void vit_space_attn_mfma_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair, int nf, int np,
+                                                                  int D) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int nk = np + 1;
+  float* Ks = sm;                                // 208 x VSK
+  float* Vs = sm + VS_NKT * 16 * VSK;            // 208 x VSV
+  const int h = blockIdx.x, f = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x;
+  const int L = 1 + nf * np;
+  const size_t row0 = (size_t)seg * L;
+  for (int u = tid; u < VS_NKT * 16 * (VHD / 4); u += 256) {
+    const int j = u / (VHD / 4), c = u % (VHD / 4);
+    f32x4 kq = f32x4{0.f, 0.f, 0.f, 0.f}, vq = kq;
+    if (j < nk) {
+      const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
+      kq = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + D + h * VHD)[c];
+      vq = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + 2 * D + h * VHD)[c];
+    }
+    float* kd = Ks + j * VSK + 4 * c;
+    kd[0] = kq[0]; kd[1] = kq[1]; kd[2] = kq[2]; kd[3] = kq[3];
+    *reinterpret_cast<f32x4*>(Vs + j * VSV + 4 * c) = vq;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int nqt = (np + 15) / 16;
+  for (int qt = wv; qt < nqt; qt += 4) {
+    const int qi = qt * 16 + r16;
+    const size_t qrow = row0 + 1 + (size_t)f * np + (qi < np ? qi : np - 1);
+    float q[16];
+    {
+      const f32x4* qp = reinterpret_cast<const f32x4*>(qkv + qrow * 3 * D + h * VHD + 16 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 t = qp[i];
+        q[4 * i] = t[0] * 0.125f; q[4 * i + 1] = t[1] * 0.125f; q[4 * i + 2] = t[2] * 0.125f; q[4 * i + 3] = t[3] * 0.125f;
+      }
+    }
+    f32x4 st[VS_NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < VS_NKT; ++kt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* kp = Ks + (kt * 16 + r16) * VSK + 16 * g;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[s], q[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * 16 + 4 * g + r >= nk) acc[r] = -INFINITY;
+        m = fmaxf(m, acc[r]);
+      }
+      st[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < VS_NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(st[kt][r] - m);
+        st[kt][r] = e;
+        l += e;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int dt = 0; dt < VHD / 16; ++dt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kt = 0; kt < VS_NKT; ++kt) {
+        const float* vp = Vs + (kt * 16 + 4 * g) * VSV + dt * 16 + r16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * VSV], st[kt][s], acc, 0, 0, 0);
+      }
+      if (qi < np) {      // the lane holds channels c0 .. c0+3 of its query: half an octet of the pair layout
+        const int c0 = h * VHD + dt * 16 + 4 * g;
+        typedef _Float16 vf16x4 __attribute__((ext_vector_type(4)));
+        vf16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float o = acc[r] * inv;
+          hi[r] = (_Float16)o;
+          lo[r] = (_Float16)(o - (float)hi[r]);
+        }
+        vf16x4* dst = reinterpret_cast<vf16x4*>(out_pair + ((qrow * (size_t)(D >> 3) + (size_t)(c0 >> 3)) * 2) * 8 + (c0 & 7));
+        dst[0] = hi;
+        dst[2] = lo;      // + 8 halves: the lo plane of the same octet
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- driver
 static int ln(const vaura_vit* v, const float* X, const float* w, const float* b, float* of, uint16_t* op, int64_t rows, int map, hipStream_t s) {
   VA_LAUNCH(vit_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, w, b, of, op, rows, v->dim, v->eps, map, v->n_frames, v->n_patches);
@@ -353,15 +457,27 @@ static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const
     VA_LAUNCH(vit_time_attn_kernel<8>, dim3(v->n_patches, n_seg), dim3(128), 0, s, (const float*)v->ws_qkv, v->ws_a, v->n_patches,
               v->heads, D);
   } else {
-    const size_t sm = sizeof(float) * 2 * (size_t)(v->n_patches + 1) * VHD;      // 100.9 KB of the CU's 160 KB
-    static bool big_lds = false;
-    if (!big_lds) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-        return VAURA_ERR_STATE;
-      big_lds = true;
+    if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & 128)) {     // debug flag bit 7: the one-thread-per-query kernel
+      const size_t sm = sizeof(float) * (size_t)(VS_NKT * 16) * (VSK + VSV);       // 108 KB of the CU's 160 KB
+      static bool big_lds_m = false;
+      if (!big_lds_m) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+          return VAURA_ERR_STATE;
+        big_lds_m = true;
+      }
+      VA_LAUNCH(vit_space_attn_mfma_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(256), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
+                v->n_patches, D);
+    } else {
+      const size_t sm = sizeof(float) * 2 * (size_t)(v->n_patches + 1) * VHD;      // 100.9 KB of the CU's 160 KB
+      static bool big_lds = false;
+      if (!big_lds) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+          return VAURA_ERR_STATE;
+        big_lds = true;
+      }
+      VA_LAUNCH(vit_space_attn_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(256), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
+                v->n_patches, D);
     }
-    VA_LAUNCH(vit_space_attn_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(256), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
-              v->n_patches, D);
   }
   // x = x + proj(attention)      vit_helper.py:452-468
   return va_launch_linear_pair(v->ws_a, (const uint16_t*)at.proj_w, at.proj_b, v->ws_x, v->ws_x, nullptr, 2, 1, (int)N, (int)N, 0, D, D, s);
