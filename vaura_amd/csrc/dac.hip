@@ -726,11 +726,13 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
 // so an activation tile is fetched into one L2 only and reused there by every column tile.
 #define LBM 128
 #define LBN 192
+template <int NBUF>
 __global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mtiles, int ntiles) {
-  __shared__ u32x4 smem[8 * (LBN + LBM)];
+  __shared__ u32x4 smem[NBUF * 8 * (LBN + LBM)];
+  int cur = 0;
   // [kq][row ^ kq]: fragment reads (16 consecutive rows, one kq) and staging writes (one row, 8 kq) are both conflict-free
-  auto Ws = [&](int kq, int row) -> u32x4& { return smem[kq * LBN + (row ^ kq)]; };
-  auto Xs = [&](int kq, int row) -> u32x4& { return smem[8 * LBN + kq * LBM + (row ^ kq)]; };
+  auto Ws = [&](int buf, int kq, int row) -> u32x4& { return smem[buf * 8 * (LBN + LBM) + kq * LBN + (row ^ kq)]; };
+  auto Xs = [&](int buf, int kq, int row) -> u32x4& { return smem[buf * 8 * (LBN + LBM) + 8 * LBN + kq * LBM + (row ^ kq)]; };
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv & 1, wm = wv >> 1;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
@@ -757,11 +759,11 @@ __global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mt
       xreg[i] = jr < a.Lin ? in[(size_t)jr * cq + q0 + (qd & 7)] : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  auto store_lds = [&]() {
+  auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const int qd = tid + 256 * i; Ws(qd & 7, qd >> 3) = wreg[i]; }
+    for (int i = 0; i < 6; ++i) { const int qd = tid + 256 * i; Ws(buf, qd & 7, qd >> 3) = wreg[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs(qd & 7, qd >> 3) = xreg[i]; }
+    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs(buf, qd & 7, qd >> 3) = xreg[i]; }
   };
 
   f32x4 acc[6][4];
@@ -772,26 +774,30 @@ __global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mt
 
   const int g = lane >> 4, r16 = lane & 15;
   load_regs(0);
+  if (NBUF == 2) { store_lds(0); __syncthreads(); }
   for (int kt = 0; kt < nk; ++kt) {
-    store_lds();
-    __syncthreads();
+    if (NBUF == 1) { store_lds(0); __syncthreads(); }
     if (kt + 1 < nk) load_regs(kt + 1);
     f16x8 xh[4], xl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      xh[j] = __builtin_bit_cast(f16x8, Xs(2 * g, wm * 64 + j * 16 + r16));
-      xl[j] = __builtin_bit_cast(f16x8, Xs(2 * g + 1, wm * 64 + j * 16 + r16));
+      xh[j] = __builtin_bit_cast(f16x8, Xs(cur, 2 * g, wm * 64 + j * 16 + r16));
+      xl[j] = __builtin_bit_cast(f16x8, Xs(cur, 2 * g + 1, wm * 64 + j * 16 + r16));
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const f16x8 wh = __builtin_bit_cast(f16x8, Ws(2 * g, wn * 96 + i * 16 + r16));
-      const f16x8 wl = __builtin_bit_cast(f16x8, Ws(2 * g + 1, wn * 96 + i * 16 + r16));
+      const f16x8 wh = __builtin_bit_cast(f16x8, Ws(cur, 2 * g, wn * 96 + i * 16 + r16));
+      const f16x8 wl = __builtin_bit_cast(f16x8, Ws(cur, 2 * g + 1, wn * 96 + i * 16 + r16));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[i][j], 0, 0, 0);
       }
+    }
+    if (NBUF == 2) {
+      if (kt + 1 < nk) store_lds(cur ^ 1);
+      cur ^= 1;
     }
     __syncthreads();
   }
@@ -854,7 +860,10 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
   p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
   if (Cout % LBN == 0 && act != 0 && !(va_debug_flags_get() & 64)) {     // debug flag bit 6: the 128 x 96 conv tile instead
     const int mtiles = (Lin + LBM - 1) / LBM, ntiles = Cout / LBN;
-    VA_LAUNCH(linear_pair_kernel, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
+    if (va_debug_flags_get() & 256)   // debug flag bit 8: two LDS stages (80 KB: whether two workgroups still share a CU is the question)
+      VA_LAUNCH(linear_pair_kernel<2>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
+    else
+      VA_LAUNCH(linear_pair_kernel<1>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
     return 0;
   }
   VA_LAUNCH((conv_pair_kernel<3, false>), dim3((Lin + BM - 1) / BM, Cout / BN, B), dim3(256), 0, s, p);

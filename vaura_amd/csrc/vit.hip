@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void vit_space_attn_kernel(const float* __rest
 #define VSK 65
 #define VSV 68
 #define VS_NKT 13                                // key tiles: np + 1 <= 208
-__global__ __launch_bounds__(256) void vit_space_attn_mfma_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair, int nf, int np,
+__global__ __launch_bounds__(512) void vit_space_attn_mfma_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair, int nf, int np,
                                                                   int D) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int nk = np + 1;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void vit_space_attn_mfma_kernel(const float* _
   const int h = blockIdx.x, f = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x;
   const int L = 1 + nf * np;
   const size_t row0 = (size_t)seg * L;
-  for (int u = tid; u < VS_NKT * 16 * (VHD / 4); u += 256) {
+  for (int u = tid; u < VS_NKT * 16 * (VHD / 4); u += 512) {
     const int j = u / (VHD / 4), c = u % (VHD / 4);
     f32x4 kq = f32x4{0.f, 0.f, 0.f, 0.f}, vq = kq;
     if (j < nk) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void vit_space_attn_mfma_kernel(const float* _
   __syncthreads();
   const int lane = tid & 63, wv = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int nqt = (np + 15) / 16;
-  for (int qt = wv; qt < nqt; qt += 4) {
+  for (int qt = wv; qt < nqt; qt += 8) {      // 13 query tiles over 8 waves (two waves per SIMD)
     const int qi = qt * 16 + r16;
     const size_t qrow = row0 + 1 + (size_t)f * np + (qi < np ? qi : np - 1);
     float q[16];
@@ -383,18 +383,32 @@ __global__ __launch_bounds__(256) void vit_space_attn_mfma_kernel(const float* _
     }
     f32x4 st[VS_NKT];
     float m = -INFINITY;
+    // two key tiles at a time: two independent accumulation chains keep the matrix pipe issuing back to back
 #pragma unroll
-    for (int kt = 0; kt < VS_NKT; ++kt) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* kp = Ks + (kt * 16 + r16) * VSK + 16 * g;
+    for (int kt = 0; kt < VS_NKT; kt += 2) {
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+      const float* kp0 = Ks + (kt * 16 + r16) * VSK + 16 * g;
+      const float* kp1 = kp0 + 16 * VSK;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[s], q[s], acc, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp0[s], q[s], acc0, 0, 0, 0);
+        if (kt + 1 < VS_NKT) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kp1[s], q[s], acc1, 0, 0, 0);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (kt * 16 + 4 * g + r >= nk) acc[r] = -INFINITY;
-        m = fmaxf(m, acc[r]);
+        if (kt * 16 + 4 * g + r >= nk) acc0[r] = -INFINITY;
+        m = fmaxf(m, acc0[r]);
       }
-      st[kt] = acc;
+      st[kt] = acc0;
+      if (kt + 1 < VS_NKT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if ((kt + 1) * 16 + 4 * g + r >= nk) acc1[r] = -INFINITY;
+          m = fmaxf(m, acc1[r]);
+        }
+        st[kt + 1] = acc1;
+      }
+      __builtin_amdgcn_sched_barrier(0);     // keep the fully unrolled body from hoisting every tile's LDS reads (spills)
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -410,15 +424,22 @@ __global__ __launch_bounds__(256) void vit_space_attn_mfma_kernel(const float* _
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
+    f32x4 oacc[VHD / 16];
+#pragma unroll
+    for (int dt = 0; dt < VHD / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < VS_NKT; ++kt) {
+      const float* vp = Vs + (kt * 16 + 4 * g) * VSV + r16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int dt = 0; dt < VHD / 16; ++dt)      // four independent chains
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * VSV + dt * 16], st[kt][s], oacc[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int dt = 0; dt < VHD / 16; ++dt) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < VS_NKT; ++kt) {
-        const float* vp = Vs + (kt * 16 + 4 * g) * VSV + dt * 16 + r16;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vp[s * VSV], st[kt][s], acc, 0, 0, 0);
-      }
+      const f32x4 acc = oacc[dt];
       if (qi < np) {      // the lane holds channels c0 .. c0+3 of its query: half an octet of the pair layout
         const int c0 = h * VHD + dt * 16 + 4 * g;
         typedef _Float16 vf16x4 __attribute__((ext_vector_type(4)));
@@ -465,7 +486,7 @@ static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const
           return VAURA_ERR_STATE;
         big_lds_m = true;
       }
-      VA_LAUNCH(vit_space_attn_mfma_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(256), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
+      VA_LAUNCH(vit_space_attn_mfma_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(512), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
                 v->n_patches, D);
     } else {
       const size_t sm = sizeof(float) * 2 * (size_t)(v->n_patches + 1) * VHD;      // 100.9 KB of the CU's 160 KB
