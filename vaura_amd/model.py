@@ -125,7 +125,10 @@ class VAURAModel(nn.Module):
             audio = self.audio_encoder.encode(audio)
         vis = self._handle_visual_conditioning(frames, clip_indices)
         if vis is None:
-            raise NotImplementedError("unconditional generation is not built (every config conditions on video)")
+            # the reference's llama sampler refuses a missing condition itself: `raise Exception("Not implemented")` under
+            # "we should always have audio and video" (llama.py:474-476) — channel-concat conditioning has no unconditional form
+            raise NotImplementedError("unconditional generation: the llama sampler always needs video features "
+                                      "(the reference raises here too, llama.py:474-476)")
         B = vis.shape[0]
         K = self.num_codebooks
         Tp = 0 if audio is None else int(audio.shape[-1])
