@@ -256,6 +256,137 @@ __global__ __launch_bounds__(128) void vit_time_attn_kernel(const float* __restr
   for (int oc = 0; oc < VHD / 8; ++oc) put_pair8(out_pair, qrow, h * (VHD / 8) + oc, D, o + 8 * oc);
 }
 
+// ---- round-2 forms of the CLS and time patterns: 16 lanes per (query, key row), each lane 4 of the head's 64 channels, so every
+// load is a 256-byte run of one row (the kernels above read 16-byte pieces of 64 different rows per instruction) and a dot
+// product is 4 fmaf + a 4-step xor reduction inside the 16-lane row.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ void put_pair4(uint16_t* base, size_t row, int c0, int C, const f32x4 v) {   // c0 % 4 == 0
+  typedef _Float16 vf16x4 __attribute__((ext_vector_type(4)));
+  vf16x4 hi, lo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { hi[r] = (_Float16)v[r]; lo[r] = (_Float16)(v[r] - (float)hi[r]); }
+  vf16x4* dst = reinterpret_cast<vf16x4*>(base + ((row * (size_t)(C >> 3) + (size_t)(c0 >> 3)) * 2) * 8 + (c0 & 7));
+  dst[0] = hi;
+  dst[2] = lo;
+}
+
+// CLS query of sequence `seq` over keys [split * chunk, ...) of its Lseq rows.  grid (heads, n_seq, nsplit).  nsplit == 1: the
+// normalised result goes to out_pair row seq * out_stride; else the partial (max, sum, 64 unnormalised outputs) goes to
+// part[((seq * heads + h) * nsplit + split) * 66] and vit_cls_combine_kernel finishes.
+__global__ __launch_bounds__(256) void vit_cls_attn_split_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair,
+                                                                 float* __restrict__ part, int Lseq, int D, int64_t out_stride, int chunk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* sc = sm;                          // chunk scores -> probabilities
+  float* red = sm + chunk;                 // 16 x 64 partial outputs | 16 partial sums | 4 wave maxima
+  const int h = blockIdx.x, seq = blockIdx.y, split = blockIdx.z, nsplit = gridDim.z, tid = threadIdx.x;
+  const int sub = tid & 15, ks = tid >> 4;
+  const size_t row0 = (size_t)seq * Lseq;
+  const float* base = qkv + row0 * 3 * D + h * VHD + 4 * sub;
+  const int j0 = split * chunk, j1 = min(Lseq, j0 + chunk);
+  f32x4 q = *reinterpret_cast<const f32x4*>(base);
+  q = q * 0.125f;
+  float mx = -INFINITY;
+  for (int j = j0 + ks; j < j1; j += 16) {
+    const f32x4 k = *reinterpret_cast<const f32x4*>(base + (size_t)j * 3 * D + D);
+    const float s = row16_sum(fmaf(q[3], k[3], fmaf(q[2], k[2], fmaf(q[1], k[1], q[0] * k[0]))));
+    if (sub == 0) sc[j - j0] = s;
+    mx = fmaxf(mx, s);
+  }
+  float* rl = red + 16 * VHD;
+  float* rm = rl + 16;
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) rm[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int j = j0 + ks; j < j1; j += 16) {
+    const float e = expf(sc[j - j0] - mx);
+    l += e;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)j * 3 * D + 2 * D);
+    o[0] = fmaf(e, v[0], o[0]); o[1] = fmaf(e, v[1], o[1]); o[2] = fmaf(e, v[2], o[2]); o[3] = fmaf(e, v[3], o[3]);
+  }
+  *reinterpret_cast<f32x4*>(red + ks * VHD + 4 * sub) = o;
+  if (sub == 0) rl[ks] = l;
+  __syncthreads();
+  if (tid < VHD) {
+    float y = 0.f, lt = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { y += red[i * VHD + tid]; lt += rl[i]; }
+    if (nsplit == 1) {
+      y *= 1.0f / lt;
+      const _Float16 hi = (_Float16)y, lo = (_Float16)(y - (float)hi);
+      _Float16* dst = reinterpret_cast<_Float16*>(out_pair) + (((size_t)seq * out_stride * (size_t)(D >> 3) + (size_t)(h * (VHD / 8) + (tid >> 3))) * 2) * 8 + (tid & 7);
+      dst[0] = hi;
+      dst[8] = lo;
+    } else {
+      float* p = part + ((size_t)(seq * gridDim.x + h) * nsplit + split) * 66;
+      p[2 + tid] = y;
+      if (tid == 0) { p[0] = mx; p[1] = lt; }
+    }
+  }
+}
+
+// grid (heads, n_seq), 64 threads: merges the nsplit partials of one (sequence, head)
+__global__ __launch_bounds__(64) void vit_cls_combine_kernel(const float* __restrict__ part, uint16_t* __restrict__ out_pair, int nsplit, int D,
+                                                             int64_t out_stride) {
+  const int h = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x;
+  const float* p = part + (size_t)(seq * gridDim.x + h) * nsplit * 66;
+  float M = -INFINITY;
+  for (int i = 0; i < nsplit; ++i) M = fmaxf(M, p[i * 66]);
+  float L = 0.f, y = 0.f;
+  for (int i = 0; i < nsplit; ++i) {
+    const float w = expf(p[i * 66] - M);
+    L = fmaf(w, p[i * 66 + 1], L);
+    y = fmaf(w, p[i * 66 + 2 + tid], y);
+  }
+  y *= 1.0f / L;
+  const _Float16 hi = (_Float16)y, lo = (_Float16)(y - (float)hi);
+  _Float16* dst = reinterpret_cast<_Float16*>(out_pair) + (((size_t)seq * out_stride * (size_t)(D >> 3) + (size_t)(h * (VHD / 8) + (tid >> 3))) * 2) * 8 + (tid & 7);
+  dst[0] = hi;
+  dst[8] = lo;
+}
+
+// time pattern, 16 lanes per (frame f, head h) query of location n: grid (heads / 2, np, n_seg), 256 threads = 2 heads x 8 frames x 16
+template <int NFT>
+__global__ __launch_bounds__(256) void vit_time_attn16_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair, int np, int D) {
+  constexpr int nf = NFT;
+  const int tid = threadIdx.x, sub = tid & 15, pr = tid >> 4;
+  const int f = pr % nf, h = blockIdx.x * 2 + pr / nf;
+  const int n = blockIdx.y, seg = blockIdx.z;
+  const int L = 1 + nf * np;
+  const size_t row0 = (size_t)seg * L;
+  const size_t qrow = row0 + 1 + (size_t)f * np + n;
+  const float* col = qkv + h * VHD + 4 * sub;
+  f32x4 q = *reinterpret_cast<const f32x4*>(col + qrow * 3 * D);
+  q = q * 0.125f;
+  float sc[NFT + 1];
+  f32x4 vv[NFT + 1];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j <= nf; ++j) {
+    const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)(j - 1) * np + n;
+    const f32x4 k = *reinterpret_cast<const f32x4*>(col + kr * 3 * D + D);
+    vv[j] = *reinterpret_cast<const f32x4*>(col + kr * 3 * D + 2 * D);
+    sc[j] = row16_sum(fmaf(q[3], k[3], fmaf(q[2], k[2], fmaf(q[1], k[1], q[0] * k[0]))));
+    mx = fmaxf(mx, sc[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j <= nf; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+  const float inv = 1.0f / sum;
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j <= nf; ++j) {
+    const float pj = sc[j] * inv;
+    o[0] = fmaf(pj, vv[j][0], o[0]); o[1] = fmaf(pj, vv[j][1], o[1]); o[2] = fmaf(pj, vv[j][2], o[2]); o[3] = fmaf(pj, vv[j][3], o[3]);
+  }
+  put_pair4(out_pair, qrow, h * VHD + 4 * sub, D, o);
+}
+
 // space attention: query (seg, f, n) over keys {CLS, (seg, f, n') for n' in 0..np-1}.  grid (heads, nf, n_seg); the frame's K and
 // V rows of this head (np + 1 <= 197 rows x 64) are staged in LDS once, every thread is one query and reads them as broadcasts;
 // online softmax over chunks of 16 keys.
@@ -464,6 +595,23 @@ static int ln(const vaura_vit* v, const float* X, const float* w, const float* b
   return 0;
 }
 
+// CLS pattern launcher: long sequences are split over 8 workgroups per (sequence, head) — 384 workgroups of 1 569 keys each left
+// a third of the chip idle and took 205 us for 308 MB — with the partials in `part` (>= n_seq * heads * 8 * 66 floats).
+static int cls_attention(const vaura_vit* v, const float* qkv, uint16_t* out, float* part, int n_seq, int Lseq, int64_t out_stride, hipStream_t s) {
+  const int D = v->dim;
+  if (va_debug_flags_get() & 512) {     // debug flag bit 9: the one-workgroup-per-(sequence, head) kernel
+    const size_t sm_cls = sizeof(float) * (size_t)(((Lseq + 3) & ~3) + 4 * VHD + 8);
+    VA_LAUNCH(vit_cls_attn_kernel, dim3(v->heads, (unsigned)n_seq), dim3(256), sm_cls, s, qkv, out, Lseq, D, out_stride);
+    return 0;
+  }
+  const int nsplit = (Lseq > 512 && part) ? 8 : 1;
+  const int chunk = (((Lseq + nsplit - 1) / nsplit) + 15) & ~15;
+  const size_t smb = sizeof(float) * (size_t)(chunk + 16 * VHD + 16 + 4);
+  VA_LAUNCH(vit_cls_attn_split_kernel, dim3(v->heads, (unsigned)n_seq, nsplit), dim3(256), smb, s, qkv, out, part, Lseq, D, out_stride, chunk);
+  if (nsplit > 1) VA_LAUNCH(vit_cls_combine_kernel, dim3(v->heads, (unsigned)n_seq), dim3(64), 0, s, (const float*)part, out, nsplit, D, out_stride);
+  return 0;
+}
+
 static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const float* ln_w, const float* ln_b, bool time, int n_seg,
                              hipStream_t s) {
   const int D = v->dim, L = 1 + v->n_frames * v->n_patches;
@@ -472,11 +620,15 @@ static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const
   if (rc) return rc;
   rc = va_launch_linear_pair(v->ws_a, (const uint16_t*)at.qkv_w, at.qkv_b, nullptr, v->ws_qkv, nullptr, 2, 1, (int)N, (int)N, 0, D, 3 * D, s);
   if (rc) return rc;
-  const size_t sm_cls = sizeof(float) * (size_t)(((L + 3) & ~3) + 4 * VHD + 8);
-  VA_LAUNCH(vit_cls_attn_kernel, dim3(v->heads, n_seg), dim3(256), sm_cls, s, (const float*)v->ws_qkv, v->ws_a, L, D, (int64_t)L);
+  rc = cls_attention(v, (const float*)v->ws_qkv, v->ws_a, v->ws_s /* free until the aggregation layer */, n_seg, L, (int64_t)L, s);
+  if (rc) return rc;
   if (time) {
-    VA_LAUNCH(vit_time_attn_kernel<8>, dim3(v->n_patches, n_seg), dim3(128), 0, s, (const float*)v->ws_qkv, v->ws_a, v->n_patches,
-              v->heads, D);
+    if ((va_debug_flags_get() & 1024) || (v->heads & 1))      // debug flag bit 10: one thread per (head, frame)
+      VA_LAUNCH(vit_time_attn_kernel<8>, dim3(v->n_patches, n_seg), dim3(128), 0, s, (const float*)v->ws_qkv, v->ws_a, v->n_patches,
+                v->heads, D);
+    else
+      VA_LAUNCH(vit_time_attn16_kernel<8>, dim3(v->heads / 2, v->n_patches, n_seg), dim3(256), 0, s, (const float*)v->ws_qkv, v->ws_a,
+                v->n_patches, D);
   } else {
     if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & 128)) {     // debug flag bit 7: the one-thread-per-query kernel
       const size_t sm = sizeof(float) * (size_t)(VS_NKT * 16) * (VSK + VSV);       // 108 KB of the CU's 160 KB
@@ -571,10 +723,8 @@ int vaura_avclip_forward(const vaura_vit* v, const float* frames, int n_seg, flo
   if (rc) return rc;
   rc = va_launch_linear_pair(v->ws_a, (const uint16_t*)v->agg_in_w, v->agg_in_b, nullptr, v->ws_qkv, nullptr, 2, 1, (int)NA, (int)NA, 0, D, 3 * D, s);
   if (rc) return rc;
-  {
-    const size_t sm_cls = sizeof(float) * (size_t)(((np + 1 + 3) & ~3) + 4 * VHD + 8);
-    VA_LAUNCH(vit_cls_attn_kernel, dim3(v->heads, (unsigned)nq), dim3(256), sm_cls, s, (const float*)v->ws_qkv, a0, np + 1, D, (int64_t)1);
-  }
+  rc = cls_attention(v, (const float*)v->ws_qkv, a0, nullptr, (int)nq, np + 1, (int64_t)1, s);     // 197 keys: one workgroup each
+  if (rc) return rc;
   VA_LAUNCH(vit_fill_rows_kernel, dim3((unsigned)((nq * (D / 4) + 255) / 256)), dim3(256), 0, s, r0, v->agg_cls, nq, (int64_t)1, D);
   rc = va_launch_linear_pair(a0, (const uint16_t*)v->agg_out_w, v->agg_out_b, r0, x0, nullptr, 2, 1, (int)nq, (int)nq, 0, D, D, s);
   if (rc) return rc;
