@@ -724,46 +724,46 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
 // step) so that two workgroups share a CU and one's epilogue / barriers sit under the other's matrix instructions, and
 // an XCD-aware tile order: workgroup id % 8 is the XCD, and an XCD walks "its" row tiles with the column tiles fastest,
 // so an activation tile is fetched into one L2 only and reused there by every column tile.
-#define LBM 128
 #define LBN 192
-template <int NBUF>
-__global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mtiles, int ntiles) {
-  __shared__ u32x4 smem[NBUF * 8 * (LBN + LBM)];
-  int cur = 0;
+// MW = wave rows: 2 -> 128 x 192 tile, 256 threads, two workgroups per CU; 4 -> 256 x 192 tile, 512 threads, one per CU
+template <int MW>
+__global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void linear_pair_kernel(ConvPArgs a, int mtiles, int ntiles) {
+  constexpr int NTH = 128 * MW, LBM_ = 64 * MW, NWQ = LBN * 8 / NTH, NXQ = LBM_ * 8 / NTH;
+  __shared__ u32x4 smem[8 * (LBN + LBM_)];
   // [kq][row ^ kq]: fragment reads (16 consecutive rows, one kq) and staging writes (one row, 8 kq) are both conflict-free
-  auto Ws = [&](int buf, int kq, int row) -> u32x4& { return smem[buf * 8 * (LBN + LBM) + kq * LBN + (row ^ kq)]; };
-  auto Xs = [&](int buf, int kq, int row) -> u32x4& { return smem[buf * 8 * (LBN + LBM) + 8 * LBN + kq * LBM + (row ^ kq)]; };
+  auto Ws = [&](int kq, int row) -> u32x4& { return smem[kq * LBN + (row ^ kq)]; };
+  auto Xs = [&](int kq, int row) -> u32x4& { return smem[8 * LBN + kq * LBM_ + (row ^ kq)]; };
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv & 1, wm = wv >> 1;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int nt = local % ntiles, mt = (local / ntiles) * 8 + xcd;
   if (mt >= mtiles) return;
   const int b = blockIdx.y;
-  const int j0 = mt * LBM, n0 = nt * LBN;
+  const int j0 = mt * LBM_, n0 = nt * LBN;
   const int cq = a.Cin / 4;                 // 16-B quads per row (C/8 octets x 2 planes)
   const u32x4* in = reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.Lin * cq;
   const u32x4* wb = reinterpret_cast<const u32x4*>(a.w);
   const int nk = a.Cin / BK;
 
-  u32x4 wreg[6], xreg[4];
+  u32x4 wreg[NWQ], xreg[NXQ];
   auto load_regs = [&](int kt) {
     const int q0 = kt * 8;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int qd = tid + 256 * i;
+    for (int i = 0; i < NWQ; ++i) {
+      const int qd = tid + NTH * i;
       wreg[i] = wb[(size_t)(n0 + (qd >> 3)) * cq + q0 + (qd & 7)];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int qd = tid + 256 * i, jr = j0 + (qd >> 3);
+    for (int i = 0; i < NXQ; ++i) {
+      const int qd = tid + NTH * i, jr = j0 + (qd >> 3);
       xreg[i] = jr < a.Lin ? in[(size_t)jr * cq + q0 + (qd & 7)] : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { const int qd = tid + 256 * i; Ws(buf, qd & 7, qd >> 3) = wreg[i]; }
+    for (int i = 0; i < NWQ; ++i) { const int qd = tid + NTH * i; Ws(qd & 7, qd >> 3) = wreg[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int qd = tid + 256 * i; Xs(buf, qd & 7, qd >> 3) = xreg[i]; }
+    for (int i = 0; i < NXQ; ++i) { const int qd = tid + NTH * i; Xs(qd & 7, qd >> 3) = xreg[i]; }
   };
 
   f32x4 acc[6][4];
@@ -774,20 +774,20 @@ __global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mt
 
   const int g = lane >> 4, r16 = lane & 15;
   load_regs(0);
-  if (NBUF == 2) { store_lds(0); __syncthreads(); }
   for (int kt = 0; kt < nk; ++kt) {
-    if (NBUF == 1) { store_lds(0); __syncthreads(); }
+    store_lds();
+    __syncthreads();
     if (kt + 1 < nk) load_regs(kt + 1);
     f16x8 xh[4], xl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      xh[j] = __builtin_bit_cast(f16x8, Xs(cur, 2 * g, wm * 64 + j * 16 + r16));
-      xl[j] = __builtin_bit_cast(f16x8, Xs(cur, 2 * g + 1, wm * 64 + j * 16 + r16));
+      xh[j] = __builtin_bit_cast(f16x8, Xs(2 * g, wm * 64 + j * 16 + r16));
+      xl[j] = __builtin_bit_cast(f16x8, Xs(2 * g + 1, wm * 64 + j * 16 + r16));
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const f16x8 wh = __builtin_bit_cast(f16x8, Ws(cur, 2 * g, wn * 96 + i * 16 + r16));
-      const f16x8 wl = __builtin_bit_cast(f16x8, Ws(cur, 2 * g + 1, wn * 96 + i * 16 + r16));
+      const f16x8 wh = __builtin_bit_cast(f16x8, Ws(2 * g, wn * 96 + i * 16 + r16));
+      const f16x8 wl = __builtin_bit_cast(f16x8, Ws(2 * g + 1, wn * 96 + i * 16 + r16));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[i][j], 0, 0, 0);
@@ -795,16 +795,13 @@ __global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mt
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (NBUF == 2) {
-      if (kt + 1 < nk) store_lds(cur ^ 1);
-      cur ^= 1;
-    }
     __syncthreads();
   }
 
-  // ---- epilogue, one 16-row slab of every wave per pass (32 rows x 192 columns staged in LDS, 25 KB): every thread then
-  // owns whole octets of a row (32 contiguous bytes per stream), like conv_tile_store
+  // ---- epilogue, one 16-row slab of every wave per pass (16 MW rows x 192 columns staged in LDS): every thread then owns whole
+  // octets of a row (32 contiguous bytes per stream), like conv_tile_store
   constexpr int SP = LBN + 4, OCT = LBN / 8;
+  static_assert(8 * (LBN + LBM_) * 16 >= 16 * MW * SP * 4, "the staged slab must fit in the main loop's LDS");
   float* stage = reinterpret_cast<float*>(smem);
   const size_t obase = (size_t)b * a.Lout;
 #pragma unroll
@@ -816,8 +813,8 @@ __global__ __launch_bounds__(256, 2) void linear_pair_kernel(ConvPArgs a, int mt
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 32 * OCT / 256; ++it) {
-      const int u = tid + 256 * it, lr = u / OCT, oc = u - lr * OCT;
+    for (int it = 0; it < 16 * MW * OCT / NTH; ++it) {
+      const int u = tid + NTH * it, lr = u / OCT, oc = u - lr * OCT;
       const int jr = j0 + (lr >> 4) * 64 + j * 16 + (lr & 15);
       if (jr < a.Lin) {
         const int co = n0 + oc * 8;
@@ -859,11 +856,16 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
   p.oshift0 = oshift; p.jcount = Lin; p.act = act;
   p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
   if (Cout % LBN == 0 && act != 0 && !(va_debug_flags_get() & 64)) {     // debug flag bit 6: the 128 x 96 conv tile instead
-    const int mtiles = (Lin + LBM - 1) / LBM, ntiles = Cout / LBN;
-    if (va_debug_flags_get() & 256)   // debug flag bit 8: two LDS stages (80 KB: whether two workgroups still share a CU is the question)
+    const int ntiles = Cout / LBN;
+    // debug flag bit 8: 256 x 192 tiles (512 threads, one workgroup per CU) — 30 % fewer operand bytes per flop, and measured
+    // SLOWER (48.8 vs 46.2 ms per forward): eight waves behind one barrier lose more than the L2 traffic saved
+    if (Lin >= 256 * 64 && (va_debug_flags_get() & 256)) {
+      const int mtiles = (Lin + 255) / 256;
+      VA_LAUNCH(linear_pair_kernel<4>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(512), 0, s, p, mtiles, ntiles);
+    } else {
+      const int mtiles = (Lin + 127) / 128;
       VA_LAUNCH(linear_pair_kernel<2>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
-    else
-      VA_LAUNCH(linear_pair_kernel<1>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
+    }
     return 0;
   }
   VA_LAUNCH((conv_pair_kernel<3, false>), dim3((Lin + BM - 1) / BM, Cout / BN, B), dim3(256), 0, s, p);
