@@ -293,6 +293,8 @@ def main():
         eng.start_sequence(None)
         L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), n_steps, 0xFF, tot, cnt,
                                            int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
+        outl = (C.c_int64 * 8)()
+        L.lib().vaura_profile_outliers(outl)     # intervals > 10x the kind's median (a stalled queue) are counted at the median
         per = {name: 1e3 * tot[bit] / max(1, cnt[bit]) for name, bit in kinds.items()}   # us per launch
         launches = {name: int(cnt[bit]) for name, bit in kinds.items()}
         total_us = {k: per[k] * launches[k] for k in per}
@@ -323,6 +325,7 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                            "kernel": f"{kname} = {dom}", "dominant_by": "total time over the decode loop",
+                           "stalled_intervals_counted_at_median": int(sum(outl)),
                            "share_of_loop_kernel_time": round(total_us[dom] / sum(total_us.values()), 4),
                            "algorithmic_bytes_per_launch": ab, "avg_us_per_launch": round(per[dom], 3),
                            "launches": launches[dom]}

@@ -206,6 +206,9 @@ typedef enum vaura_kernel_kind {
 } vaura_kernel_kind;
 int vaura_profile_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_steps, unsigned kind_mask,
                        double* total_ms_host, int64_t* launches_host, vaura_stream_t s);
+/* Launches of the calling thread's last vaura_profile_loop whose interval exceeded 10x their kind's median (a stalled queue, not
+ * the kernel): they were counted at the median in total_ms_host; per kind, HOST array of VAURA_K_COUNT entries.               */
+void vaura_profile_outliers(int64_t* per_kind);
 
 /* -------------------------------------------------------------------------------------------
  * op-level entry points (parity tests call the same kernels the step uses)                      */

@@ -135,6 +135,7 @@ SIGNATURES = {
     "vaura_step_graph_free": (None, [C.c_void_p]),
     "vaura_profile_loop": (C.c_int, [C.POINTER(Decoder), C.POINTER(Sampling), C.c_int, C.c_uint, C.POINTER(C.c_double),
                                      C.POINTER(C.c_int64), C.c_void_p]),
+    "vaura_profile_outliers": (None, [C.POINTER(C.c_int64)]),
     "vaura_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                              C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vaura_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
