@@ -589,6 +589,144 @@ __global__ __launch_bounds__(512) void vit_space_attn_mfma_kernel(const float* _
   }
 }
 
+// The same dataflow on fp16 pairs (x = hi + lo, 22 significand bits; three v_mfma_f32_16x16x32_f16 per product like every linear
+// layer of this file): 5x fewer matrix cycles than the exact-fp32 instruction.  K as hi / lo planes in the k-major image of the
+// GEMM kernels ([kq = d / 8][key] quads of 8 halves: the fragment read of a 16-lane group is 16 consecutive quads and the four
+// groups of a ds_read_b128 service set fall on different banks because 208 % 16 == 0); V TRANSPOSED ([d][key], row stride 432 B
+// = 27 x 16: conflict-free 8-byte reads) because O^T = V^T . P^T sums over keys: a lane's 8 k slots are keys 4g .. 4g+3 of two
+// adjacent key tiles — the registers it already holds — and the matching V^T fragment is two 8-byte reads.
+#define VP_KEYS (VS_NKT * 16)                      // 208
+#define VP_VSTRIDE 216                             // halves per V^T row (432 B)
+__global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair, int nf, int np,
+                                                                  int D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h8* Kh = reinterpret_cast<h8*>(smraw);                                   // [8][208]
+  h8* Kl = Kh + 8 * VP_KEYS;
+  _Float16* Vh = reinterpret_cast<_Float16*>(Kl + 8 * VP_KEYS);            // [64][216] (+ 16 halves of slack)
+  _Float16* Vl = Vh + VHD * VP_VSTRIDE + 16;
+  const int nk = np + 1;
+  const int h = blockIdx.x, f = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x;
+  const int L = 1 + nf * np;
+  const size_t row0 = (size_t)seg * L;
+  for (int u = tid; u < VP_KEYS * 8; u += 512) {       // K: one octet of one key per item
+    const int j = u >> 3, kq = u & 7;
+    h8 hi, lo;
+    if (j < nk) {
+      const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
+      const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + D + h * VHD + 8 * kq);
+      const f32x4 a = kp[0], b = kp[1];
+      const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { hi[i] = (_Float16)0.f; lo[i] = (_Float16)0.f; }
+    }
+    Kh[kq * VP_KEYS + j] = hi;
+    Kl[kq * VP_KEYS + j] = lo;
+  }
+  for (int u = tid; u < VP_VSTRIDE * (VHD / 4); u += 512) {   // V^T: 4 channels of one key per item (keys >= nk: zeros)
+    const int j = u / (VHD / 4), c = u % (VHD / 4);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (j < nk) {
+      const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
+      v = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + 2 * D + h * VHD)[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const _Float16 hi = (_Float16)v[i];
+      Vh[(4 * c + i) * VP_VSTRIDE + j] = hi;
+      Vl[(4 * c + i) * VP_VSTRIDE + j] = (_Float16)(v[i] - (float)hi);
+    }
+  }
+  if (tid < 32) { Vh[VHD * VP_VSTRIDE + (tid & 15)] = (_Float16)0.f; Vl[VHD * VP_VSTRIDE + (tid & 15)] = (_Float16)0.f; }
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int nqt = (np + 15) / 16;
+  for (int qt = wv; qt < nqt; qt += 8) {
+    const int qi = qt * 16 + r16;
+    const size_t qrow = row0 + 1 + (size_t)f * np + (qi < np ? qi : np - 1);
+    h8 qh[2], ql[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const f32x4* qp = reinterpret_cast<const f32x4*>(qkv + qrow * 3 * D + h * VHD + 32 * st + 8 * g);
+      const f32x4 a = qp[0], b = qp[1];
+      const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float x = v[i] * 0.125f;
+        qh[st][i] = (_Float16)x;
+        ql[st][i] = (_Float16)(x - (float)qh[st][i]);
+      }
+    }
+    f32x4 sc[VS_NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < VS_NKT; ++kt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const h8 kh = Kh[(4 * st + g) * VP_KEYS + kt * 16 + r16], kl = Kl[(4 * st + g) * VP_KEYS + kt * 16 + r16];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[st], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * 16 + 4 * g + r >= nk) acc[r] = -INFINITY;
+        m = fmaxf(m, acc[r]);
+      }
+      sc[kt] = acc;
+      if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < VS_NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(sc[kt][r] - m);
+        sc[kt][r] = e;
+        l += e;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    f32x4 oacc[VHD / 16];
+#pragma unroll
+    for (int dt = 0; dt < VHD / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mp = 0; mp < (VS_NKT + 1) / 2; ++mp) {       // 32 keys per instruction: key tiles 2 mp and 2 mp + 1
+      h8 ph, pl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p0 = sc[2 * mp][r], p1 = 2 * mp + 1 < VS_NKT ? sc[2 * mp + 1][r] : 0.f;
+        ph[r] = (_Float16)p0; pl[r] = (_Float16)(p0 - (float)ph[r]);
+        ph[r + 4] = (_Float16)p1; pl[r + 4] = (_Float16)(p1 - (float)ph[r + 4]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < VHD / 16; ++dt) {
+        const int off = (dt * 16 + r16) * VP_VSTRIDE + 32 * mp + 4 * g;
+        const h4 a0 = *reinterpret_cast<const h4*>(Vh + off), a1 = *reinterpret_cast<const h4*>(Vh + off + 16);
+        const h4 b0 = *reinterpret_cast<const h4*>(Vl + off), b1 = *reinterpret_cast<const h4*>(Vl + off + 16);
+        const h8 vh = h8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const h8 vl = h8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oacc[dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (qi < np) {
+#pragma unroll
+      for (int dt = 0; dt < VHD / 16; ++dt) put_pair4(out_pair, qrow, h * VHD + dt * 16 + 4 * g, D, oacc[dt] * inv);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- driver
 static int ln(const vaura_vit* v, const float* X, const float* w, const float* b, float* of, uint16_t* op, int64_t rows, int map, hipStream_t s) {
   VA_LAUNCH(vit_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, w, b, of, op, rows, v->dim, v->eps, map, v->n_frames, v->n_patches);
@@ -630,7 +768,17 @@ static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const
       VA_LAUNCH(vit_time_attn16_kernel<8>, dim3(v->heads / 2, v->n_patches, n_seg), dim3(256), 0, s, (const float*)v->ws_qkv, v->ws_a,
                 v->n_patches, D);
   } else {
-    if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & 128)) {     // debug flag bit 7: the one-thread-per-query kernel
+    if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & (128 | 2048))) {   // the fp16-pair MFMA kernel
+      const size_t sm = 2 * 8 * VP_KEYS * 16 + 2 * (VHD * VP_VSTRIDE + 16) * 2;      // 108 KB of the CU's 160 KB
+      static bool big_lds_p = false;
+      if (!big_lds_p) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
+          return VAURA_ERR_STATE;
+        big_lds_p = true;
+      }
+      VA_LAUNCH(vit_space_attn_pair_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(512), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
+                v->n_patches, D);
+    } else if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & 128)) {   // debug flag bit 11: exact-fp32 MFMA; bit 7: one thread per query
       const size_t sm = sizeof(float) * (size_t)(VS_NKT * 16) * (VSK + VSV);       // 108 KB of the CU's 160 KB
       static bool big_lds_m = false;
       if (!big_lds_m) {
