@@ -262,7 +262,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float*
       float sv[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if constexpr (FAST) {
+        if (FAST && a.act == 0) {
           sv[r] = snake_fast(v0[r], al0[r]);
           sv[r + 4] = snake_fast(v1[r], al1[r]);
         } else {
