@@ -376,6 +376,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        vdist.barrier()          # rank 0's extras above take a while: tear the group down together
         torch.distributed.destroy_process_group()
 
 
