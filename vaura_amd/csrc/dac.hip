@@ -565,33 +565,55 @@ __global__ __launch_bounds__(256, 2) void conv_mx8_kernel(ConvPArgs a) {
 }
 
 // z[b][t][c] = sum_k ( W_k[c][:] . codebook_k[code] + b_k[c] )   — quantizer.from_codes
+// A workgroup takes FC_NT frames of one clip: a thread keeps the 9 x 8 projection weights of a channel in registers and
+// reuses them for every frame (one workgroup per frame re-read the 295 KB of projection weights 1 760 times: 219 us).
+#define FC_NT 8
 __global__ __launch_bounds__(256) void from_codes_kernel(const int32_t* __restrict__ codes, const float* __restrict__ cb,
                                                           const float* __restrict__ pw, const float* __restrict__ pb,
                                                           float* __restrict__ z, int K, int T, int size, int dim, int latent,
                                                           int pairs) {
-  __shared__ float e[16][8];
-  const int t = blockIdx.x, b = blockIdx.y;
-  if (threadIdx.x < K * dim) {
-    const int k = threadIdx.x / dim, i = threadIdx.x % dim;
+  __shared__ float e[FC_NT][16][8];
+  const int t0 = blockIdx.x * FC_NT, b = blockIdx.y;
+  if (dim < 8) {     // slots i >= dim meet zero weights below: they must hold finite numbers
+    for (int u = threadIdx.x; u < FC_NT * 16 * 8; u += blockDim.x) (&e[0][0][0])[u] = 0.f;
+    __syncthreads();
+  }
+  for (int u = threadIdx.x; u < FC_NT * K * dim; u += blockDim.x) {
+    const int f = u / (K * dim), k = (u / dim) % K, i = u % dim;
+    const int t = t0 + f < T ? t0 + f : T - 1;
     const int code = codes[((size_t)b * K + k) * T + t];
-    e[k][i] = cb[((size_t)k * size + code) * dim + i];
+    e[f][k][i] = cb[((size_t)k * size + code) * dim + i];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < latent; c += blockDim.x) {
-    float o = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float* wr = pw + ((size_t)k * latent + c) * dim;
-      float zk = 0.f;
-      for (int i = 0; i < dim; ++i) zk = fmaf(wr[i], e[k][i], zk);
-      o += zk + pb[(size_t)k * latent + c];
+    float w[16][8], bias[16];       // fully unrolled with predicates: the arrays stay in registers (K <= 16, dim <= 8)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float* wr = pw + ((size_t)(k < K ? k : 0) * latent + c) * dim;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[k][i] = (k < K && i < dim) ? wr[i] : 0.f;      // a zero weight leaves the fmaf chain unchanged
+      bias[k] = k < K ? pb[(size_t)k * latent + c] : 0.f;
     }
-    if (pairs) {
-      const _Float16 h = (_Float16)o, l = (_Float16)(o - (float)h);
-      _Float16* zp = reinterpret_cast<_Float16*>(z) + ((((size_t)b * T + t) * (latent >> 3) + (c >> 3)) * 2) * 8 + (c & 7);
-      zp[0] = h;
-      zp[8] = l;
-    } else {
-      z[((size_t)b * T + t) * latent + c] = o;
+    for (int f = 0; f < FC_NT && t0 + f < T; ++f) {
+      float o = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < K) {
+          float zk = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) zk = fmaf(w[k][i], e[f][k][i], zk);
+          o += zk + bias[k];
+        }
+      }
+      const int t = t0 + f;
+      if (pairs) {
+        const _Float16 h = (_Float16)o, l = (_Float16)(o - (float)h);
+        _Float16* zp = reinterpret_cast<_Float16*>(z) + ((((size_t)b * T + t) * (latent >> 3) + (c >> 3)) * 2) * 8 + (c & 7);
+        zp[0] = h;
+        zp[8] = l;
+      } else {
+        z[((size_t)b * T + t) * latent + c] = o;
+      }
     }
   }
 }
@@ -638,6 +660,72 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const float* __restrict__
   d += __shfl_xor(d, 2, 64);
   d += __shfl_xor(d, 4, 64);
   if (sub == 0 && l < L) wav[(size_t)b * L + l] = tanhf(d + bias[0]);
+}
+
+// The same last conv with the 7-row window of every output staged ONCE: a workgroup takes 128 outputs, stages rows
+// l0-3 .. l0+130 of the activation (dequantised to fp32, row stride C + 4 floats = an odd number of 16-byte quads: the 16-byte
+// reads of consecutive outputs hit different banks) and two waves per channel half sum 7 x C/2 products per output in four
+// independent chains, with wave-uniform weight addresses (scalar loads).
+// The kernel above fetched every activation row seven times through L1 (275 us for 346 MB); C <= 128, C % 8 == 0.
+#define CO_TL 128
+__global__ __launch_bounds__(256) void conv_out_tiled_kernel(const float* __restrict__ act, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ wav, int L, int C,
+                                                              int pairs) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];      // (CO_TL + 6) x (C + 1) | CO_TL partial sums
+  const int b = blockIdx.y, l0 = blockIdx.x * CO_TL, tid = threadIdx.x;
+  const int SR = C + 4, oct = C >> 3;
+  for (int u = tid; u < (CO_TL + 6) * oct; u += 256) {
+    const int rr = u / oct, oc = u - rr * oct;
+    const int r = l0 - 3 + rr;
+    float x[8];
+    if (r < 0 || r >= L) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    } else if (pairs == 3) {
+      const uint8_t* q = reinterpret_cast<const uint8_t*>(act) + (size_t)b * L * C;
+      const int nsc = (C + 127) >> 7;
+      const uint8_t* sc = reinterpret_cast<const uint8_t*>(act) + mx8_scale_offset((size_t)gridDim.y * L * C) + (size_t)b * L * nsc * 4;
+      typedef int i32x2 __attribute__((ext_vector_type(2)));
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const i32x2 w8 = *reinterpret_cast<const i32x2*>(q + (size_t)r * C + 8 * oc);
+      const int e8 = sc[((size_t)r * nsc + (oc >> 4)) * 4 + ((oc >> 2) & 3)];
+      const float scl = __builtin_bit_cast(float, (uint32_t)e8 << 23);
+      const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w8.x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w8.x, true);
+      const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8(w8.y, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(w8.y, true);
+      x[0] = a0.x * scl; x[1] = a0.y * scl; x[2] = a1.x * scl; x[3] = a1.y * scl;
+      x[4] = a2.x * scl; x[5] = a2.y * scl; x[6] = a3.x * scl; x[7] = a3.y * scl;
+    } else if (pairs) {
+      const f16x8* pp = reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(act) + (((size_t)b * L + r) * oct + oc) * 16);
+      const f16x8 h = pp[0], lo = pp[1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (float)h[e] + (float)lo[e];
+    } else {
+      const f32x4* pp = reinterpret_cast<const f32x4*>(act + ((size_t)b * L + r) * C + 8 * oc);
+      const f32x4 a0 = pp[0], a1 = pp[1];
+      x[0] = a0[0]; x[1] = a0[1]; x[2] = a0[2]; x[3] = a0[3]; x[4] = a1[0]; x[5] = a1[1]; x[6] = a1[2]; x[7] = a1[3];
+    }
+    *reinterpret_cast<f32x4*>(rows + rr * SR + 8 * oc) = f32x4{x[0], x[1], x[2], x[3]};
+    *reinterpret_cast<f32x4*>(rows + rr * SR + 8 * oc + 4) = f32x4{x[4], x[5], x[6], x[7]};
+  }
+  __syncthreads();
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 7), lo_ = tid & 127;      // waves 0, 1: channels [0, C/2); waves 2, 3: the rest
+  const int c0 = half * (C >> 1), c1 = c0 + (C >> 1);
+  f32x4 d4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const f32x4* xr = reinterpret_cast<const f32x4*>(rows + (lo_ + t) * SR + c0);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w + (size_t)t * C + c0);
+#pragma unroll 4
+    for (int c = 0; c < (c1 - c0) / 4; ++c) {
+      const f32x4 x = xr[c], ww = wr[c];
+      d4[0] = fmaf(x[0], ww[0], d4[0]); d4[1] = fmaf(x[1], ww[1], d4[1]); d4[2] = fmaf(x[2], ww[2], d4[2]); d4[3] = fmaf(x[3], ww[3], d4[3]);
+    }
+  }
+  const float d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+  float* part = rows + (CO_TL + 6) * SR;
+  if (half) part[lo_] = d;
+  __syncthreads();
+  if (!half && l0 + lo_ < L) wav[(size_t)b * L + l0 + lo_] = tanhf((d + part[lo_]) + bias[0]);
 }
 
 // fp32 (rows, C) -> the activation format of a codec precision (op-level entry vaura_dac_conv below)
@@ -1011,7 +1099,7 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   if (pr < 0 || pr > 3) return VAURA_ERR_DTYPE;
   float* R = c->ws[0]; float* A = c->ws[1]; float* Y = c->ws[2]; float* Z = c->ws[3];
 
-  VA_LAUNCH(from_codes_kernel, dim3(T, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
+  VA_LAUNCH(from_codes_kernel, dim3((T + FC_NT - 1) / FC_NT, B), dim3(256), 0, s, codes, c->codebooks, c->out_proj_w, c->out_proj_b, Y,
                      c->n_codebooks, T, c->codebook_size, c->codebook_dim, c->latent_dim, pr ? 1 : 0);
   // conv_in: only the activated output is consumed (by the first transposed conv)
   int rc = launch_conv(c->conv_in, Y, nullptr, c->alpha_up[0], nullptr, A, B, T, pr, s);
@@ -1035,7 +1123,18 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   }
   const int C = c->conv_out.cin;
   if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
-  VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
+  if (C <= 128 && C % 8 == 0 && !(va_debug_flags_get() & 8192)) {     // debug flag bit 13: the untiled kernel
+    const size_t sm = sizeof(float) * ((size_t)(CO_TL + 6) * (C + 4) + CO_TL);
+    static bool big = false;
+    if (!big) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+        return VAURA_ERR_STATE;
+      big = true;
+    }
+    VA_LAUNCH(conv_out_tiled_kernel, dim3((L + CO_TL - 1) / CO_TL, B), dim3(256), sm, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
+  } else {
+    VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
+  }
   return 0;
 }
 

@@ -8,7 +8,7 @@
 // bit 5 = 64-row prefill GEMM workgroups only, bit 6 = row f2's linears on the 128 x 96 conv tile instead of linear_pair_kernel,
 // bit 7 = row f2's space attention with one thread per query instead of the MFMA kernel, bit 8 = 256-row tiles in
 // linear_pair_kernel, bit 9 = unsplit CLS attention, bit 10 = time attention with one thread per (head, frame),
-// bit 11 = space attention on the exact-fp32 MFMA instead of fp16 pairs
+// bit 11 = space attention on the exact-fp32 MFMA instead of fp16 pairs, bit 13 = the codec's last conv without the LDS window
 unsigned va_debug_flags = 0;
 unsigned va_debug_flags_get() { return va_debug_flags; }
 
