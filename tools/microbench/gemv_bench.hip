@@ -184,6 +184,13 @@ int main(int argc, char** argv) {
   G3("   qkv <3,16,1> 288 WG x1024", 3, 16, 1, E3_STORE, true, 1, 0, 288, 4608, false, false, bq);
   G3("   qkv <3,16,2> 144 WG x1024", 3, 16, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
   G3("   qkv <3,16,4> 72 WG x1024", 3, 16, 4, E3_STORE, true, 1, 0, 72, 4608, false, false, bq);
+  // x as fp32 split in registers (timing only): product instances vs the same with ABL 16, and the 2-plane load-only bound
+  G3("fx qkv <6,8,2> product shape", 6, 8, 2, E3_STORE, true, 1, 0, 144, 4608, false, false, bq);
+  G3("fx qkv <6,8,2> fp32 x split in registers", 6, 8, 2, E3_STORE, true, 1, 16, 144, 4608, false, false, bq);
+  G3("fx w13 <6,8,2> product shape", 6, 8, 2, E3_SWIGLU, true, 1, 0, 256, 4096, false, true, b13);
+  G3("fx w13 <6,8,2> fp32 x split in registers", 6, 8, 2, E3_SWIGLU, true, 1, 16, 256, 4096, false, true, b13);
+  G3("fx heads <6,8,3> product shape", 6, 8, 3, E3_LOGITS, true, 1, 0, 192, 9216, false, false, bh);
+  G3("fx heads <6,8,3> fp32 x split in registers", 6, 8, 3, E3_LOGITS, true, 1, 16, 192, 9216, false, false, bh);
   G3("g3 wo  <6,8,1> resid+split", 6, 8, 1, E3_RESID, false, 1, 0, 96, 1536, true, true, bo);
   G3("   wo  <3,16,1>", 3, 16, 1, E3_RESID, false, 1, 0, 96, 1536, true, true, bo);
   G3("g3 w13 <6,8,2> swiglu", 6, 8, 2, E3_SWIGLU, true, 1, 0, 256, 4096, false, true, b13);

@@ -215,7 +215,8 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 }
 
 // ABL: ablation bits for tools/microbench only (0 in the product): 1 = no MFMA, 2 = no x loads, 4 = no weight
-// loads, 8 = same k-slice order in every workgroup.
+// loads, 8 = same k-slice order in every workgroup, 16 = TIMING of "activations as fp32 (4 B per element), split into the
+// three bf16 planes in registers by every workgroup": two of the three plane loads + split3_w8 per k-group (numbers meaningless).
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
 // been consumed, for depths whose three planes do not fit the register budget at once)
 // WT = storage of the weights: 0 bf16 MFMA tiles, 1 fp8 tile pairs (+ row scales), 2 fp32 MFMA tiles (two 16-byte halves per
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < ((ABL & 16) ? 2 : 3); ++p)
         xb[b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
                                       : __builtin_amdgcn_raw_buffer_load_b128(
                                             xrs, lane16, (int)(((rb * 3 + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
@@ -343,6 +344,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       }
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
+        if constexpr (ABL & 16) {
+          bf16x8 s0, s1, s2;
+          split3_w8(xb[b % NXB][g][0], xb[b % NXB][g][1], s0, s1, s2);
+          xb[b % NXB][g][0] = __builtin_bit_cast(u32x4, s0);
+          xb[b % NXB][g][1] = __builtin_bit_cast(u32x4, s1);
+          xb[b % NXB][g][2] = __builtin_bit_cast(u32x4, s2);
+        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           bf16x8 wf[F32 ? 3 : 1];
