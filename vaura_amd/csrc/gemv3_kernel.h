@@ -264,7 +264,10 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   // per-lane address part (the split-rows index of lane (m, q) is uniform + 16 * q + m = uniform + lane).  With flat 64-bit
   // addresses hipcc kept a VGPR pair per 4 KB of stream alive (spills in the fp32-weight instances) and spent VALU on them.
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, -16, 0x00020000);
+  // the activation descriptor ends with the last row block: lanes of batch rows that do not exist (a decode step of fewer
+  // than 16 rows: configs[3] has 4, a single clip 1 or 2) are sent out of range — they read zeros, as the padding rows of the
+  // planes would give them, WITHOUT moving the bytes: every workgroup pulls rows/16 of the 147 KB instead of all of it
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * 3 * (K / 8) * 256, 0x00020000);
   const int lane16 = lane * 16;
 
   // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
@@ -293,13 +296,14 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   constexpr int NXB = XB > 1 ? 2 : 1;   // with several batches two are in flight (double buffer)
   u32x4 xb[NXB][GB][3];
   auto load_x = [&](int rb, int b) {
+    const int xl16 = rb * 16 + m < a.rows ? lane16 : 0x7ffffff0;
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int p = 0; p < ((ABL & 16) ? 2 : 3); ++p)
         xb[b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
                                       : __builtin_amdgcn_raw_buffer_load_b128(
-                                            xrs, lane16, (int)(((rb * 3 + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
+                                            xrs, xl16, (int)(((rb * 3 + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
   };
 
   auto row_block = [&](const int rb, const bool first) {
@@ -458,9 +462,9 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   const int w = (wid + tile) % NW;            // de-phase the k-slices across workgroups
   const int la = lane & 7, sb = (lane >> 3) & 1, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, -16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * 3 * (K / 8) * 256, 0x00020000);
   const int voffw0 = (la + 16 * q) * 16 + sb * BS;          // weight rows 0..7 of the tile; + 128 bytes for rows 8..15
-  const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;
+  const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;   // batch row la + 8 h of the block (out of range below when it does not exist)
 
   u32x4 wb[NB][GB][2][WH];
   u32x4 xb[NB][GB][3];
@@ -480,7 +484,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
     for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        xb[b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, voffx, ((rb * 3 + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
+        xb[b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, rb * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0,
+                                                                 ((rb * 3 + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
   };
 
   for (int rb = 0; rb < a.R; ++rb) {
