@@ -110,6 +110,25 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
     }
 
 
+def self_launch(n: int, argv) -> int:
+    """Run this script as `n` ranks under torch.distributed.run (child processes) and return their exit status."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if have < n and env.get("VAURA_BENCH_SHARE_GPU") != "1":
+        print(f"bench.py: --gpus {n} but this box has {have} GPU(s); set VAURA_BENCH_SHARE_GPU=1 VAURA_BENCH_BACKEND=gloo to exercise "
+              "the control flow on shared GPUs (never a reported number)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +151,12 @@ def main():
     ap.add_argument("--no-plugin", action="store_true", help="skip timing VAURAModel.generate() through the plugin classes")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` from a plain shell: start the N ranks as FRESH child processes (one per GPU, RCCL),
+        # before anything in this process has touched the GPU (counting devices does not initialise HIP on this image; an
+        # exec from a GPU-initialised process would not be allowed), relay rank 0's JSON line and exit with their status.
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     # VAURA_BENCH_BACKEND=gloo + VAURA_BENCH_SHARE_GPU=1: exercise the multi-rank control flow on a 1-GPU box
     # (all ranks on cuda:0, collectives on host copies).  Never used for reported numbers.
@@ -373,6 +398,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale, B)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
 
+    if os.environ.get("VAURA_BENCH_SHARE_GPU") == "1" and world > 1:
+        out["shared_gpu_control_flow_only"] = True      # ranks shared a GPU: the number says nothing about scaling
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

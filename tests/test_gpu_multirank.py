@@ -46,3 +46,49 @@ def test_two_ranks_gather_what_one_rank_generates(tmp_path, total):
     assert a["codes"].shape == (total, 9, 24) and a["codes"].min() >= 0 and a["codes"].max() < 1024
     assert np.array_equal(a["codes"], b["codes"])
     assert np.array_equal(a["wav"], b["wav"]) and np.isfinite(a["wav"]).all() and np.abs(a["wav"]).max() > 0
+
+
+def _torchrun(world, args, env, timeout):
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *args], env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_eight_ranks_control_flow_configs2_shape(tmp_path):
+    """BASELINE configs[2]'s control flow at world 8: 64 clips -> 8 per rank (and a ragged 61 -> 8,8,8,8,8,7,7,7), tiny model,
+    every rank a fresh process running the product path, the final gather of DEVICE tensors in global clip order == what one
+    process generates.  With fewer than 8 GPUs all ranks share cuda:0 and the collectives run over gloo on host copies; with 8
+    GPUs the same test runs over RCCL (that run is the driver's)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(HERE, "shard_worker.py")
+    shared = torch.cuda.device_count() < 8
+    env8 = dict(env, VAURA_BENCH_BACKEND="gloo", VAURA_BENCH_SHARE_GPU="1") if shared else env
+    for total in (64, 61):
+        one = tmp_path / f"one{total}.npz"
+        r = subprocess.run([sys.executable, worker, "--out", str(one), "--total", str(total), "--layers", "2", "--frames", "8"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        eight = tmp_path / f"eight{total}.npz"
+        r = _torchrun(8, [worker, "--out", str(eight), "--total", str(total), "--layers", "2", "--frames", "8"], env8, 1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        a, b = np.load(one), np.load(eight)
+        assert int(b["world"]) == 8 and a["codes"].shape == (total, 9, 8)
+        assert np.array_equal(a["codes"], b["codes"]) and np.array_equal(a["wav"], b["wav"])
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (WORLD_SIZE unset) starts its two ranks as fresh child processes and relays
+    rank 0's JSON line (the form the round-end driver uses for N = 1).  On a 1-GPU box the ranks share the GPU (control flow only,
+    flagged in the record); with >= 2 GPUs this is the real RCCL run."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if torch.cuda.device_count() < 2:
+        env.update(VAURA_BENCH_BACKEND="gloo", VAURA_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["value"] > 0
+    assert rec.get("shared_gpu_control_flow_only", False) == (torch.cuda.device_count() < 2)

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../include/vaura_hip.h"
 
@@ -54,7 +55,7 @@ template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * 
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights bf16|f32] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
-  int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16, rounds = 0;
+  int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1;
   std::vector<unsigned> variants{0u};
   for (int i = 2; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--time")) rounds = atoi(argv[i + 1]);
@@ -66,6 +67,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[i + 1]);
   }
   void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
@@ -109,6 +111,63 @@ int main(int argc, char** argv) {
   vaura_sampling sp{1, 1.0f, 250, 0.0f, 6.0f, 1234ull, 0ull};
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CK(hipDeviceSynchronize());
+  if (chains > 1) {
+    // Concurrency experiment: the batch as `chains` independent decode chains (rows / chains rows each: clips are independent,
+    // SURVEY.md 8e), each with its own stream, step graph, K/V cache and workspaces, sharing the weights; one host thread per
+    // chain replays its graph.  Wall time until ALL chains have finished their 228 steps, against one chain with all rows.
+    auto gbuild = (int (*)(const vaura_decoder*, const vaura_sampling*, vaura_stream_t, vaura_step_graph_t*))dlsym(lib, "vaura_step_graph_build");
+    auto gloop = (int (*)(const vaura_decoder*, const vaura_sampling*, int, int, vaura_step_graph_t, vaura_stream_t))dlsym(lib, "vaura_generate_loop");
+    const int crow = rows / chains, cb = crow / 2, crp = (crow + 15) / 16 * 16;
+    std::vector<vaura_decoder> ds(chains, d);
+    std::vector<hipStream_t> sts(chains);
+    std::vector<vaura_step_graph_t> gs(chains);
+    for (int c = 0; c < chains; ++c) {
+      vaura_decoder& e = ds[c];
+      e.batch = cb; e.rows = crow;
+      e.cond_proj = dev_f32((size_t)((crow * Tv + 15) / 16 * 16) * 512, 0.3f);
+      e.kcache = dev_f32((size_t)NL * crow * H * ML * 96, 0.5f); e.vcache = dev_f32((size_t)NL * crow * H * ML * 96, 0.5f);
+      int32_t* sq; CK(hipMalloc(&sq, (size_t)cb * K * S * 4)); fill_i32<<<64, 256>>>(sq, (size_t)cb * K * S, 7);
+      e.seq = sq; e.state = dev_zero<int32_t>(4);
+      e.ws_h = dev_zero<float>((size_t)crp * D); e.ws_qkv = dev_zero<float>((size_t)crp * 3 * D); e.ws_qkv2 = dev_zero<float>((size_t)crp * 3 * D);
+      e.ws_attn = dev_zero<float>((size_t)crp * D); e.ws_ffn = dev_zero<float>((size_t)crp * F); e.ws_logits = dev_zero<float>((size_t)crow * K * V);
+      e.ws_h_split = dev_zero<uint16_t>((size_t)crp * 3 * D); e.ws_attn_split = dev_zero<uint16_t>((size_t)crp * 3 * D);
+      e.ws_ffn_split = dev_zero<uint16_t>((size_t)crp * 3 * F); e.ws_ss = dev_zero<float>((size_t)(crp / 16) * (D / 16) * 16);
+      e.ws_sync = nullptr;
+      CK(hipStreamCreateWithFlags(&sts[c], hipStreamNonBlocking));
+      CK(hipDeviceSynchronize());
+      const int rc = gbuild(&e, &sp, sts[c], &gs[c]);
+      if (rc) { fprintf(stderr, "graph build chain %d: %d\n", c, rc); return 3; }
+    }
+    const int n = S - 1;
+    const bool one_thread = getenv("PMC_ONE_THREAD") != nullptr;
+    std::vector<float> wall;
+    for (int r = -1; r < (rounds > 0 ? rounds : 5); ++r) {
+      int32_t zero[4] = {0, 0, 0, 1};
+      for (int c = 0; c < chains; ++c) CK(hipMemcpy(ds[c].state, zero, sizeof zero, hipMemcpyHostToDevice));
+      CK(hipDeviceSynchronize());
+      const auto h0 = std::chrono::steady_clock::now();
+      if (one_thread) {
+        // one host thread, steps interleaved over the chains
+        for (int i = 0; i < n; ++i)
+          for (int c = 0; c < chains; ++c)
+            if (gloop(&ds[c], &sp, 0, 1, gs[c], sts[c])) { fprintf(stderr, "loop\n"); return 3; }
+      } else {
+        std::vector<std::thread> th;
+        for (int c = 0; c < chains; ++c)
+          th.emplace_back([&, c] { (void)hipSetDevice(0); if (gloop(&ds[c], &sp, 0, n, gs[c], sts[c])) fprintf(stderr, "loop failed\n"); });
+        for (auto& t : th) t.join();
+      }
+      const auto h1 = std::chrono::steady_clock::now();
+      CK(hipDeviceSynchronize());
+      const auto h2 = std::chrono::steady_clock::now();
+      if (r >= 0) wall.push_back(std::chrono::duration<float, std::milli>(h2 - h0).count());
+      if (r == 0) printf("host enqueue %.3f ms, wall %.3f ms\n", std::chrono::duration<float, std::milli>(h1 - h0).count(), wall.back());
+    }
+    std::sort(wall.begin(), wall.end());
+    printf("chains %d x rows %d (%s): %d-step loops of ALL chains: median wall %.3f ms, min %.3f ms\n", chains, crow,
+           one_thread ? "one host thread" : "one host thread per chain", n, wall[wall.size() / 2], wall[0]);
+    return 0;
+  }
   if (rounds > 0) {
     auto gbuild = (int (*)(const vaura_decoder*, const vaura_sampling*, vaura_stream_t, vaura_step_graph_t*))dlsym(lib, "vaura_step_graph_build");
     auto gloop = (int (*)(const vaura_decoder*, const vaura_sampling*, int, int, vaura_step_graph_t, vaura_stream_t))dlsym(lib, "vaura_generate_loop");

@@ -64,6 +64,18 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 
 inline hipStream_t as_stream(vaura_stream_t s) { return (hipStream_t)s; }
 
+// Opt a kernel into more than 64 KB of dynamic LDS — once per DEVICE (function attributes are per device: an engine on a second
+// GPU of the same process needs its own call).  `done` is a per-call-site bit mask of devices already set up.
+inline int va_big_lds_once(const void* fn, size_t bytes, unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return VAURA_ERR_STATE;
+  if (!((*done >> dev) & 1ull)) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return VAURA_ERR_STATE;
+    *done |= 1ull << dev;
+  }
+  return 0;
+}
+
 // ---- launchers implemented across the .hip files (host side, internal)
 int va_launch_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
                    int64_t rows, int64_t N, int64_t K, int epilogue, float eps, hipStream_t s);

@@ -1125,12 +1125,8 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   if (c->conv_out.cout != 1 || c->conv_out.taps != 7 || (C % 4)) return VAURA_ERR_SHAPE;
   if (C <= 128 && C % 8 == 0 && !(va_debug_flags_get() & 8192)) {     // debug flag bit 13: the untiled kernel
     const size_t sm = sizeof(float) * ((size_t)(CO_TL + 6) * (C + 4) + CO_TL);
-    static bool big = false;
-    if (!big) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_out_tiled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-        return VAURA_ERR_STATE;
-      big = true;
-    }
+    static unsigned long long big = 0;
+    if (va_big_lds_once(reinterpret_cast<const void*>(conv_out_tiled_kernel), 80 * 1024, &big)) return VAURA_ERR_STATE;
     VA_LAUNCH(conv_out_tiled_kernel, dim3((L + CO_TL - 1) / CO_TL, B), dim3(256), sm, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
   } else {
     VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);

@@ -770,32 +770,20 @@ static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const
   } else {
     if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & (128 | 2048))) {   // the fp16-pair MFMA kernel
       const size_t sm = 2 * 8 * VP_KEYS * 16 + 2 * (VHD * VP_VSTRIDE + 16) * 2;      // 108 KB of the CU's 160 KB
-      static bool big_lds_p = false;
-      if (!big_lds_p) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-          return VAURA_ERR_STATE;
-        big_lds_p = true;
-      }
+      static unsigned long long big_lds_p = 0;
+      if (va_big_lds_once(reinterpret_cast<const void*>(vit_space_attn_pair_kernel), sm, &big_lds_p)) return VAURA_ERR_STATE;
       VA_LAUNCH(vit_space_attn_pair_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(512), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
                 v->n_patches, D);
     } else if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & 128)) {   // debug flag bit 11: exact-fp32 MFMA; bit 7: one thread per query
       const size_t sm = sizeof(float) * (size_t)(VS_NKT * 16) * (VSK + VSV);       // 108 KB of the CU's 160 KB
-      static bool big_lds_m = false;
-      if (!big_lds_m) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-          return VAURA_ERR_STATE;
-        big_lds_m = true;
-      }
+      static unsigned long long big_lds_m = 0;
+      if (va_big_lds_once(reinterpret_cast<const void*>(vit_space_attn_mfma_kernel), sm, &big_lds_m)) return VAURA_ERR_STATE;
       VA_LAUNCH(vit_space_attn_mfma_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(512), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
                 v->n_patches, D);
     } else {
       const size_t sm = sizeof(float) * 2 * (size_t)(v->n_patches + 1) * VHD;      // 100.9 KB of the CU's 160 KB
-      static bool big_lds = false;
-      if (!big_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(vit_space_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess)
-          return VAURA_ERR_STATE;
-        big_lds = true;
-      }
+      static unsigned long long big_lds = 0;
+      if (va_big_lds_once(reinterpret_cast<const void*>(vit_space_attn_kernel), sm, &big_lds)) return VAURA_ERR_STATE;
       VA_LAUNCH(vit_space_attn_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(256), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
                 v->n_patches, D);
     }

@@ -181,6 +181,7 @@ class DecoderEngine:
         rows = 2 * batch if cfg_on else batch
         max_len = (max(S, block_size or 0) + 31) // 32 * 32
         key = (batch, timesteps, n_cond_tokens, cfg_on, tokens_per_frame, max_len)
+        self._fc = None                       # whoever prepares the engine is about to overwrite the K/V cache
         if self._shape == key:
             return
         with torch.cuda.device(self.dev):
@@ -248,6 +249,7 @@ class DecoderEngine:
         """feats (B, Tv, 768) fp32 on device.  Rows [B, 2B) get the CFG null embedding
         (models/vaura_model.py:790-793) when the engine was prepared with cfg_on."""
         assert self.dec is not None
+        self._fc = None
         B, Tv, Cin = feats.shape
         assert B == self.batch and Tv == self.Tv and Cin == self.cfg.cond_in
         x = feats.to(self.dev, torch.float32)
@@ -327,6 +329,7 @@ class DecoderEngine:
     def _reset_state(self):
         """position / arrivals / step back to 0 and a NEW sequence id in state[3]: the epochs of the in-launch hand-offs
         (mlp_fused.h) are derived from (sequence id, position, layer) and must never repeat on live flag words."""
+        self._fc = None                       # position 0 again: a cached forward() prefix no longer matches the K/V cache
         DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x7FF
         self.state.zero_()                                   # two tiny device fills: no host-device synchronisation
         self.state[3:4].fill_(DecoderEngine._sequence_id)
@@ -406,7 +409,7 @@ class DecoderEngine:
             self.cached_forward_steps = getattr(self, "cached_forward_steps", 0) + 1
         st["idx"][:, :, n0:Lq] = idx[:, :, n0:Lq]
         st["n"] = Lq
-        return st["logits"][:, :, :Lq]
+        return st["logits"][:, :, :Lq].clone()      # a copy: the cache must survive in-place edits by the caller
 
     # ------------------------------------------------------------------ op-level access (tests)
     def logits_all_positions(self, idx: torch.Tensor, feats: torch.Tensor, tokens_per_frame: int = 7) -> torch.Tensor:

@@ -37,6 +37,10 @@ class MotionFormer(nn.Module):
                 not factorize_space_time:
             raise L.VauraHipError("vaura_amd.feature_extractor.MotionFormer builds the avclip_vggsound.yaml configuration only "
                                   "(factorize_space_time, TransformerEncoderLayer spatial aggregation, Identity in time, no global repr)")
+        if not extract_features:
+            raise L.VauraHipError("vaura_amd.feature_extractor.MotionFormer returns features only (extract_features=True, as in "
+                                  "configs/modules/feature_extractors/avclip_vggsound.yaml:4); the classification head of "
+                                  "motionformer.py:311-320 is not built")
         self.extract_features = extract_features
         self.ckpt_path = ckpt_path
         self.cfg = synth.FULL_AVCLIP
