@@ -71,6 +71,22 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
         cd = CachedDecoder(dec, cond, n_steps + 1)
         tok = torch.randint(0, 1024, (rows, K_CB), generator=g)
         cd.step(tok)                      # warm-up (allocations, thread pool)
+        # the host's best: torch's default (one thread per logical CPU) oversubscribes a 16-row GEMV; sweep and keep the fastest
+        default_threads = torch.get_num_threads()
+        sweep = {}
+        for nt in sorted({8, 16, 32, 64, max(1, (os.cpu_count() or 1) // 2), os.cpu_count() or 1, default_threads}):
+            if nt > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(nt)
+            cd.pos = 1
+            cd.step(tok)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                cd.step(tok)
+            sweep[nt] = (time.perf_counter() - t0) / 2
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        cd.pos = 1
         reps = 6
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -98,7 +114,9 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
         for i in range(1, len(xs)):
             total += 0.5 * (ys[i] + ys[i - 1]) * (xs[i] - xs[i - 1])
     return {
-        "value": round(cached_tok_s, 2), "unit": "codec tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": round(cached_tok_s, 2), "unit": "codec tokens/s", "cores": best, "kind": "port",
+        "thread_sweep_ms_per_step": {str(k): round(1e3 * v, 1) for k, v in sweep.items()},
+        "logical_cpus": os.cpu_count(), "torch_default_threads": default_threads,
         "sample": (f"oracle/ fp32 torch-CPU port with a K/V cache, the GPU's batch ({n_clips} clips, rows={rows}, cfg {cfg_scale}): "
                    f"{reps} steps at cache length ~1 ({t_early * 1e3:.0f} ms/step) and {reps} at ~{n_steps - reps} "
                    f"({t_late * 1e3:.0f} ms/step), mean x {n_steps} steps = {cached_s:.1f} s per batch; decode loop only (codec excluded)"),
@@ -106,7 +124,9 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
             "value": round(K_CB * T_FRAMES / total, 2), "unit": "codec tokens/s", "clips": 1,
             "how": (f"cache-less full-prefix forward (what the reference runs every step) of ONE clip (rows={cond1.shape[0]}) timed at "
                     f"L={pts} -> {['%.3f' % t for t in ts]} s, piecewise-linear integral over {n_steps} steps = {total:.1f} s per clip: "
-                    "an extrapolation, not a full run")},
+                    "an extrapolation, not a full run.  Calibration of the method (build container, 8 threads, BASELINE.md 2): the same "
+                    "integral over the reference's own timed forwards (L=1: 80 ms, 64: 403 ms, 228: 909 ms) gives 122.8 s per clip "
+                    "against 110.5 s for the full reference generate() run there: the extrapolation reads ~11 % slow")},
     }
 
 
@@ -392,6 +412,38 @@ def main():
                                      "tokens_per_s": round(B * K_CB * T_FRAMES / t_plugin, 1),
                                      "delta_ms_vs_engines": round(1e3 * t_plugin - (t_loop + t_codec), 3)}
             del model, r
+            torch.cuda.empty_cache()
+
+        # ---- the step BEFORE the hot path included (row f2): raw frames (B, 4, 3, 16, 224, 224) -> Segment-AVCLIP features ->
+        #      decode loop -> codec, what scripts/generate.py:302-325 runs per batch.  Not in `value` (SURVEY.md 8d excludes
+        #      feature extraction from the metric's wall time); reported beside it.
+        if not long_ctx and not args.no_plugin:
+            from vaura_amd.engine import AvclipEngine
+            fx = AvclipEngine(synth.FULL_AVCLIP, synth.avclip_state_dict(seed=0), dev)
+            frames = synth.video_frames(B, TV // 8, seed=0, first_clip=first).to(dev)
+
+            def e2e():
+                f = fx.forward(frames).reshape(B, TV, cfg.cond_in)
+                return codec.decode(eng.generate_codes(f, T_FRAMES, **kw))
+            for _ in range(2):
+                e2e()
+            torch.cuda.synchronize(dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ev[0].record()
+                f = fx.forward(frames)
+                ev[1].record()
+                w = codec.decode(eng.generate_codes(f.reshape(B, TV, cfg.cond_in), T_FRAMES, **kw))
+            ev[2].record()
+            torch.cuda.synchronize(dev)
+            t_e2e = (time.perf_counter() - t0) / reps
+            out["end_to_end_with_extractor"] = {"what": "raw frames -> Segment-AVCLIP (divided space-time ViT-B/16, 4 segments per clip) -> decode loop "
+                                                        "-> DAC decode; engine level, same storage as `value`",
+                                                "ms_per_step": round(1e3 * t_e2e, 3), "extractor_ms_last_step": round(ev[0].elapsed_time(ev[1]), 3),
+                                                "tokens_per_s": round(B * K_CB * T_FRAMES / t_e2e, 1)}
+            assert w.shape == (B, 1, T_FRAMES * HOP)
+            del fx, frames, f, w
             torch.cuda.empty_cache()
 
         if world == 1 and not args.no_cpu_baseline and not long_ctx:

@@ -134,10 +134,8 @@ typedef struct vaura_decoder {
   const float* first_norm;   /* layers[0].attn_norm (device), gain applied by the embed kernel */
   float*    ws_attn_part;    /* optional (rows, n_head, 8, head_dim + 8): partials of the range-split attention used when
                                 rows*n_head < 256 and max_len > 256 (vaura_attention_splits); NULL -> never split       */
-  uint32_t* ws_sync;         /* optional 1025 words, zeroed once at allocation: [0, 1024) hand-off flag words of the (experimental) fused MLP launch
-                                (one per workgroup; epochs from state[0], state[3]), [1024] = timeout word (non-zero after a
-                                launch whose bounded spin gave up: results of that step are invalid).  NULL -> two launches per MLP.
-                                state[3] must hold a sequence id that changes whenever state[0] is reset (any value).        */
+  uint32_t* ws_sync;         /* reserved (NULL): round 2's experimental one-launch MLP used it for hand-off flags; that experiment was measured
+                                no faster than two launches (profiles/r02_ab_fused_mlp.txt) and removed in round 3                    */
 } vaura_decoder;
 
 /* -------------------------------------------------------------------------------------------
@@ -380,10 +378,9 @@ int vaura_avclip_forward(const vaura_vit* v, const float* frames, int n_seg, flo
 size_t vaura_avclip_workspace_bytes(const vaura_vit* v, int n_seg, int which);
 
 /* Measurement aid (tools/pmc_driver, A/B timing): selects kernel variants for launches enqueued (or graphs captured) afterwards.
- * bit 0: wo / w2 GEMVs as one workgroup per column tile instead of the row-split pair; bit 2: the MLP as ONE fused launch with an
- * in-launch hand-off (experiment, also env VAURA_FUSED_MLP=1; needs ws_sync and a 256-CU device with no other spinning kernel);
- * bit 3: that launch without its acquire fence (timing experiment only); bit 4: prefill attention as one workgroup per position
- * instead of the MFMA kernel.  0 = the product configuration.                             */
+ * bit 0: wo / w2 GEMVs as one workgroup per column tile instead of the row-split pair; bit 4: prefill attention as one workgroup
+ * per position instead of the MFMA kernel (tools/README.md lists every bit).
+ * 0 = the product configuration.                                                          */
 void vaura_set_debug_flags(unsigned flags);
 
 const char* vaura_version(void);

@@ -514,30 +514,6 @@ def test_dac_decode_block_scaled_fp8_against_its_emulation():
     assert rms_model > 1e-4
 
 
-def test_fused_mlp_launch_is_token_exact(tiny_sampler_sd):
-    """The experimental one-launch MLP (csrc/mlp_fused.h: in-launch hand-off between w1|w3 and w2, debug flag bit 2; measured no
-    faster than two launches, profiles/r02_ab_fused_mlp.txt) computes the same numbers: tokens identical to the product path for
-    16 rows (two row halves) and for 4 rows (one), and its bounded spin never gave up."""
-    from vaura_amd import _lib as L
-    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
-        pytest.skip("the fused launch needs a 256-CU device")
-    eng = DecoderEngine(synth.tiny_sampler(2), tiny_sampler_sd, DEV, wdtype="bf16")
-    feats = synth.video_features(8, seed=12).to(DEV)
-    kw = dict(use_sampling=True, top_k=250, cfg_scale=6.0, seed=3)
-    ref16 = eng.generate_codes(feats, 24, **kw).cpu()
-    ref4 = eng.generate_codes(feats[:4], 24, use_graph=False).cpu()
-    L.lib().vaura_set_debug_flags(4)
-    try:
-        eng._graph_key = None                     # the captured step graph holds the kernel choice
-        got16 = eng.generate_codes(feats, 24, **kw).cpu()
-        got4 = eng.generate_codes(feats[:4], 24, use_graph=False).cpu()
-        eng.check_sync_timeouts()
-    finally:
-        L.lib().vaura_set_debug_flags(0)
-        eng._graph_key = None
-    assert torch.equal(got16, ref16) and torch.equal(got4, ref4)
-
-
 def test_configs4_per_gpu_shape_fp8_weights_and_mx8_codec(full_sampler_sd):
     """BASELINE configs[4] at its per-GPU shape: 16 clips = 32 decoder rows (two row blocks), full depth, fp8 weights for
     QKV / MLP, block-scaled fp8 codec.  (1) Tokens: the fp8 engine IS the bf16 engine on the dequantised checkpoint (same real

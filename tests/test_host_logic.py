@@ -325,3 +325,35 @@ def test_mx8_weight_stream_and_activation_rule():
     assert torch.equal(quant.mx8_effective_activation(q), q) and bool((q[3] == 0).all())
     rel = ((q - x).abs().reshape(-1, 32).amax(1) / x.abs().reshape(-1, 32).amax(1).clamp_min(1e-30))
     assert float(rel.max()) <= 2.0 ** -4 + 1e-6           # half an e4m3 step (3 mantissa bits) of the block maximum
+
+
+def test_load_from_checkpoint_like_the_reference_driver(tmp_path):
+    """scripts/generate.py:208-212: ``VAURAModel.load_from_checkpoint(ckpt, hparams_file=hparams.yaml, map_location=device)`` on a
+    Lightning-shaped file whose hparams name the REFERENCE's plugin classes: they are mapped onto this package's plugins, the
+    codec and the extractor take their weights from the checkpoint's own state_dict, every tensor arrives, the extractor's
+    unused 2-D patch embedding is dropped, and anything else that does not fit fails the (strict) load."""
+    from ckpt_fixture import write_checkpoint
+    from vaura_amd.model import VAURAModel
+    cfg = synth.tiny_sampler(2)
+    ckpt, hp, (sd_s, sd_c, sd_v) = write_checkpoint(str(tmp_path), cfg)
+    m = VAURAModel.load_from_checkpoint(ckpt, hparams_file=hp, map_location="cpu")
+    assert type(m.sampler).__module__ == "vaura_amd.sampler" and type(m.audio_encoder).__module__ == "vaura_amd.codec"
+    assert type(m.visual_feature_extractor).__module__ == "vaura_amd.feature_extractor" and m.flatten_vis_feats and not m.training
+    got = m.state_dict()
+    for pre, sd in (("sampler.", sd_s), ("audio_encoder.model.", sd_c), ("visual_feature_extractor.", sd_v)):
+        for k, v in sd.items():
+            assert torch.equal(got[pre + k], v.float()), pre + k
+    assert m.visual_feature_extractor._loaded and m.num_codebooks == 9
+    # without an hparams file the checkpoint's own hyper_parameters are used; keyword arguments override them
+    m2 = VAURAModel.load_from_checkpoint(ckpt, seed=99)
+    assert m2.seed == 99 and torch.equal(m2.state_dict()["sampler.norm.weight"], sd_s["norm.weight"])
+    # a state_dict that does not fit is refused
+    blob = torch.load(ckpt, weights_only=False)
+    del blob["state_dict"]["sampler.layers.1.feed_forward.w2.weight"]
+    blob["state_dict"]["sampler.bogus"] = torch.zeros(1)
+    bad = str(tmp_path / "bad.ckpt")
+    torch.save(blob, bad)
+    with pytest.raises(L.VauraHipError, match="does not fit"):
+        VAURAModel.load_from_checkpoint(bad, hparams_file=hp)
+    with pytest.raises(L.VauraHipError, match="HIP device only|no CPU"):
+        m.generate(frames=torch.zeros(1, 4, 8, 768), max_new_tokens=4, prompt_is_encoded=True)

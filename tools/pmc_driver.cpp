@@ -56,6 +56,7 @@ template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights bf16|f32] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
   int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1;
+  const char* stamps_out = nullptr;
   std::vector<unsigned> variants{0u};
   for (int i = 2; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--time")) rounds = atoi(argv[i + 1]);
@@ -68,6 +69,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--stamps")) stamps_out = argv[i + 1];
   }
   void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
   if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
@@ -107,10 +109,42 @@ int main(int argc, char** argv) {
   d.ws_ffn_split = dev_zero<uint16_t>((size_t)rp * 3 * F); d.ws_ss = dev_zero<float>((size_t)(rp / 16) * (D / 16) * 16);
   d.first_norm = lw[0].attn_norm;
   d.ws_attn_part = nullptr;
-  d.ws_sync = dev_zero<uint32_t>(1025);
+  d.ws_sync = nullptr;
   vaura_sampling sp{1, 1.0f, 250, 0.0f, 6.0f, 1234ull, 0ull};
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CK(hipDeviceSynchronize());
+  if (stamps_out) {
+    // <lib> must be the DIAGNOSTIC build (python -m vaura_amd.csrc.build --stamps): wave 0 of every workgroup of the decode-step
+    // kernels writes s_memrealtime stamps to this side buffer (csrc/common.h); `steps` graph-replayed decode steps at pos0.
+    auto set_g = (int (*)(unsigned long long*))dlsym(lib, "vaura_stamps_set_gemv3");
+    auto set_a = (int (*)(unsigned long long*))dlsym(lib, "vaura_stamps_set_attention");
+    auto gbuild = (int (*)(const vaura_decoder*, const vaura_sampling*, vaura_stream_t, vaura_step_graph_t*))dlsym(lib, "vaura_step_graph_build");
+    auto gloop = (int (*)(const vaura_decoder*, const vaura_sampling*, int, int, vaura_step_graph_t, vaura_stream_t))dlsym(lib, "vaura_generate_loop");
+    if (!set_g || !set_a || !gbuild || !gloop) { fprintf(stderr, "%s is not a stamps build\n", argv[1]); return 1; }
+    const size_t cap = 1500000;
+    unsigned long long* buf; CK(hipMalloc(&buf, (8 + cap * 16) * 8)); CK(hipMemset(buf, 0, (8 + cap * 16) * 8));
+    unsigned long long hdr[2] = {0, cap};
+    vaura_step_graph_t g;
+    if (gbuild(&d, &sp, st, &g)) { fprintf(stderr, "graph build\n"); return 3; }
+    const int32_t st0[4] = {pos0, 0, 0, 1};
+    CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
+    if (gloop(&d, &sp, 0, 4, g, st)) return 3;               // warm-up, unstamped
+    CK(hipStreamSynchronize(st));
+    CK(hipMemcpy(buf, hdr, sizeof hdr, hipMemcpyHostToDevice));
+    if (set_g(buf) || set_a(buf)) { fprintf(stderr, "stamp setters failed\n"); return 3; }
+    CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
+    if (gloop(&d, &sp, 0, steps, g, st)) return 3;
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> host(8 + cap * 16);
+    CK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
+    const size_t n = std::min<size_t>(host[0], cap);
+    FILE* f = fopen(stamps_out, "wb");
+    if (!f) { perror(stamps_out); return 1; }
+    fwrite(host.data() + 8, 128, n, f);
+    fclose(f);
+    printf("stamps: %zu records of %d steps at position %d (rows %d, weights %s) -> %s\n", n, steps, pos0, rows, wd == VAURA_W_F32 ? "f32" : "bf16", stamps_out);
+    return 0;
+  }
   if (chains > 1) {
     // Concurrency experiment: the batch as `chains` independent decode chains (rows / chains rows each: clips are independent,
     // SURVEY.md 8e), each with its own stream, step graph, K/V cache and workspaces, sharing the weights; one host thread per
@@ -132,7 +166,6 @@ int main(int argc, char** argv) {
       e.ws_attn = dev_zero<float>((size_t)crp * D); e.ws_ffn = dev_zero<float>((size_t)crp * F); e.ws_logits = dev_zero<float>((size_t)crow * K * V);
       e.ws_h_split = dev_zero<uint16_t>((size_t)crp * 3 * D); e.ws_attn_split = dev_zero<uint16_t>((size_t)crp * 3 * D);
       e.ws_ffn_split = dev_zero<uint16_t>((size_t)crp * 3 * F); e.ws_ss = dev_zero<float>((size_t)(crp / 16) * (D / 16) * 16);
-      e.ws_sync = nullptr;
       CK(hipStreamCreateWithFlags(&sts[c], hipStreamNonBlocking));
       CK(hipDeviceSynchronize());
       const int rc = gbuild(&e, &sp, sts[c], &gs[c]);
@@ -218,10 +251,7 @@ int main(int argc, char** argv) {
       printf("\n");
     }
     setf(0);
-    uint32_t tmo = 0;
-    CK(hipMemcpy(&tmo, d.ws_sync + 1024, 4, hipMemcpyDeviceToHost));
-    printf("hand-off timeout word: %u\n", tmo);
-    return tmo ? 5 : 0;
+    return 0;
   }
   const int32_t st0[4] = {pos0, 0, 0, 1};
   CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
@@ -232,9 +262,6 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(st));
   int32_t st1[4];
   CK(hipMemcpy(st1, d.state, sizeof st1, hipMemcpyDeviceToHost));
-  uint32_t tmo = 0;
-  CK(hipMemcpy(&tmo, d.ws_sync + 1024, 4, hipMemcpyDeviceToHost));
-  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d, hand-off timeout word %u\n", steps, wd == VAURA_W_F32 ? "f32" : "bf16",
-         rows, pos0, st1[0] - 1, tmo);
-  return st1[0] == pos0 + steps && !tmo ? 0 : 4;
+  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wd == VAURA_W_F32 ? "f32" : "bf16", rows, pos0, st1[0] - 1);
+  return st1[0] == pos0 + steps ? 0 : 4;
 }

@@ -60,7 +60,7 @@ class _Holder(nn.Module):
 
 class DacModelWrapper(nn.Module):
     def __init__(self, model_sr: int = 24000, ckpt_path: tp.Optional[str] = None, synthetic: bool = False,
-                 synthetic_seed: int = 0, precision: str = "f16pair") -> None:
+                 synthetic_seed: int = 0, precision: str = "f16pair", weights_from_state_dict: bool = False) -> None:
         """``model_sr`` / ``ckpt_path`` as in the reference (dac/model.py:12-25).  Extras understood by this plugin only:
         ``precision`` of the decode convolutions — "f16pair" (default), "f32" (exact fp32 MFMA), "f16pair_w8" (fp8 conv
         weights) or "mx8" (fp8 weights and block-scaled fp8 activations on the fp8 MFMA; both BASELINE configs[4]); ``synthetic=True`` (or env VAURA_SYNTHETIC_CODEC=1) asks for seeded synthetic weights
@@ -83,6 +83,11 @@ class DacModelWrapper(nn.Module):
                 raise L.VauraHipError(f"DacModelWrapper: checkpoint {ckpt_path!r} does not exist (the reference would download "
                                       "one here, dac/model.py:23; there is no network path in this build)")
             self.model.load_state_dict(self.checkpoint_state_dict(ckpt_path, self.model.state_dict()), strict=True)
+        elif weights_from_state_dict:
+            # VAURAModel.load_from_checkpoint: the Lightning checkpoint carries audio_encoder.model.*; the strict load that
+            # follows fills every tensor (or fails).  Until then the holder is poisoned so that nothing decodes by accident.
+            for t in self.model.parameters():
+                t.data.fill_(float("nan"))
         elif synthetic:
             warnings.warn("DacModelWrapper: seeded SYNTHETIC DAC weights (synthetic=True): output is not real audio")
         else:

@@ -6,7 +6,6 @@
 #include "common.h"
 #include <algorithm>
 #include "gemv3_kernel.h"
-#include "mlp_fused.h"
 #include <vector>
 
 enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
@@ -114,8 +113,6 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
   // K-split qkv (consumer-reduced): fewer than 16 row blocks (otherwise the GEMM tiling takes over)
   float* qkv2 = (d->ws_qkv2 && (rows + 15) / 16 < 16) ? d->ws_qkv2 : nullptr;
-  // one launch per MLP: bf16 storage, one row block, the caller's sync words, a 256-CU device with nothing else spinning on it
-  const bool fused_mlp = d->wdtype == VAURA_W_BF16 && rows <= 16 && d->ws_sync && va_mlp_fused_available();
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -136,18 +133,6 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
                          E3_RESID, false, s);
     PROF_A(VAURA_K_WO);
     if (rc) return rc;
-    if (fused_mlp) {       // both GEMVs of the MLP in one launch, w2's weight stream under the hand-off (mlp_fused.h)
-      PROF_B(VAURA_K_W13);
-      MlpFusedArgs f;
-      f.W13 = L.w13; f.XP = d->ws_h_split; f.ss_in = d->ws_ss; f.n_ss_in = D / 16; f.ffnp = d->ws_ffn_split; f.W2 = L.w2;
-      f.res = d->ws_h; f.out = d->ws_h; f.outp = d->ws_h_split; f.gain_out = next_attn_gain; f.ss_out = d->ws_ss;
-      f.rows = rows; f.halves = (rows <= 8 ? 1 : 2) | ((va_debug_flags_get() & 8u) ? 4 : 0); f.eps = m.eps; f.flags = d->ws_sync; f.tmo = d->ws_sync + 1024;
-      f.state = d->state; f.layer = l;
-      rc = va_launch_mlp_fused(f, s);
-      PROF_A(VAURA_K_W13);
-      if (rc) return rc;
-      continue;
-    }
     PROF_B(VAURA_K_W13);   // ffn = silu(W1 x) * (W3 x), x = rmsnorm(h)                  llama.py:282, 177
     rc = va_launch_gemv3(g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F), 2 * F, D,
                          E3_SWIGLU, true, s);

@@ -211,6 +211,8 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
 
   // ---- 1. requests first: the new q/k/v quad + its rope entry, then the whole cache of this (row, head), K
   //         before V.  Slots past the end of the last pass re-read the last cached row and are masked below.
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);
   const int gt = min(tid, 3 * QUADS - 1);
   const int which = gt / QUADS, cq = gt % QUADS;
   f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
@@ -231,6 +233,9 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
     for (int i = 0; i < QPL; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i];
   }
 
+  VA_STAMP(stamps, 1);                       // every request issued
+  VA_WAIT_VM(2 * NU * QPL);
+  VA_STAMP(stamps, 2);                       // the new q / k / v quads (written by the previous kernel) and the rope entry have landed
   // ---- 2. rotate q and k (v passes through), park them in LDS, append k and v to the cache.  Every thread
   //         rotates and writes LDS (threads past the 72 real quads hit a scratch slot): an unconditional use keeps
   //         the compiler from sinking the two loads into a branch behind the cache loads.
@@ -244,6 +249,11 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   if (tid >= QUADS && tid < 3 * QUADS)
     reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD)[cq] = y;
   __syncthreads();
+#ifdef VAURA_STAMPS
+  VA_STAMP(stamps, 3);                       // rotated q / k / v parked in LDS (first barrier)
+  VA_WAIT_VM(0);
+  VA_STAMP(stamps, 4);                       // every cached K and V row has landed
+#endif
 
   // ---- 3. scores: 8 lanes per position; the new position's score is computed by every 8-lane group
   f32x4 qf[QPL];
@@ -303,6 +313,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   }
   if (lane == 0) { wm[wv] = m; wl[wv] = l; }
   __syncthreads();
+  VA_STAMP(stamps, 5);                       // scores, softmax, P.V of every wave done (second barrier)
 
   // ---- 5. combine the 8 waves and the new position
   if (tid < QUADS) {
@@ -322,6 +333,11 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
     reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
     if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
   }
+#ifdef VAURA_STAMPS
+  VA_WAIT_VM(0);
+  VA_STAMP(stamps, 6);                       // output stores acknowledged
+  VA_STAMP_FLUSH(stamps, 2);
+#endif
 }
 
 template <int HD>
@@ -428,6 +444,8 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
   const int sub = tid & 7, prow = tid >> 3;
 
   // new q/k/v quad of this head + rope entry, then the first block of the cache range
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);
   const int gt = min(tid, 3 * QUADS - 1);
   const int which = gt / QUADS, cq = gt % QUADS;
   f32x4 gx = reinterpret_cast<const f32x4*>(qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
@@ -730,6 +748,8 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     if (outp) store_split4(outp, vrow, h * HD + 4 * cq, D, v4);
   }
 }
+
+VA_STAMP_SETTER(vaura_stamps_set_attention)
 
 int va_attention_splits(int rows, int n_head, int max_len) {
   if (max_len <= 256) return 1;

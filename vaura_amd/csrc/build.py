@@ -13,6 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac.hip", "post.hip", "vit.hip"]
 HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", os.path.join("..", "..", "include", "vaura_hip.h")]
 LIB = os.path.join(HERE, "libvaura_hip.so")
+# diagnostic build (--stamps): the same sources with -DVAURA_STAMPS (in-kernel s_memrealtime stamps, common.h); never loaded by the
+# package, only by tools/pmc_driver --stamps
+LIB_STAMPS = os.path.join(HERE, "libvaura_hip_stamps.so")
 ARCH = "gfx950"
 # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs at wave launch (gfx94x/gfx950); the
 # compiler keeps a compatibility prologue that loads them the old way when the firmware does not preload
@@ -34,11 +37,11 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(HERE, src.replace(".hip", ".o"))
+def _compile(src: str, force: bool, stamps: bool = False) -> str:
+    obj = os.path.join(HERE, src.replace(".hip", ".stamps.o" if stamps else ".o"))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *(["-DVAURA_STAMPS"] if stamps else []), "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -47,10 +50,11 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    LIB = LIB_STAMPS if stamps else globals()["LIB"]
     with cf.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, stamps), srcs))
     if force or _stale(LIB, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -62,4 +66,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv)

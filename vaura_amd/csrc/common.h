@@ -76,6 +76,50 @@ inline int va_big_lds_once(const void* fn, size_t bytes, unsigned long long* don
   return 0;
 }
 
+
+// ---- in-kernel time stamps: DIAGNOSTIC BUILD ONLY (python -m vaura_amd.csrc.build --stamps -> libvaura_hip_stamps.so; the product
+// library is compiled without VAURA_STAMPS and contains none of this).  Every wave of the decode-step kernels reads
+// s_memrealtime (100 MHz, one counter for the whole chip: comparable across CUs and across launches) at fixed points and writes
+// ONE 128-byte record per wave to a side buffer that no kernel reads: {kind | block << 8 | xcc << 40 | wave << 48, t0 .. t6, t7}.  tools/pmc_driver --stamps
+// collects them, tools/stamp_report.py turns them into the per-phase shares of profiles/r03_stage_stamps.json.  The stamps
+// drain the memory pipeline where they wait, so this build's run TIME means nothing; its phase SHARES do.
+#ifdef VAURA_STAMPS
+static __device__ unsigned long long* va_stamp_ptr = nullptr;   // [0] = record counter, [1] = capacity, records from [8]
+struct VaStamps { unsigned long long t[7]; };
+__device__ __forceinline__ unsigned long long va_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define VA_STAMP(st, i) do { __builtin_amdgcn_sched_barrier(0); (st).t[i] = va_now(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// wait until at most n vector-memory operations of this wave are outstanding (loads retire in order)
+#define VA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+__device__ __forceinline__ void va_stamp_flush(const VaStamps& st, int kind) {
+  unsigned long long* p = va_stamp_ptr;
+  if (!p || (threadIdx.x & 63) != 0) return;                 // lane 0 of EVERY wave: one 128-byte record per wave
+  const unsigned long long slot = atomicAdd(p, 1ull);
+  const unsigned long long t7 = va_now();                    // the slot counter's round trip is over: what follows is fire-and-forget
+  if (slot >= p[1]) return;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  unsigned long long* r = p + 8 + slot * 16;
+  r[0] = (unsigned long long)kind | ((unsigned long long)(blockIdx.x + gridDim.x * blockIdx.y) << 8) | ((unsigned long long)(xcc & 15u) << 40) |
+         ((unsigned long long)(threadIdx.x >> 6) << 48);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r[1 + i] = st.t[i];
+  r[8] = t7;
+}
+#define VA_STAMP_DECL(st) VaStamps st = {}
+#define VA_STAMP_FLUSH(st, kind) va_stamp_flush(st, kind)
+#define VA_STAMP_SETTER(name) extern "C" int name(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(va_stamp_ptr), &p, sizeof p); }
+#else
+#define VA_STAMP(st, i) do { } while (0)
+#define VA_WAIT_VM(n) do { } while (0)
+#define VA_STAMP_DECL(st) do { } while (0)
+#define VA_STAMP_FLUSH(st, kind) do { } while (0)
+#define VA_STAMP_SETTER(name)
+#endif
+
 // ---- launchers implemented across the .hip files (host side, internal)
 int va_launch_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
                    int64_t rows, int64_t N, int64_t K, int epilogue, float eps, hipStream_t s);
@@ -84,10 +128,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
                         float* part, int n_split, hipStream_t s);
 struct Gemv3Args;
-struct MlpFusedArgs;
 unsigned va_debug_flags_get();   // vaura_set_debug_flags (gemv3.hip): kernel-variant switches for A/B measurements
-bool va_mlp_fused_available();
-int va_launch_mlp_fused(const MlpFusedArgs& a, hipStream_t s);
 int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s);
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t s);

@@ -1,15 +1,15 @@
 // Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
 #include "gemv3_kernel.h"
-#include "mlp_fused.h"
 #include <cstdlib>
 
 // measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split),
-// bit 2 = fused MLP launch, bit 3 = fused without the acquire, bit 4 = per-position prefill attention,
+// bit 4 = per-position prefill attention,
 // bit 5 = 64-row prefill GEMM workgroups only, bit 6 = row f2's linears on the 128 x 96 conv tile instead of linear_pair_kernel,
 // bit 7 = row f2's space attention with one thread per query instead of the MFMA kernel, bit 8 = 256-row tiles in
 // linear_pair_kernel, bit 9 = unsplit CLS attention, bit 10 = time attention with one thread per (head, frame),
 // bit 11 = space attention on the exact-fp32 MFMA instead of fp16 pairs, bit 13 = the codec's last conv without the LDS window
 unsigned va_debug_flags = 0;
+VA_STAMP_SETTER(vaura_stamps_set_gemv3)
 unsigned va_debug_flags_get() { return va_debug_flags; }
 
 template <int WT, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
@@ -20,11 +20,11 @@ static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
 }
 
 
-template <int WT, int G2, int EPI, int XB, int NBF = 2>
+template <int WT, int G2, int EPI, int XB, int NBF = 2, int NW = 8>
 static int launch3h(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   const int halves = (a.R == 1 && a.rows <= 8) ? 1 : 2;    // at most 8 live rows: the second half would multiply zeros
   if (halves == 2 && (n_tiles % 8)) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((gemv3h_kernel<G2, 8, EPI, XB, WT, NBF>), dim3((unsigned)(n_tiles * halves)), dim3(512), 0, s, a.W, a.XP, a, halves);
+  VA_LAUNCH((gemv3h_kernel<G2, NW, EPI, XB, WT, NBF>), dim3((unsigned)(n_tiles * halves)), dim3(NW * 64), 0, s, a.W, a.XP, a, halves);
   return 0;
 }
 
@@ -87,7 +87,7 @@ static int dispatch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, int epil
 int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
   Gemv3Args a = a0;
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
-  if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128)) return VAURA_ERR_ARG;
+  if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128 || (int64_t)a.n_ss_in * 16 > K)) return VAURA_ERR_ARG;   // one partial per 16 columns of the normed vector
   const int64_t tiles = n_weight_rows / 16;
   if (a.out2) {   // the caller asked for two K-half partials (decode qkv): bf16 weights, fused norm, K = 1536 only
     if (K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
@@ -186,28 +186,6 @@ __global__ void split_rows_kernel(const float* __restrict__ src, uint16_t* __res
   }
   if (gain) v *= *reinterpret_cast<const f32x4*>(gain + cq * 4);
   store_split4(dst, row, cq * 4, C, v);
-}
-
-// ---------------------------------------------------------------------------- fused MLP (mlp_fused.h)
-// EXPERIMENT, off by default: measured no faster than the two launches it replaces (profiles/r02_ab_fused_mlp.txt).  Enabled by
-// VAURA_FUSED_MLP=1 (read once) or debug flag bit 2.  Usable only when every workgroup of the 256-wide grid is resident at once:
-// the device must have exactly that many CUs and the decode loop must be the only spinning kernel on it (one decode loop per GPU).
-bool va_mlp_fused_available() {
-  static int cus = -1, env_on = 0;
-  if (cus < 0) {
-    int dev = 0;
-    const char* on = getenv("VAURA_FUSED_MLP");
-    env_on = on && on[0] == '1';
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-  }
-  return cus == 256 && (env_on || (va_debug_flags & 4u));
-}
-
-int va_launch_mlp_fused(const MlpFusedArgs& a, hipStream_t s) {
-  if (!a.W13 || !a.XP || !a.ss_in || !a.ffnp || !a.W2 || !a.res || !a.out || !a.flags || !a.tmo || !a.state) return VAURA_ERR_ARG;
-  if (a.rows <= 0 || a.rows > 16 || a.n_ss_in != 96) return VAURA_ERR_SHAPE;
-  VA_LAUNCH((mlp_fused_kernel<0>), dim3(256), dim3(512), 0, s, a.W13, a.XP, a);
-  return 0;
 }
 
 extern "C" {

@@ -229,6 +229,8 @@ template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, int
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a) {
   // Wq / XPq duplicate a.W / a.XP as explicit scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs
   // at wave launch, so the address arithmetic of the first (weight) loads does not wait for a kernarg s_load
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);                       // wave start
   a.W = Wq;
   a.XP = XPq;
   constexpr bool FP8 = WT == 1, F32 = WT == 2;
@@ -244,7 +246,12 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   constexpr int GW = FP8 ? G / 2 : (WBATCH ? 2 * GB : G);   // weight register groups per tile
   constexpr int NACC = F32 ? 4 : 3;
   __shared__ f32x4 red[NW][T][64];
-  constexpr int SSL = NORM ? 2048 : 4;   // n_ss_in * 16 <= 2048 floats
+  constexpr int NSS = K / 64;            // partial sums of squares per lane: n_ss_in = K / 16 tiles, 4 lane groups
+  constexpr int EWN = (EPI == E3_SWIGLU) ? 1 : T;   // waves that run the epilogue (see below)
+  // where the 24 values fit the register file next to the weight slice (bf16 / fp8 weights, 8 waves) the epilogue waves fetch
+  // them straight into registers; the fp32-weight and 16-wave instances park them in LDS (whole workgroup, one load each)
+  constexpr bool SS_DIRECT = NORM && WT != 2 && NW <= 8;
+  constexpr int SSL = (NORM && !SS_DIRECT) ? K : 4;   // n_ss_in * 16 <= K floats
   __shared__ float ssl[SSL];
 
   const int lane = threadIdx.x & 63;
@@ -314,11 +321,24 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       __builtin_amdgcn_sched_barrier(0);
       if (first) load_x(rb, 0);
     }
-    // rinv inputs: the producer's per-tile partial sums of squares, fetched by the whole workgroup in one
-    // go and parked in LDS (a load->add loop in one wave pays an L2 round trip per partial: 2.4 us)
-    constexpr int SSN = NORM ? 2048 / (NW * 64) : 1;
+    // rinv inputs: the producer's per-tile partial sums of squares.  The waves that will run the epilogue request their
+    // lane's partials (row m, tiles q, q + 4, ...: every instruction a contiguous 256 bytes) right behind the stream loads,
+    // add them in tile order after their last MFMA and have rinv in a register BEFORE the reduction barrier.  (Round 2 parked
+    // the partials in LDS and added them after the barrier in a load -> wait -> add loop of 24 dependent LDS round trips:
+    // 1.0-1.3 us on the critical path of every normed GEMV, profiles/r03_stage_stamps.json.  Same sums, same order.)
+    float ssv[SS_DIRECT ? NSS : 1];
+    constexpr int SSN = (NORM && !SS_DIRECT) ? (K + NW * 64 - 1) / (NW * 64) : 1;
     float ssr[SSN];
-    if constexpr (NORM) {
+    if constexpr (SS_DIRECT) {
+      if (wid < EWN) {
+        const float* sp = a.ss_in + (size_t)rb * a.n_ss_in * 16 + m;
+#pragma unroll
+        for (int j = 0; j < NSS; ++j) {
+          const int i = q + 4 * j;
+          ssv[j] = (i < a.n_ss_in) ? sp[i * 16] : 0.f;
+        }
+      }
+    } else if constexpr (NORM) {
       const float* sp = a.ss_in + (size_t)rb * a.n_ss_in * 16;
 #pragma unroll
       for (int j = 0; j < SSN; ++j) {
@@ -339,6 +359,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int p = 0; p < NACC; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (first) {
+      VA_STAMP(stamps, 1);                   // every request of the first batch issued
+      VA_WAIT_VM(GB * 3 + (SS_DIRECT ? NSS : (NORM ? SSN : 0)));
+      VA_STAMP(stamps, 2);                   // the weight tiles (HBM) have landed
+      VA_WAIT_VM(0);
+      VA_STAMP(stamps, 3);                   // the activation planes / partial sums (written by the previous kernel) have landed
+    }
 
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
@@ -380,23 +407,40 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
 
 #pragma unroll
     for (int t = 0; t < T; ++t) red[wid][t][lane] = acc_sum<WT>(acc[t]);
-    if constexpr (NORM) {
+    float rinv = 1.f;
+    if constexpr (SS_DIRECT) {
+      if (wid < EWN) {
+        float ssp = 0.f;
+#pragma unroll
+        for (int j = 0; j < NSS; ++j) ssp += ssv[j];      // tile order q, q + 4, ... (slots past n_ss_in hold 0)
+        ssp += __shfl_xor(ssp, 16, 64);
+        ssp += __shfl_xor(ssp, 32, 64);
+        rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+      }
+    } else if constexpr (NORM) {
 #pragma unroll
       for (int j = 0; j < SSN; ++j) {
         const int i = threadIdx.x + j * NW * 64;
         if (i < SSL) ssl[i] = ssr[j];
       }
     }
+    if (first) VA_STAMP(stamps, 4);          // MFMAs done, partial tiles written to LDS
     __syncthreads();
+    if (first) VA_STAMP(stamps, 5);          // all 8 waves have arrived
     // Epilogue: one wave per output tile where the tiles are independent (store / residual / logits), so T waves
     // finish the T tiles side by side; SwiGLU needs both tiles of a (w1, w3) pair in the same lane: one wave does all.
     constexpr int EW = (EPI == E3_SWIGLU) ? 1 : T;     // waves taking part
     constexpr int ET = (EPI == E3_SWIGLU) ? T : 1;     // tiles per such wave
+    static_assert(EW == EWN, "the waves that fetched the partial sums run the epilogue");
     if (wid < EW) {
-      float rinv = 1.f;
-      if constexpr (NORM) {
+      if constexpr (NORM && !SS_DIRECT) {
+        // every LDS read issued before the first add (a fixed trip count: the round-2 loop over a.n_ss_in waited for each read)
+        float pv[NSS];
+#pragma unroll
+        for (int j = 0; j < NSS; ++j) pv[j] = (q + 4 * j < a.n_ss_in) ? ssl[(q + 4 * j) * 16 + m] : 0.f;
         float ssp = 0.f;
-        for (int i = q; i < a.n_ss_in; i += 4) ssp += ssl[i * 16 + m];
+#pragma unroll
+        for (int j = 0; j < NSS; ++j) ssp += pv[j];
         ssp += __shfl_xor(ssp, 16, 64);
         ssp += __shfl_xor(ssp, 32, 64);
         rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
@@ -416,6 +460,11 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   };
 
   row_block(0, true);
+#ifdef VAURA_STAMPS
+  VA_WAIT_VM(0);
+  VA_STAMP(stamps, 6);                       // wave 0's epilogue stores acknowledged
+  VA_STAMP_FLUSH(stamps, EPI == E3_SWIGLU ? 4 : (EPI == E3_LOGITS ? 6 : ((EPI == E3_STORE && NORM) ? 1 : 9)));
+#endif
   for (int rb = 1; rb < a.R; ++rb) {
     __syncthreads();
     row_block(rb, false);
@@ -437,6 +486,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
 // G2 = k-group pairs per wave, XB = batches (weights and planes together, two in flight), WT = 0 bf16 | 2 fp32 weights.
 template <int G2, int NW, int EPI, int XB = 1, int WT = 0, int NBF = 2>
 __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a, int halves) {
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);
   a.W = Wq;
   a.XP = XPq;
   static_assert(WT == 0 || WT == 2, "bf16 or fp32 weights");
@@ -506,6 +557,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
       for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rb == 0) {
+      VA_STAMP(stamps, 1);
+      VA_WAIT_VM(GB * 3 + 2);                // wave 0 also holds the residual / gain requests
+      VA_STAMP(stamps, 2);
+      VA_WAIT_VM(0);
+      VA_STAMP(stamps, 3);
+    }
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
       if (XB > 1 && b + NB - 1 < XB) { load_w(b + NB - 1); load_x(rb, b + NB - 1); }
@@ -533,7 +591,9 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       }
       red[wid][nh][lane] = o;
     }
+    if (rb == 0) VA_STAMP(stamps, 4);
     __syncthreads();
+    if (rb == 0) VA_STAMP(stamps, 5);
     if (wid == 0) {
       // epilogue lane (m = lane & 15, q' = lane >> 4) = row m, columns 4 q' .. 4 q' + 3 of the tile: weight rows n = 4 q' + r
       // -> nh = q' >> 1, source lane (s' = 0 copy) = (m & 7) + 16 (q' & 1); rows of the other half are not this workgroup's
@@ -545,6 +605,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       for (int i = 1; i < NW; ++i) v += red[i][q >> 1][src];
       if (mine) gemv3_epilogue<1, EPI>(a, rb, tile, lane, &v, &pre);
     }
+#ifdef VAURA_STAMPS
+    if (rb == 0) {
+      VA_WAIT_VM(0);
+      VA_STAMP(stamps, 6);
+      VA_STAMP_FLUSH(stamps, K == 1536 ? 3 : 5);
+    }
+#endif
   }
 }
 

@@ -206,7 +206,6 @@ class DecoderEngine:
             self.ws_ffn_split = torch.zeros(rp * 3 * c.ffn_dim, **i16)
             self.ws_ss = torch.zeros((rp // 16) * (c.d_model // 16) * 16, **f32)
             self.ws_attn_part = torch.zeros(rows * c.nhead * 8 * (c.d_model // c.nhead + 8), **f32)
-            self.ws_sync = torch.zeros(1025, dtype=torch.int32, device=self.dev)     # fused-MLP hand-off flags + timeout word
             crp = self._rows_padded(rows * n_cond_tokens)
             self.cond_in = torch.zeros(crp * c.cond_in, **f32)
             self.cond_tmp = torch.zeros(crp * c.cond_dim, **f32)
@@ -235,7 +234,7 @@ class DecoderEngine:
             d.ws_h_split = d.ws_attn_split = d.ws_ffn_split = d.ws_ss = 0
         d.first_norm = self.layers[0].attn_norm
         d.ws_attn_part = L.ptr(self.ws_attn_part)
-        d.ws_sync = L.ptr(self.ws_sync) if self.planes else 0
+        d.ws_sync = 0            # reserved
         self.dec = d
         self._shape = key
         self._graph_key = None
@@ -327,21 +326,11 @@ class DecoderEngine:
             pass
 
     def _reset_state(self):
-        """position / arrivals / step back to 0 and a NEW sequence id in state[3]: the epochs of the in-launch hand-offs
-        (mlp_fused.h) are derived from (sequence id, position, layer) and must never repeat on live flag words."""
+        """position / arrivals / step back to 0; state[3] carries a sequence id (reserved for in-launch hand-off epochs)."""
         self._fc = None                       # position 0 again: a cached forward() prefix no longer matches the K/V cache
         DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x7FF
         self.state.zero_()                                   # two tiny device fills: no host-device synchronisation
         self.state[3:4].fill_(DecoderEngine._sequence_id)
-
-    def check_sync_timeouts(self):
-        """Raise if a fused launch gave up waiting for its peers (bounded spin: it never hangs, but that step's numbers are
-        wrong).  Only the experimental fused MLP launch (VAURA_FUSED_MLP=1) spins; it times out when its 256 workgroups were not
-        resident together — e.g. a second decode loop on the same GPU.  Synchronises (reads one device word)."""
-        if getattr(self, "ws_sync", None) is not None and int(self.ws_sync[1024].item()) != 0:
-            self.ws_sync[1024] = 0
-            raise L.VauraHipError("a fused decode launch timed out waiting for its peer workgroups (another spinning kernel on this "
-                                  "GPU?): results are invalid; unset VAURA_FUSED_MLP when GPUs are shared")
 
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T

@@ -37,10 +37,6 @@ class MotionFormer(nn.Module):
                 not factorize_space_time:
             raise L.VauraHipError("vaura_amd.feature_extractor.MotionFormer builds the avclip_vggsound.yaml configuration only "
                                   "(factorize_space_time, TransformerEncoderLayer spatial aggregation, Identity in time, no global repr)")
-        if not extract_features:
-            raise L.VauraHipError("vaura_amd.feature_extractor.MotionFormer returns features only (extract_features=True, as in "
-                                  "configs/modules/feature_extractors/avclip_vggsound.yaml:4); the classification head of "
-                                  "motionformer.py:311-320 is not built")
         self.extract_features = extract_features
         self.ckpt_path = ckpt_path
         self.cfg = synth.FULL_AVCLIP
@@ -99,6 +95,10 @@ class MotionFormer(nn.Module):
             return x, None
         if x.dim() != 6:
             raise ValueError(f"MotionFormer expects frames (B, S, C, T, H, W) or features (B, S, t, {self.embed_dim}); got {tuple(x.shape)}")
+        if not self.extract_features:
+            raise L.VauraHipError("vaura_amd.feature_extractor.MotionFormer encodes frames to features only (extract_features=True, "
+                                  "as in configs/modules/feature_extractors/avclip_vggsound.yaml:4); with extract_features=False the "
+                                  "reference returns the classification head's output (motionformer.py:160-166, 311-320), which is not built")
         if not self._loaded:
             raise L.VauraHipError("MotionFormer has no weights: pass ckpt_path=... or load_state_dict(...) before encoding frames")
         return self.engine().forward(x), None

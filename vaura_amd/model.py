@@ -32,6 +32,16 @@ def _disabled_train(self, mode: bool = True):
     return self
 
 
+def _plain(o):
+    """OmegaConf / Lightning AttributeDict containers -> plain dicts and lists (hyper-parameters out of a checkpoint)."""
+    if hasattr(o, "items"):
+        return {str(k): _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)) or (hasattr(o, "__iter__") and not isinstance(o, (str, bytes)) and hasattr(o, "__len__")
+                                        and not torch.is_tensor(o)):
+        return [_plain(v) for v in o]
+    return o
+
+
 class VAURAModel(nn.Module):
     def __init__(self, learning_rate: float = 5e-6, lr_scheduler: dict = None, weight_decay: float = 0.01,
                  betas: tuple = (0.9, 0.95), batch_size: int = 1, use_visual_conditioning: bool = True,
@@ -71,6 +81,78 @@ class VAURAModel(nn.Module):
         self.seed = seed
         self.clip_base = 0  # global index of this rank's first clip (vaura_amd.dist)
         self.eval()
+
+    # ------------------------------------------------------------------ checkpoint ingress (scripts/generate.py:208-212)
+    # reference plugin classes -> their MI355X counterparts: a hparams.yaml written by the reference's training run names the
+    # reference's classes; with `remap_targets` the reference's driver needs no config edit at all
+    TARGET_MAP = {
+        "models.modules.sampler.llama.Transformer": "vaura_amd.sampler.Transformer",
+        "models.modules.dac.model.DacModelWrapper": "vaura_amd.codec.DacModelWrapper",
+        "models.modules.feature_extractors.avclip.motionformer.MotionFormer": "vaura_amd.feature_extractor.MotionFormer",
+        "models.modules.misc.codebook_patterns.DelayedPatternProvider": "vaura_amd.patterns.DelayedPatternProvider",
+    }
+    # tensors of a reference checkpoint that nothing on the generation path reads: the extractor's 2-D patch embedding
+    # (video_model_builder.py:246-248 builds it, forward_features uses patch_embed_3d)
+    UNUSED_CHECKPOINT_KEYS = ("visual_feature_extractor.patch_embed.proj.weight", "visual_feature_extractor.patch_embed.proj.bias")
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict: bool = True,
+                             remap_targets: bool = True, **kwargs) -> "VAURAModel":
+        """``LightningModule.load_from_checkpoint`` as ``scripts/generate.py:208-212`` calls it —
+        ``VAURAModel.load_from_checkpoint(ckpt, hparams_file=hparams.yaml, map_location=device)`` — without Lightning:
+        constructor arguments from ``hparams_file`` (the YAML ``save_hyperparameters()`` wrote, vaura_model.py:50; plain
+        ``yaml.safe_load``) or, without one, from the checkpoint's own ``hyper_parameters``; then ``state_dict`` (keys
+        ``sampler.*``, ``audio_encoder.model.*``, ``visual_feature_extractor.*``) loaded strictly; then ``.to(map_location)``.
+        Keyword arguments override hyper-parameters, like Lightning's.  Plugin weights that the checkpoint itself carries
+        need no file of their own: a codec without ``ckpt_path`` and an extractor whose ``ckpt_path`` does not exist on this
+        machine (scripts/generate.py:31-35 points it at ./segment_avclip/...) are built empty and filled from ``state_dict``
+        — if the checkpoint lacks them, the strict load fails loudly."""
+        import inspect
+        import os
+        import yaml
+        blob = torch.load(os.fspath(checkpoint_path), map_location="cpu", weights_only=False)   # a Lightning file: pickled hparams inside
+        if "state_dict" not in blob:
+            raise L.VauraHipError(f"{checkpoint_path}: not a Lightning checkpoint (no 'state_dict')")
+        sd = dict(blob["state_dict"])
+        if hparams_file is not None:
+            if not str(hparams_file).endswith((".yaml", ".yml")):
+                raise L.VauraHipError("hparams_file must be the hparams.yaml of the run (csv is not read)")
+            with open(os.fspath(hparams_file)) as f:
+                hp = yaml.safe_load(f) or {}
+        else:
+            hp = blob.get("hyper_parameters") or {}
+        hp = _plain(hp)
+        hp.update(kwargs)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        hp = {k: v for k, v in hp.items() if k in accepted}
+        for key in ("feature_extractor_config", "audio_encoder_config", "sampler_config", "pattern_provider_config"):
+            c = hp.get(key)
+            if remap_targets and isinstance(c, dict) and c.get("target") in cls.TARGET_MAP:
+                c["target"] = cls.TARGET_MAP[c["target"]]
+        ae = hp.get("audio_encoder_config")
+        if isinstance(ae, dict) and ae.get("target", "").startswith("vaura_amd.") and any(k.startswith("audio_encoder.model.") for k in sd):
+            p = ae.setdefault("params", {})
+            if not p.get("ckpt_path") and not p.get("synthetic"):
+                p["weights_from_state_dict"] = True
+        fe = hp.get("feature_extractor_config")
+        if isinstance(fe, dict) and fe.get("target", "").startswith("vaura_amd.") and any(k.startswith("visual_feature_extractor.") for k in sd):
+            p = fe.setdefault("params", {})
+            if p.get("ckpt_path") and not os.path.exists(p["ckpt_path"]):
+                p["ckpt_path"] = None
+        model = cls(**hp)
+        for k in cls.UNUSED_CHECKPOINT_KEYS:
+            sd.pop(k, None)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        if strict and (missing or unexpected):
+            raise L.VauraHipError(f"{checkpoint_path}: state_dict does not fit the plugin modules: {len(missing)} missing "
+                                  f"(e.g. {list(missing)[:3]}), {len(unexpected)} unexpected (e.g. {list(unexpected)[:3]})")
+        fx = model.visual_feature_extractor
+        if fx is not None and hasattr(fx, "_loaded") and not any(k.startswith("visual_feature_extractor.") for k in missing):
+            fx._loaded = fx._loaded or any(k.startswith("visual_feature_extractor.") for k in sd)
+        model.eval()
+        if map_location is not None and not callable(map_location) and not isinstance(map_location, dict):
+            model = model.to(map_location)
+        return model
 
     # ------------------------------------------------------------------ small surface
     @property
@@ -157,7 +239,6 @@ class VAURAModel(nn.Module):
             special = torch.full_like(seq, self.special_token_id)
             assert not bool((seq == -1).any()), "unknown tokens left in the generated sequence"
             assert bool((seq == torch.where(mask[None].expand_as(seq), seq, special)).all()), "sequence and pattern mask disagree"
-        eng.check_sync_timeouts()
         return codes[..., (Tp if remove_prompts else 0):max_new_tokens]
 
     @torch.no_grad()
