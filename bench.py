@@ -160,14 +160,20 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 8 for c2, 4 for c4)")
     ap.add_argument("--cfg-scale", type=float, default=None)
     ap.add_argument("--top-k", type=int, default=250)
-    ap.add_argument("--weights", choices=["bf16", "f32", "fp8"], default="bf16", help="storage of the streamed matrices")
+    ap.add_argument("--weights", choices=["auto", "h1", "h2", "fp8", "f32"], default="auto",
+                    help="storage of the streamed matrices (vaura_amd.engine.resolve_weight_dtype); auto = the plugin default: two fp16 "
+                         "planes (h2) for the un-rounded checkpoint")
+    ap.add_argument("--checkpoint", choices=["raw", "bf16repr"], default="raw",
+                    help="synthetic checkpoint of the headline run: raw = un-rounded fp32 weights (what a real V-AURA checkpoint looks "
+                         "like to the storage decision), bf16repr = every streamed weight bf16-representable (one fp16 plane is lossless)")
     ap.add_argument("--codec", choices=["f32", "f16pair", "f16pair_w8", "mx8"], default=None,
                     help="codec conv precision (default: f16pair; f16pair_w8 with --weights fp8).  mx8 = block-scaled fp8 on "
                          "the fp8 MFMA, BASELINE configs[4] together with --weights fp8 --batch 16")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="experiment: codec + gather of batch i on a second stream (slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f32", action="store_true", help="skip the second timed region (f32 storage on the un-rounded checkpoint)")
+    ap.add_argument("--no-second", "--no-f32", dest="no_second", action="store_true",
+                    help="skip the second timed region (the bf16-representable checkpoint on one fp16 plane)")
     ap.add_argument("--no-plugin", action="store_true", help="skip timing VAURAModel.generate() through the plugin classes")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -201,13 +207,15 @@ def main():
     ccfg = synth.FULL_CODEC
     B = args.batch
     first, _ = vdist.shard(B * world, rank, world)
-    # Two synthetic checkpoints (no network: weights are regenerated from seeds): the bf16-representable one (every
-    # storage then holds the same numbers: bf16 storage is exact for it) and, for `value_f32_storage`, the UN-rounded one
-    # — fp32 weights bf16 cannot hold, i.e. what a real V-AURA checkpoint looks like: "auto" resolves to f32 storage there.
-    sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
+    # Two synthetic checkpoints (no network: weights are regenerated from seeds).  `value` runs on the UN-rounded one — fp32
+    # weights 16 bits cannot hold, i.e. what a real V-AURA checkpoint looks like: the plugin default "auto" resolves to two fp16
+    # planes (22 significand bits) there.  `value_h1_lossless_checkpoint` is the same job on a bf16-representable checkpoint,
+    # which one fp16 plane holds exactly (half the weight bytes).
+    sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=(args.checkpoint == "bf16repr"))
     eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights)
+    storage = eng.wdtype                     # what "auto" resolved to
     if args.codec is None:
-        args.codec = "f16pair_w8" if args.weights == "fp8" else "f16pair"
+        args.codec = "f16pair_w8" if storage == "fp8" else "f16pair"
     codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision=args.codec)
     feats_cpu = synth.video_features(B, TV, cfg.cond_in, seed=0, first_clip=first)
     feats = feats_cpu.to(dev)
@@ -264,21 +272,23 @@ def main():
 
     tokens = world * B * K_CB * T_FRAMES * args.steps
     rows = 2 * B if args.cfg_scale > 1 else B
-    wbytes = {"bf16": 2, "f32": 4, "fp8": 1}[args.weights]
+    wbytes = {"h1": 2, "h2": 4, "f32": 4, "fp8": 1}[storage]
     out = {
         "metric": f"audio codec tokens/sec (whole node), {'10.24' if long_ctx else '2.56'} s clips",
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",   # dtype = the arithmetic type: fp32 products / accumulate (exact bf16-plane products), whatever the storage
-        "config": {"workload": (f"configs[{3 if long_ctx else (4 if args.weights == 'fp8' and args.codec == 'mx8' else 1)}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",   # dtype = the arithmetic type: fp32 accumulate of exact products of (hi, lo) fp16 operand pairs (22 significand bits), whatever the storage
+        "config": {"workload": (f"configs[{3 if long_ctx else (4 if storage == 'fp8' and args.codec == 'mx8' else 1)}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
                    "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
-                   "weights": ({"bf16": "bf16 storage of the streamed matrices (synthetic checkpoint is bf16-representable: exact)",
-                                "f32": "fp32 storage of the streamed matrices",
+                   "weights": ({"h2": "two fp16 planes (hi, lo) + power-of-two row scales per streamed matrix: 22 significand bits, 4 bytes per weight",
+                                "h1": "one fp16 plane + power-of-two row scales: lossless for this (bf16-representable) checkpoint, 2 bytes per weight",
+                                "f32": "fp32 tiles on the exact-fp32-MFMA GEMVs (cross-check path)",
                                 "fp8": "fp8 e4m3 + power-of-two row scales for the per-layer matrices and the codec's conv weights, "
-                                       "bf16 heads (a different model than the bf16 one: not the headline configuration)"}[args.weights]
-                               + "; fp32 activations / accumulate / KV cache; codec: "
+                                       "one-plane heads (a different model: not the headline configuration)"}[storage]
+                               + f" (requested: {args.weights}; checkpoint: {args.checkpoint})"
+                               + "; activations as (hi, lo) fp16 planes between kernels, fp32 accumulate / residual stream / KV cache; codec: "
                                + {"f32": "fp32 MFMA", "f16pair": "activations and weights on (hi, lo) fp16 pairs, fp32 accumulate",
                                   "f16pair_w8": "fp8 weights in one fp16 plane, activations on (hi, lo) fp16 pairs",
                                   "mx8": "fp8 weights and block-scaled fp8 activations on the fp8 MFMA (NOT inside the 1e-4 waveform "
@@ -287,29 +297,28 @@ def main():
                    "streams": "decode loop of batch i+1 overlaps codec+gather of batch i (two HIP streams)" if args.overlap
                               else "one non-null HIP stream"},
         "sec_audio_per_sec": round(world * B * T_FRAMES * HOP / 44100.0 * args.steps / elapsed, 2),
-        "value_storage": {"bf16": "bf16 storage, bf16-representable synthetic checkpoint (exact for THAT checkpoint)",
-                          "f32": "f32 storage", "fp8": "fp8 storage (a different model)"}[args.weights],
+        "value_storage": f"{storage} (weight_dtype={args.weights!r}) on the {'un-rounded (real-checkpoint-shaped)' if args.checkpoint == 'raw' else 'bf16-representable'} synthetic checkpoint",
     }
 
-    # ---- the same job on an UN-rounded checkpoint with the plugin's default storage decision ("auto" -> f32): the
-    #      reference-exact configuration for real (fp32) checkpoints.  Every rank runs it (same barriers).
-    if not args.no_extras and args.weights == "bf16" and not args.no_f32:
+    # ---- the same job on the bf16-representable checkpoint, where "auto" resolves to ONE fp16 plane (half the weight bytes,
+    #      same real numbers).  Every rank runs it (same barriers).
+    if not args.no_extras and args.weights == "auto" and args.checkpoint == "raw" and not args.no_second:
         eng_main = eng
-        sd_raw = synth.sampler_state_dict(cfg, seed=0, round_bf16=False)
-        eng = DecoderEngine(cfg, sd_raw, dev)                    # wdtype="auto"
-        assert eng.wdtype == "f32", eng.wdtype
-        del sd_raw
-        el32, (codes32, wav32) = timed(step)
-        t_loop32 = sum(a.elapsed_time(b) for a, b, _ in marks[-args.steps:]) / args.steps
-        assert int(codes32.min()) >= 0 and int(codes32.max()) < 1024 and bool(torch.isfinite(wav32).all())
-        out["value_f32_storage"] = round(tokens / el32, 1)
-        out["ms_per_step_f32_storage"] = round(1e3 * el32 / args.steps, 3)
-        lb32 = decode_loop_bytes(cfg, 4, 2 * B if args.cfg_scale > 1 else B, T_FRAMES + K_CB - 1)
-        out["decode_loop_roofline_f32_storage"] = {"bound": "hbm", "achieved": round(lb32 / (t_loop32 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                                   "unit": "GB/s", "frac": round(lb32 / (t_loop32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                                   "bytes": lb32, "decode_loop_ms": round(t_loop32, 3)}
-        out["f32_storage_checkpoint"] = ("un-rounded synthetic checkpoint (fp32 weights, not bf16-representable: real-checkpoint-shaped); "
-                                         "storage chosen by weight_dtype='auto'; fp32 weights split into exact bf16 planes in registers")
+        sd_b = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
+        eng = DecoderEngine(cfg, sd_b, dev)                    # wdtype="auto"
+        assert eng.wdtype == "h1", eng.wdtype
+        del sd_b
+        el1, (codes1, wav1) = timed(step)
+        t_loop1 = sum(a.elapsed_time(b) for a, b, _ in marks[-args.steps:]) / args.steps
+        assert int(codes1.min()) >= 0 and int(codes1.max()) < 1024 and bool(torch.isfinite(wav1).all())
+        out["value_h1_lossless_checkpoint"] = round(tokens / el1, 1)
+        out["ms_per_step_h1_lossless_checkpoint"] = round(1e3 * el1 / args.steps, 3)
+        lb1 = decode_loop_bytes(cfg, 2, 2 * B if args.cfg_scale > 1 else B, T_FRAMES + K_CB - 1)
+        out["decode_loop_roofline_h1_lossless_checkpoint"] = {"bound": "hbm", "achieved": round(lb1 / (t_loop1 * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                                              "unit": "GB/s", "frac": round(lb1 / (t_loop1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                              "bytes": lb1, "decode_loop_ms": round(t_loop1, 3)}
+        out["h1_lossless_checkpoint"] = ("bf16-representable synthetic checkpoint: every streamed weight fits one fp16 plane exactly; storage chosen by "
+                                         "weight_dtype='auto'")
         del eng
         torch.cuda.empty_cache()
         eng = eng_main
@@ -354,14 +363,14 @@ def main():
         ach = ab / (per[dom] * 1e-6) / 1e9
         names = json.load(open(os.path.join(REPO, "profiles", "kernel_names.json"))) if os.path.exists(
             os.path.join(REPO, "profiles", "kernel_names.json")) else {}
-        kname = names.get(args.weights, {}).get(dom, dom)
+        kname = names.get("c4" if long_ctx else storage, {}).get(dom, dom)
         # HBM traffic of that kernel from the PMC passes over the SAME library (tools/pmc_driver.cpp + tools/profile_pmc.sh):
         # only quoted when the committed record is for this kernel instance and storage, else null
         traffic, tsrc = None, None
-        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith(f"_pmc_hbm_bytes_{args.weights}.json")), reverse=True):
+        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith(f"_pmc_hbm_bytes_{storage}.json")), reverse=True):
             try:
                 rec = json.load(open(os.path.join(REPO, "profiles", cand)))
-                hit = rec.get("weights") == args.weights and rec.get("rows") == rows and rec.get("kernels", {}).get(kname)
+                hit = rec.get("weights") == storage and rec.get("rows") == rows and rec.get("kernels", {}).get(kname)
                 if hit:
                     traffic, tsrc = hit["hbm_bytes_per_launch"], f"profiles/{cand}"
                     break
@@ -379,7 +388,7 @@ def main():
 
         # ---- the plugin surface (wall = generate() entry -> waveform): VAURAModel.generate() built from
         #      reference-style config dicts, same workload, next to the engine-level number above
-        if not args.no_plugin and not long_ctx and args.weights == "bf16":
+        if not args.no_plugin and not long_ctx and args.weights == "auto":
             import warnings
             from vaura_amd.model import VAURAModel
             with warnings.catch_warnings():

@@ -22,8 +22,10 @@
  *
  * Streamed-weight layout ("MFMA tiles"): an (N x K) matrix, N%16==0, K%32==0, is stored as
  *     [N/16][K/32][64 lanes][8]  with lane = (n%16) + 16*((k%32)/8), element j = k%8
- *   (fp32: [N/16][K/32][2 halves][64 lanes][4];
- *    fp8:  [N/16][K/64][64 lanes][16 bytes] = the lane's 8 values of the even then of the odd k-group, K%64==0,
+ *   (VAURA_W_F32: [N/16][K/32][2 halves][64 lanes][4] fp32;  VAURA_W_BF16: 8 bf16 per lane;
+ *    VAURA_W_H1:  8 fp16 per lane = W[n,k] / scale[n], followed by float scale[N] (power of two, max|W[n,:]| / scale in [2^13, 2^14));
+ *    VAURA_W_H2:  [N/16][K/32][2 planes][64 lanes][8 fp16]: hi = fp16(W/scale), lo = fp16(W/scale - hi), followed by scale[N];
+ *    VAURA_W_FP8: [N/16][K/64][64 lanes][16 bytes] = the lane's 8 values of the even then of the odd k-group, K%64==0,
  *          followed by float scale[N], scale[n] = smallest power of two with max|W[n,:]| <= 448*scale[n]);
  *   see vaura_pack_weight().
  */
@@ -47,9 +49,16 @@ typedef enum vaura_status {
   VAURA_ERR_STATE = -4      /* e.g. step graph not built                   */
 } vaura_status;
 
-/* storage of the streamed matrices.  VAURA_W_FP8 (BASELINE configs[4]; no reference counterpart): OCP e4m3 with
- * one power-of-two scale per output row, for the four per-layer matrices; heads / conditioning stay bf16.   */
-typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1, VAURA_W_FP8 = 2 } vaura_wdtype;
+/* storage of the streamed matrices.
+ *   VAURA_W_H2  (hi, lo) fp16 planes + power-of-two row scales: 22 significand bits, 4 bytes per weight — fp32 checkpoints on
+ *               the fp16-pair decode kernels (gemv3_kernel.h); the default for real (fp32) checkpoints
+ *   VAURA_W_H1  one fp16 plane + row scales, 2 bytes per weight: lossless for checkpoints whose weights fit 11 significand
+ *               bits (bf16-representable ones: 8)
+ *   VAURA_W_FP8 (BASELINE configs[4]; no reference counterpart): OCP e4m3 with one power-of-two scale per output row, for the
+ *               four per-layer matrices; heads stay VAURA_W_H1
+ *   VAURA_W_F32 / VAURA_W_BF16: fp32 / bf16 MFMA tiles of the exact-fp32-MFMA GEMVs (gemv_kernel.h): the conditioning MLP, and
+ *               the decode step when the split workspaces are NULL (an exact, slower cross-check)                        */
+typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1, VAURA_W_FP8 = 2, VAURA_W_H1 = 3, VAURA_W_H2 = 4 } vaura_wdtype;
 
 /* ---- model geometry: configs/modules/samplers/llama_9cbs.yaml:3-17 + sampler/llama.py:308-361 */
 typedef struct vaura_dims {
@@ -102,7 +111,7 @@ typedef struct vaura_decoder {
                                 prompt is teacher-forced in chunks of that many positions per pass (bf16 path) */
 
   const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
-  const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles (bf16 when wdtype is FP8) llama.py:356-361 */
+  const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles (VAURA_W_H1 when wdtype is FP8) llama.py:356-361 */
   const float* final_norm;   /* (d_model)                                          llama.py:355 */
   const float* tok_emb;      /* (K, vocab+1, codebook_dim)                         llama.py:392-404 */
   const float* tok_proj_w;   /* (K, tok_dim, codebook_dim) weight-norm folded      llama.py:405-409 */
@@ -120,13 +129,14 @@ typedef struct vaura_decoder {
 
   float* ws_h;               /* packed rows (rows x d_model) residual stream        */
   float* ws_qkv;             /* packed rows (rows x 3*d_model)                      */
-  float* ws_qkv2;            /* optional, same shape (one position's worth): with bf16 storage the decode step's qkv GEMV
+  float* ws_qkv2;            /* optional, same shape (one position's worth): on the pair path the decode step's qkv GEMV
                                 then runs as two K-half workgroup sets (ws_qkv, ws_qkv2) that attention adds on load   */
   float* ws_attn;            /* packed rows (rows x d_model)                        */
   float* ws_ffn;             /* packed rows (rows x ffn_dim)                        */
   float* ws_logits;          /* row-major (rows, K*vocab)                           */
-  /* bf16-weight path only: activations as exact hi/mid/lo bf16 planes ("split rows", see
-   * vaura_amd/csrc/gemv3_kernel.h) and per-tile partial sums of squares for the fused RMSNorm  */
+  /* pair path (wdtype H1 / H2 / FP8): activations as (hi, lo) fp16 planes ("split rows", 2 * rows_padded * C fp16, see
+   * vaura_amd/csrc/gemv3_kernel.h) and per-tile partial sums of squares for the fused RMSNorm.  NULL with wdtype F32 / BF16
+   * selects the exact-fp32-MFMA step                                                                              */
   uint16_t* ws_h_split;      /* split rows (rows x d_model) of h * next_norm_gain   */
   uint16_t* ws_attn_split;   /* split rows (rows x d_model)                         */
   uint16_t* ws_ffn_split;    /* split rows (rows x ffn_dim)                         */
@@ -214,16 +224,16 @@ void vaura_profile_outliers(int64_t* per_kind);
  * 4 row-major logits.  K must be one of the compiled depths (512, 768, 1024, 1536, 4096).        */
 int vaura_gemv(const void* w, int wdtype, const float* x, const float* gain, const float* residual, float* out,
                int64_t rows, int64_t N, int64_t K, int epilogue, float eps, vaura_stream_t s);
-/* bf16-weight form of vaura_gemv: x as exact hi/mid/lo bf16 planes ("split rows"), products on
- * v_mfma_f32_16x16x32_bf16.  ss_in (row_blocks, n_ss_in, 16): partial sums of squares of the raw input
+/* pair form of vaura_gemv: x as (hi, lo) fp16 planes ("split rows"), weights as fp16 plane(s) or fp8, products on
+ * v_mfma_f32_16x16x32_f16.  ss_in (row_blocks, n_ss_in, 16): partial sums of squares of the raw input
  * (fused RMSNorm) or NULL.  Optional outputs: fp32 packed rows, split rows of out*gain_out, partial
  * sums of squares of out.  epilogue: 0 store, 1 +residual, 2 SwiGLU pairs, 4 row-major logits.       */
-int vaura_gemv_bf16(const void* w, int wdtype /* BF16 | FP8 */, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
-                    float* out_khalf2 /* NULL, or (bf16, K = 1536, fused norm, store): `out` gets the partial over the first half
+int vaura_gemv_pair(const void* w, int wdtype /* H1 | H2 | FP8 */, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+                    float* out_khalf2 /* NULL, or (K = 1536, fused norm, store): `out` gets the partial over the first half
                                          of K and this buffer the second half's; the consumer adds them */,
                     uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s);
-/* packed rows (rows x C) fp32 [* gain] -> split rows (3 * rows_padded * C bf16) [+ partial sums of squares] */
+/* packed rows (rows x C) fp32 [* gain] -> split rows (2 * rows_padded * C fp16: hi plane, lo plane) [+ partial sums of squares] */
 int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* ss, int64_t rows, int64_t C, vaura_stream_t s);
 
 /* a8/a9 for one layer at position `pos` (host value): rope(q,k), append, softmax(qK^T/sqrt(hd)) V. */

@@ -33,7 +33,7 @@ def test_frames_to_wav_file_against_the_oracle_chain(tmp_path):
     model.eval()
     assert model.audio_encoder.__class__.__name__ == "DacModelWrapper"
     model.sampler.audio_tokens_per_video_frame = 7
-    assert model.sampler.resolved_weight_dtype == "f32"          # an un-rounded checkpoint: "auto" keeps fp32 storage
+    assert model.sampler.resolved_weight_dtype == "h2"           # an un-rounded checkpoint: "auto" -> two fp16 planes (22 bits)
     # ---- :302-325 (single chunk)
     T, cfg_scale = 20, 3.0
     frames = synth.video_frames(2, 4, seed=31)                   # (B, S, 3, 16, 224, 224): 4 segments of 16 frames = 2.56 s

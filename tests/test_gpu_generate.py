@@ -10,15 +10,14 @@ from vaura_amd import synth
 from vaura_amd.engine import CodecEngine, DecoderEngine
 
 DEV = "cuda:0"
-WDTYPES = ["f32", "bf16"]
-# (storage, kernels for f32 storage): "planes" = fp32 weights split into bf16 planes in registers (default),
-# "mfma32" = the exact-fp32-MFMA GEMVs kept as a cross-check
-ENGINE_KINDS = [("f32", "planes"), ("f32", "mfma32"), ("bf16", "planes")]
+# storages of the streamed matrices: "h2" = (hi, lo) fp16 planes (what "auto" gives an fp32 checkpoint), "h1" = one fp16 plane
+# (lossless for the bf16-representable synthetic checkpoint), "f32" = the exact-fp32-MFMA GEMVs kept as a cross-check
+ENGINE_KINDS = ["h2", "f32", "h1"]
 
 
-@pytest.fixture(scope="module", params=ENGINE_KINDS, ids=lambda k: f"{k[0]}-{k[1]}")
+@pytest.fixture(scope="module", params=ENGINE_KINDS)
 def tiny_engine(request, tiny_sampler_sd):
-    return DecoderEngine(synth.tiny_sampler(2), tiny_sampler_sd, DEV, wdtype=request.param[0], f32_kernels=request.param[1])
+    return DecoderEngine(synth.tiny_sampler(2), tiny_sampler_sd, DEV, wdtype=request.param)
 
 
 def _ref(g, k):
@@ -118,18 +117,18 @@ def test_random_depth_against_live_oracle():
     feats = synth.video_features(3, tokens=3, seed=78)
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
     ref = go.generate(dec, feats, 33, mode="cached")
-    eng = DecoderEngine(cfg, sd, DEV, wdtype="bf16")
+    eng = DecoderEngine(cfg, sd, DEV, wdtype="h1")
     got = eng.generate_codes(feats.to(DEV), 33).cpu()
     assert torch.equal(got, ref)
 
 
-@pytest.mark.parametrize("wdtype,kernels", ENGINE_KINDS, ids=lambda v: str(v))
-def test_full_size_greedy_tokens_match_reference(golden, full_sampler_sd, wdtype, kernels):
+@pytest.mark.parametrize("wdtype", ENGINE_KINDS)
+def test_full_size_greedy_tokens_match_reference(golden, full_sampler_sd, wdtype):
     """configs[0]-shaped case at full depth (24 layers, 694 M params), B=2, T=220, greedy:
     tokens identical to what the reference's cache-less CPU generate() produced (bf16-representable checkpoint:
     every storage holds the same numbers)."""
     g = golden("full_greedy_B2_T220.npz")
-    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd, DEV, wdtype=wdtype, f32_kernels=kernels)
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd, DEV, wdtype=wdtype)
     feats = synth.video_features(2, seed=int(g["feat_seed"])).to(DEV)
     tok = eng.generate_codes(feats, 220).cpu()
     ref = _ref(g, "tokens")
@@ -139,19 +138,20 @@ def test_full_size_greedy_tokens_match_reference(golden, full_sampler_sd, wdtype
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("kernels", ["planes", "mfma32"])
-def test_unrounded_checkpoint_f32_storage_against_live_oracle(kernels):
-    """A checkpoint whose weights bf16 cannot hold (no rounding at synthesis = a real fp32 checkpoint's situation):
-    the default storage decision is f32, and the f32-storage engine is token-exact against the oracle — greedy,
-    ragged batch, CFG + top-k sampling with a recorded noise stream, and a teacher-forced prompt."""
+@pytest.mark.parametrize("wdtype", ["auto", "f32"])
+def test_unrounded_checkpoint_against_live_oracle(wdtype):
+    """A checkpoint whose weights 16 bits cannot hold (no rounding at synthesis = a real fp32 checkpoint's situation):
+    the default storage decision is two fp16 planes ("h2"), and both that engine and the exact-fp32-MFMA one ("f32") are
+    token-exact against the oracle — greedy, ragged batch, CFG + top-k sampling with a recorded noise stream, and a
+    teacher-forced prompt."""
     from oracle import generate_oracle as go
     from oracle.decoder_oracle import DecoderOracle
     cfg = synth.tiny_sampler(3)
     sd = synth.sampler_state_dict(cfg, seed=171, round_bf16=False)
     assert not all(torch.equal(sd[k], sd[k].bfloat16().float()) for k in sd if synth.is_streamed_weight(k))
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
-    eng = DecoderEngine(cfg, sd, DEV, f32_kernels=kernels)          # wdtype="auto"
-    assert eng.wdtype == "f32" and eng.requested_wdtype == "auto"
+    eng = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
+    assert eng.wdtype == ("h2" if wdtype == "auto" else "f32") and eng.requested_wdtype == wdtype
     feats = synth.video_features(3, tokens=3, seed=172)
     ref = go.generate(dec, feats, 33, mode="cached")
     assert torch.equal(eng.generate_codes(feats.to(DEV), 33).cpu(), ref)
@@ -169,18 +169,18 @@ def test_unrounded_checkpoint_f32_storage_against_live_oracle(kernels):
 def test_full_size_unrounded_checkpoint_matches_reference(golden, full_sampler_sd_raw):
     """Full depth, B=2, T=220, greedy, on the UN-rounded 694 M-parameter checkpoint, against tokens the reference's
     own cache-less CPU generate() produced for that checkpoint (make_golden.py full_greedy_raw; min top-1/top-2
-    margin 6.6e-5).  (1) default storage ("auto" -> f32): tokens identical; (2) bf16 storage FORCED on this
-    checkpoint rounds 694 M weights: not token-exact by construction — its agreement and logit error are REPORTED
-    (gpurun_out/r02_bf16_storage_on_raw_checkpoint.json), with a loose sanity bound only."""
+    margin 6.6e-5).  (1) default storage ("auto" -> two fp16 planes, 22 bits): tokens identical, first-forward logits within
+    3e-5; (2) ONE plane FORCED on this checkpoint rounds 694 M weights to 11 bits: not token-exact by construction — its
+    agreement and logit error are REPORTED (gpurun_out/r03_h1_storage_on_raw_checkpoint.json), with a loose sanity bound only."""
     import json
     import os
     g = golden("full_greedy_raw_B2_T220.npz")
     ref = _ref(g, "tokens")
     feats = synth.video_features(2, seed=int(g["feat_seed"])).to(DEV)
     eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV)      # "auto"
-    assert eng.wdtype == "f32"
+    assert eng.wdtype == "h2"
     tok = eng.generate_codes(feats, 220).cpu()
-    assert torch.equal(tok, ref), f"f32 storage: token agreement {float((tok == ref).float().mean()):.4f}"
+    assert torch.equal(tok, ref), f"h2 storage: token agreement {float((tok == ref).float().mean()):.4f}"
     # first forward of the reference run = position 0 of every row (all special tokens): its recorded logits
     step1 = torch.from_numpy(g["logits"][list(g["logits_steps"]).index(1)])            # (B, K, V)
     idx0 = torch.full((2, 9, 1), 1024, dtype=torch.long)
@@ -189,7 +189,7 @@ def test_full_size_unrounded_checkpoint_matches_reference(golden, full_sampler_s
     assert err32 < 3e-5, err32
     del eng
     torch.cuda.empty_cache()
-    e16 = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV, wdtype="bf16")
+    e16 = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV, wdtype="h1")
     tok16 = e16.generate_codes(feats, 220).cpu()
     lg16 = e16.logits_all_positions(idx0.to(DEV), feats)[:, :, 0].cpu()
     del e16
@@ -199,14 +199,14 @@ def test_full_size_unrounded_checkpoint_matches_reference(golden, full_sampler_s
     err16 = float((lg16 - step1).abs().max())
     rel16 = float((lg16 - step1).pow(2).mean().sqrt() / step1.pow(2).mean().sqrt())
     rep = {"checkpoint": "synth.sampler_state_dict(FULL_SAMPLER, seed=0, round_bf16=False)", "B": 2, "T": 220,
-           "f32_storage": {"token_agreement": 1.0, "logits_max_abs_err_step1": err32},
-           "bf16_storage": {"token_agreement": agree, "first_frame_with_a_different_token": first_bad,
+           "h2_storage": {"token_agreement": 1.0, "logits_max_abs_err_step1": err32},
+           "h1_storage": {"token_agreement": agree, "first_frame_with_a_different_token": first_bad,
                             "logits_max_abs_err_step1": err16, "logits_rel_rms_step1": rel16},
            "reference_min_margin": float(g["margins"].min())}
-    print("bf16 storage forced on an un-rounded checkpoint:", json.dumps(rep))
+    print("one fp16 plane forced on an un-rounded checkpoint:", json.dumps(rep))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "r02_bf16_storage_on_raw_checkpoint.json"), "w") as f:
+    with open(os.path.join(out, "r03_h1_storage_on_raw_checkpoint.json"), "w") as f:
         json.dump(rep, f, indent=1)
     assert err16 < 0.1 and 0.0 < agree <= 1.0      # a rounded model is close, and it IS a different model than f32
 
@@ -216,7 +216,7 @@ def test_configs1_batch8_full_row_block_matches_reference(golden, full_sampler_s
     reference's B=2 goldens — greedy cfg 1 (8 rows) and CFG 6 / top-k 250 sampled (16 rows = one FULL row block, the
     benchmark's shape) with the reference's noise stream in the rows of clips 0-1."""
     g = golden("full_greedy_B2_T220.npz")
-    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd, DEV, wdtype="bf16")
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd, DEV, wdtype="h1")
     feats = synth.video_features(8, seed=int(g["feat_seed"])).to(DEV)
     tok = eng.generate_codes(feats, 220).cpu()
     assert torch.equal(tok[:2], _ref(g, "tokens")), float((tok[:2] == _ref(g, "tokens")).float().mean())
@@ -229,7 +229,7 @@ def test_configs1_batch8_full_row_block_matches_reference(golden, full_sampler_s
     assert int(tok.min()) >= 0 and int(tok.max()) < 1024
 
 
-@pytest.mark.parametrize("wdtype", ["bf16", "f32"])
+@pytest.mark.parametrize("wdtype", ["h1", "h2"])
 def test_configs3_long_context_matches_reference(golden, wdtype):
     """BASELINE configs[3] at full depth against the reference itself (make_golden.py full_c4: the reference
     Transformer built with block_size_audio=1024, Tv=128, cfg 1.0, B=1, greedy, T=880 -> 888 cache-less passes):
@@ -255,7 +255,7 @@ def test_full_size_sampled_tokens_match_reference(golden, full_sampler_sd):
     """configs[1] sampling settings (top-k 250, cfg 6.0) at B=2 with the reference's own CPU noise
     stream (seed recorded in the fixture) -> identical tokens."""
     g = golden("full_topk250_cfg6_B2_T220.npz")
-    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd, DEV, wdtype="bf16")
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd, DEV, wdtype="h1")
     feats = synth.video_features(2, seed=int(g["feat_seed"])).to(DEV)
     nz = synth.exp_noise(228, 18, 1024, int(g["noise_seed"]))
     tok = eng.generate_codes(feats, 220, use_sampling=True, temp=1.0, top_k=250, cfg_scale=6.0, noise=nz).cpu()
@@ -293,7 +293,7 @@ def test_two_row_blocks_with_cfg_against_live_oracle():
     feats = synth.video_features(10, seed=32)
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
     ref = go.generate(dec, feats, 14, mode="cached", cfg_scale=6.0)
-    for wd in WDTYPES:
+    for wd in ("f32", "h1", "h2"):
         eng = DecoderEngine(cfg, sd, DEV, wdtype=wd)
         got = eng.generate_codes(feats.to(DEV), 14, cfg_scale=6.0).cpu()
         assert torch.equal(got, ref), wd
@@ -310,7 +310,7 @@ def test_long_context_single_pass_against_live_oracle():
     feats = synth.video_features(2, tokens=128, seed=42)
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead, block_size=1024)
     ref = go.generate(dec, feats, 300, mode="cached")
-    eng = DecoderEngine(cfg, sd, DEV, wdtype="bf16")
+    eng = DecoderEngine(cfg, sd, DEV, wdtype="h1")
     got = eng.generate_codes(feats.to(DEV), 300).cpu()
     assert eng.max_len >= 1024
     assert torch.equal(got, ref), float((got == ref).float().mean())
@@ -331,7 +331,7 @@ def test_batched_prompt_prefill_against_live_oracle(B, cfg_scale, pass_positions
     prompt = torch.randint(0, 1024, (B, 9, 40), generator=torch.Generator().manual_seed(53))
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
     ref = go.generate(dec, feats, 60, prompt=prompt, mode="cached", cfg_scale=cfg_scale)
-    eng = DecoderEngine(cfg, sd, DEV, wdtype="bf16")
+    eng = DecoderEngine(cfg, sd, DEV, wdtype="h1")
     got = eng.generate_codes(feats.to(DEV), 60, prompt=prompt.to(DEV), cfg_scale=cfg_scale).cpu()
     assert torch.equal(got[:, :, :40], prompt)
     assert torch.equal(got, ref), float((got == ref).float().mean())
@@ -377,14 +377,14 @@ def test_fp8_full_size_agreement_with_bf16(full_sampler_sd):
     lg8 = e8.logits_all_positions(idx.to(DEV), feats).cpu()
     del e8
     torch.cuda.empty_cache()
-    e_eff = DecoderEngine(cfg, quant.fp8_effective_state_dict(full_sampler_sd), DEV, wdtype="bf16")
+    e_eff = DecoderEngine(cfg, quant.fp8_effective_state_dict(full_sampler_sd), DEV, wdtype="h1")
     greedy_eff = e_eff.generate_codes(feats, 220, cfg_scale=6.0).cpu()
     lg_eff = e_eff.logits_all_positions(idx.to(DEV), feats).cpu()
     del e_eff
     torch.cuda.empty_cache()
     assert float((lg8 - lg_eff).abs().max()) < 2e-5, float((lg8 - lg_eff).abs().max())
     assert torch.equal(greedy8, greedy_eff), float((greedy8 == greedy_eff).float().mean())
-    e16 = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype="bf16")
+    e16 = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype="h1")
     tok16 = e16.generate_codes(feats, 220, **kw).cpu()
     lg16 = e16.logits_all_positions(idx.to(DEV), feats).cpu()
     del e16
@@ -450,8 +450,8 @@ def test_codec_round_trip_through_the_plugin():
 def test_two_engines_interleaved_keep_their_own_step_graphs(tiny_sampler_sd):
     """Each engine owns the hipGraph it captured (vaura_step_graph_build returns a handle): A, B, A again must
     not replay B's graph against A's buffers."""
-    a = DecoderEngine(synth.tiny_sampler(2), tiny_sampler_sd, DEV, wdtype="bf16")
-    b = DecoderEngine(synth.tiny_sampler(2), synth.sampler_state_dict(synth.tiny_sampler(2), seed=9), DEV, wdtype="bf16")
+    a = DecoderEngine(synth.tiny_sampler(2), tiny_sampler_sd, DEV, wdtype="h1")
+    b = DecoderEngine(synth.tiny_sampler(2), synth.sampler_state_dict(synth.tiny_sampler(2), seed=9), DEV, wdtype="h1")
     fa, fb = synth.video_features(2, seed=1).to(DEV), synth.video_features(3, seed=2).to(DEV)
     a1 = a.generate_codes(fa, 16, cfg_scale=6.0).cpu()
     b1 = b.generate_codes(fb, 16).cpu()
@@ -533,7 +533,7 @@ def test_configs4_per_gpu_shape_fp8_weights_and_mx8_codec(full_sampler_sd):
     assert int(s8.min()) >= 0 and int(s8.max()) < 1024
     del e8
     torch.cuda.empty_cache()
-    e_eff = DecoderEngine(cfg, quant.fp8_effective_state_dict(full_sampler_sd), DEV, wdtype="bf16")
+    e_eff = DecoderEngine(cfg, quant.fp8_effective_state_dict(full_sampler_sd), DEV, wdtype="h1")
     g_eff = e_eff.generate_codes(feats, 220, cfg_scale=6.0).cpu()
     seq_eff = e_eff.seq.clone()
     K = g8.shape[1]

@@ -100,7 +100,7 @@ SPLIT_GEMV_CASES = [
     (4096, 1536, L.EPI_RESID, False, 16),
     (1536, 9216, L.EPI_LOGITS, True, 7),
     (1536, 4608, L.EPI_STORE, True, 40),
-    # >= 16 row blocks: the prefill GEMM tiling (bf16 and fp8 weights); 17 / 19 blocks = ragged M tile
+    # >= 16 row blocks: the prefill GEMM tiling; 17 / 19 blocks = ragged M tile
     (1536, 4608, L.EPI_STORE, True, 300),
     (1536, 1536, L.EPI_RESID, False, 256),
     (1536, 8192, L.EPI_SWIGLU, True, 260),
@@ -110,13 +110,16 @@ SPLIT_GEMV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("wdtype", [L.W_BF16, L.W_FP8])
+@pytest.mark.parametrize("wdtype", [L.W_H1, L.W_H2, L.W_FP8])
 @pytest.mark.parametrize("K,N,epi,norm,rows", SPLIT_GEMV_CASES)
 def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
-    """vaura_gemv_bf16: activations as exact hi/mid/lo bf16 planes, bf16 or fp8 weights, fused RMSNorm via
-    partial sums of squares, optional split / sum-of-squares outputs for the next kernel.  The fp8 case is
-    checked against the SAME fp64 product on the dequantised matrix (quant.fp8_effective_weight)."""
+    """vaura_gemv_pair: activations as (hi, lo) fp16 planes (22 significand bits), weights as one fp16 plane (a
+    bf16-representable matrix: held exactly), two planes (an fp32 matrix: 22 bits) or fp8, fused RMSNorm via partial sums of
+    squares, optional split / sum-of-squares outputs for the next kernel.  Checked against the fp64 product on the matrix the
+    storage HOLDS (engine.h_effective_weight / quant.fp8_effective_weight) and, for two planes, also on the fp32 matrix itself:
+    the tolerance there is what 22-bit operands cost (2^-22 per product, averaged over K)."""
     from vaura_amd import quant
+    from vaura_amd.engine import h_effective_weight
     g = torch.Generator().manual_seed(K + N + epi + rows + 1)
     w = torch.randn(N, K, generator=g) * 0.02
     x = torch.randn(rows, K, generator=g)
@@ -128,7 +131,11 @@ def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
     if epi == L.EPI_SWIGLU:
         F_ = N // 2
         w = torch.stack([w[:F_].view(F_ // 16, 16, K), w[F_:].view(F_ // 16, 16, K)], dim=1).reshape(N, K)
-    w_eff = quant.fp8_effective_weight(w) if wdtype == L.W_FP8 else synth.to_bf16_exact(w)
+    if wdtype == L.W_H1:
+        w = synth.to_bf16_exact(w)
+    w_eff = quant.fp8_effective_weight(w) if wdtype == L.W_FP8 else h_effective_weight(w, 1 if wdtype == L.W_H1 else 2)
+    if wdtype == L.W_H1:
+        assert torch.equal(w_eff, w)          # one plane holds a bf16-representable matrix exactly
     # the producer's side of the fused norm: x*gain travels as planes, sum(x^2) as per-tile partials
     xd = x.to(DEV)
     xs, ss = ops.split_rows(ops.pack_rows(xd), rows, K, gain.to(DEV) if norm else None, want_ss=norm)
@@ -142,20 +149,22 @@ def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
         ref = res.double() + y
     else:
         ref = y
-    wp = ops.pack_weight(w.to(DEV) if wdtype == L.W_FP8 else w_eff.to(DEV), wdtype)
+    wp = ops.pack_weight(w.to(DEV), wdtype)
     resp = ops.pack_rows(res.to(DEV)) if res is not None else None
     want = epi != L.EPI_LOGITS
     if epi == L.EPI_SWIGLU:
         gain_out = torch.ones(n_out)     # the SwiGLU output feeds w2 directly: no norm gain in between
-    out, osp, oss = ops.gemv_bf16(wp, xs, rows, N, K, epi, ss_in=ss if norm else None, residual=resp,
+    out, osp, oss = ops.gemv_pair(wp, xs, rows, N, K, epi, ss_in=ss if norm else None, residual=resp,
                                   gain_out=gain_out.to(DEV) if want and epi != L.EPI_SWIGLU else None, want_split=want,
                                   want_ss=want and epi != L.EPI_SWIGLU, eps=eps, wdtype=wdtype)
     got = out.cpu() if epi == L.EPI_LOGITS else ops.unpack_rows(out, rows, n_out).cpu()
     assert rel_err(got.double(), ref) < 3e-6, rel_err(got.double(), ref)
     if want:
         planes = ops.unsplit_rows(osp, rows, n_out).cpu()
-        # the planes add up to out*gain_out exactly (fp32 sums of 8-bit pieces are exact)
-        assert torch.equal((planes[0] + planes[1]) + planes[2], got * gain_out)
+        # hi = fp16(v), lo = fp16(v - hi) of v = out * gain_out: the planes' own definition, bit for bit
+        v = got * gain_out
+        assert torch.equal(planes[0], v.half().float()) and torch.equal(planes[1], (v - v.half().float()).half().float())
+        assert float(((planes[0] + planes[1]) - v).abs().max()) <= float(v.abs().max()) * 2.0 ** -22
         if oss is not None:
             ssum = oss.view(-1, n_out // 16, 16).sum(1).reshape(-1)[:rows].cpu()
             assert rel_err(ssum, (got * got).sum(-1)) < 1e-5
@@ -173,14 +182,14 @@ def test_k_split_gemv_partials_add_up(rows):
     xs, ss = ops.split_rows(ops.pack_rows(x.to(DEV)), rows, K, gain.to(DEV), want_ss=True)
     rp = (rows + 15) // 16 * 16
     out2 = torch.full((rp * N,), float("nan"), device=DEV)
-    out, _, _ = ops.gemv_bf16(ops.pack_weight(w.to(DEV), L.W_BF16), xs, rows, N, K, L.EPI_STORE, ss_in=ss, out_khalf2=out2)
+    out, _, _ = ops.gemv_pair(ops.pack_weight(w.to(DEV), L.W_H1), xs, rows, N, K, L.EPI_STORE, ss_in=ss, out_khalf2=out2)
     x64 = x.double()
     ref = ((x64 * gain.double()) * torch.rsqrt(torch.mean(x64 * x64, dim=-1, keepdim=True) + 1e-5)) @ w.double().t()
     a, b = ops.unpack_rows(out, rows, N).cpu().double(), ops.unpack_rows(out2, rows, N).cpu().double()
     assert rel_err(a + b, ref) < 3e-6
     assert float(b.abs().max()) > 0.01 and rel_err(a, ref) > 0.1        # each half really is a partial
     with pytest.raises(L.VauraHipError):                                 # only that instance is compiled
-        ops.gemv_bf16(ops.pack_weight(w[:1536].to(DEV), L.W_BF16), xs, rows, 1536, K, L.EPI_RESID,
+        ops.gemv_pair(ops.pack_weight(w[:1536].to(DEV), L.W_H1), xs, rows, 1536, K, L.EPI_RESID,
                       residual=torch.zeros(rp * 1536, device=DEV), out_khalf2=out2)
 
 

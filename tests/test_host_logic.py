@@ -200,20 +200,28 @@ def test_sliding_window_schedule_known_answers():
 
 
 def test_auto_weight_storage_follows_the_checkpoint():
-    """"auto" (the plugin default) stores bf16 only when that loses nothing; an un-rounded (real-checkpoint-shaped) dict
-    resolves to f32 — the reference samples in fp32 (configs/vaura_defaults.yaml precision: 32)."""
-    from vaura_amd.engine import bf16_lossless, resolve_weight_dtype
+    """"auto" (the plugin default) stores one fp16 plane only when that loses nothing; an un-rounded (real-checkpoint-shaped)
+    dict resolves to two planes — the reference samples in fp32 (configs/vaura_defaults.yaml precision: 32)."""
+    from vaura_amd.engine import h1_lossless, h_effective_weight, resolve_weight_dtype
     from vaura_amd.sampler import Transformer
     cfg = synth.tiny_sampler(1)
     rounded = synth.sampler_state_dict(cfg, seed=1, round_bf16=True)
     raw = synth.sampler_state_dict(cfg, seed=1, round_bf16=False)
-    assert resolve_weight_dtype(rounded, "auto") == "bf16" and resolve_weight_dtype(raw, "auto") == "f32"
-    assert resolve_weight_dtype(raw, "bf16") == "bf16"       # forcing a storage is still possible (and rounds)
+    assert resolve_weight_dtype(rounded, "auto") == "h1" and resolve_weight_dtype(raw, "auto") == "h2"
+    assert resolve_weight_dtype(raw, "h1") == "h1" and resolve_weight_dtype(raw, "bf16") == "h1"      # forcing a storage is still possible (and rounds)
+    with pytest.raises(L.VauraHipError):
+        resolve_weight_dtype(raw, "int4")
     one = dict(rounded)
     k = "layers.0.feed_forward.w2.weight"
     one[k] = one[k].clone()
     one[k][3, 5] += 2.0 ** -20                               # a single unrepresentable weight is enough
-    assert not bf16_lossless(one[k]) and resolve_weight_dtype(one, "auto") == "f32"
+    assert not h1_lossless(one[k]) and resolve_weight_dtype(one, "auto") == "h2"
+    # two planes hold an fp32 matrix to 2^-22 of every element, or 2^-38 of the row's largest for the tiny ones (the row scale
+    # puts the largest at 2^13..2^14, so only elements below 2^-17 of it reach fp16's denormal spacing)
+    w = raw[k]
+    err = (h_effective_weight(w, 2) - w).abs()
+    assert bool((err <= torch.maximum(w.abs() * 2.0 ** -22, w.abs().amax(dim=1, keepdim=True) * 2.0 ** -38)).all())
+    assert torch.equal(h_effective_weight(rounded[k], 1), rounded[k])
     assert Transformer(**cfg.yaml_params()).weight_dtype == "auto"
 
 

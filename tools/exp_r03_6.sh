@@ -1,0 +1,11 @@
+set -u
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+O=gpurun_out/r03/exp6.log
+: > $O
+LIB=vaura_amd/csrc/libvaura_hip.so
+echo "== pair format: h1 / h2 decode loop" >> $O
+timeout 600 tools/pmc_driver $LIB --time 5 --flags 0 --weights h1 >> $O 2>&1
+timeout 600 tools/pmc_driver $LIB --time 5 --flags 0 --weights h2 >> $O 2>&1
+timeout 3000 python -m pytest tests/test_gpu_ops.py tests/test_gpu_generate.py tests/test_gpu_plugins.py tests/test_gpu_e2e.py -q 2>&1 | tail -40 >> $O
+cat $O

@@ -4,7 +4,7 @@
 // (include/vaura_hip.h) on a full-size decoder descriptor (24 layers, 1536/4096, 16 rows = 8 clips with CFG) filled with seeded
 // values.  No python, no env/bash hop: the program itself goes after `--`.
 //
-//   pmc_driver <lib> [--weights bf16|f32] [--steps 24] [--pos0 100] [--rows 16]
+//   pmc_driver <lib> [--weights h1|h2] [--steps 24] [--pos0 100] [--rows 16]
 //   pmc_driver <lib> --time 7 [--flags 0,1,...] [--weights ...]     A/B timing, no profiler: for every debug-flag set
 //       (vaura_set_debug_flags) one captured step graph; `--time` rounds of the full 228-step loop per variant, INTERLEAVED in
 //       one process (median / min reported), then the per-stage averages of one eager pass (vaura_profile_loop)
@@ -29,13 +29,18 @@ __global__ void fill_f32(float* p, size_t n, float scale, float offset, uint32_t
     p[i] = offset + scale * ((float)(h & 0xffff) / 32768.0f - 1.0f);
   }
 }
-__global__ void fill_bf16(uint16_t* p, size_t n, float scale, uint32_t seed) {
+// fp16 plane images: a tile image is a permutation of the matrix, so any finite values are a valid weight set.  `planes` = 2: even
+// 1 KiB blocks are hi planes (|v| < 4096), odd ones lo planes (|v| < 2)
+__global__ void fill_f16(_Float16* p, size_t n, int planes, uint32_t seed) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t h = (uint32_t)i * 2654435761u ^ seed;
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-    const float v = scale * ((float)(h & 0xffff) / 32768.0f - 1.0f);
-    p[i] = (uint16_t)(__builtin_bit_cast(uint32_t, v) >> 16);
+    const bool lo = planes == 2 && ((i >> 9) & 1);
+    p[i] = (_Float16)((lo ? 2.0f : 4096.0f) * ((float)(h & 0xffff) / 32768.0f - 1.0f));
   }
+}
+__global__ void fill_const(float* p, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 __global__ void fill_i32(int32_t* p, size_t n, int32_t v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
@@ -47,15 +52,18 @@ static float* dev_f32(size_t n, float scale, float offset = 0.f) {
   fill_f32<<<1024, 256>>>(p, n, scale, offset, g_seed++);
   return p;
 }
-static void* dev_weight(size_t n, int wd) {   // any bytes are a valid MFMA-tile image: the layout is a permutation
-  if (wd == VAURA_W_BF16) { uint16_t* p; CK(hipMalloc(&p, n * 2)); fill_bf16<<<1024, 256>>>(p, n, 0.035f, g_seed++); return p; }
-  return dev_f32(n, 0.035f);
+static void* dev_weight(size_t N, size_t K, int wd) {   // N x K fp16 plane(s) in MFMA-tile order + float scale[N] (2^-17: weights of +-0.03)
+  const int planes = wd == VAURA_W_H2 ? 2 : 1;
+  char* p; CK(hipMalloc(&p, N * K * 2 * planes + N * 4));
+  fill_f16<<<1024, 256>>>((_Float16*)p, N * K * planes, planes, g_seed++);
+  fill_const<<<64, 256>>>((float*)(p + N * K * 2 * planes), N, 7.62939453125e-06f);
+  return p;
 }
 template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights bf16|f32] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
-  int wd = VAURA_W_BF16, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1;
+  if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights h1|h2] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
+  int wd = VAURA_W_H1, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1;
   const char* stamps_out = nullptr;
   std::vector<unsigned> variants{0u};
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -64,7 +72,7 @@ int main(int argc, char** argv) {
       variants.clear();
       for (char* t = strtok(argv[i + 1], ","); t; t = strtok(nullptr, ",")) variants.push_back((unsigned)strtoul(t, nullptr, 0));
     }
-    if (!strcmp(argv[i], "--weights")) wd = !strcmp(argv[i + 1], "f32") ? VAURA_W_F32 : VAURA_W_BF16;
+    if (!strcmp(argv[i], "--weights")) wd = (!strcmp(argv[i + 1], "h2") || !strcmp(argv[i + 1], "f32")) ? VAURA_W_H2 : VAURA_W_H1;   // h1 | h2
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
@@ -86,12 +94,12 @@ int main(int argc, char** argv) {
   d.prefill_positions = 0;
   std::vector<vaura_layer_weights> lw(NL);
   for (int l = 0; l < NL; ++l) {
-    lw[l].wqkv = dev_weight((size_t)3 * D * D, wd); lw[l].wo = dev_weight((size_t)D * D, wd);
-    lw[l].w13 = dev_weight((size_t)2 * F * D, wd); lw[l].w2 = dev_weight((size_t)D * F, wd);
+    lw[l].wqkv = dev_weight(3 * D, D, wd); lw[l].wo = dev_weight(D, D, wd);
+    lw[l].w13 = dev_weight(2 * F, D, wd); lw[l].w2 = dev_weight(D, F, wd);
     lw[l].attn_norm = dev_f32(D, 0.2f, 1.0f); lw[l].ffn_norm = dev_f32(D, 0.2f, 1.0f);
   }
   d.layers_host = lw.data();
-  d.heads = dev_weight((size_t)K * V * D, wd);
+  d.heads = dev_weight((size_t)K * V, D, wd);
   d.final_norm = dev_f32(D, 0.2f, 1.0f);
   d.tok_emb = dev_f32((size_t)K * (V + 1) * 8, 1.f); d.tok_proj_w = dev_f32((size_t)K * 1024 * 8, 0.3f); d.tok_proj_b = dev_f32((size_t)K * 1024, 0.02f);
   d.tok_table = dev_f32((size_t)K * (V + 1) * 1024, 0.5f);
@@ -123,7 +131,7 @@ int main(int argc, char** argv) {
     if (!set_g || !set_a || !gbuild || !gloop) { fprintf(stderr, "%s is not a stamps build\n", argv[1]); return 1; }
     const size_t cap = 1500000;
     unsigned long long* buf; CK(hipMalloc(&buf, (8 + cap * 16) * 8)); CK(hipMemset(buf, 0, (8 + cap * 16) * 8));
-    unsigned long long hdr[2] = {0, cap};
+    unsigned long long hdr[3] = {0, cap, getenv("PMC_STAMP_ALL_WAVES") ? 1ull : 0ull};
     vaura_step_graph_t g;
     if (gbuild(&d, &sp, st, &g)) { fprintf(stderr, "graph build\n"); return 3; }
     const int32_t st0[4] = {pos0, 0, 0, 1};
@@ -142,7 +150,7 @@ int main(int argc, char** argv) {
     if (!f) { perror(stamps_out); return 1; }
     fwrite(host.data() + 8, 128, n, f);
     fclose(f);
-    printf("stamps: %zu records of %d steps at position %d (rows %d, weights %s) -> %s\n", n, steps, pos0, rows, wd == VAURA_W_F32 ? "f32" : "bf16", stamps_out);
+    printf("stamps: %zu records of %d steps at position %d (rows %d, weights %s) -> %s\n", n, steps, pos0, rows, wd == VAURA_W_H2 ? "h2" : "h1", stamps_out);
     return 0;
   }
   if (chains > 1) {
@@ -246,7 +254,7 @@ int main(int argc, char** argv) {
       const int rc = prof(&d, &sp, n, 0xFF, tot, cnt, st);
       if (rc) { fprintf(stderr, "profile_loop: %d\n", rc); return 3; }
       printf("flags %u weights %s rows %d: loop of %d steps median %.3f ms min %.3f ms (%.1f us/step) |", variants[v],
-             wd == VAURA_W_F32 ? "f32" : "bf16", rows, n, ms[v][ms[v].size() / 2], ms[v][0], 1e3 * ms[v][ms[v].size() / 2] / n);
+             wd == VAURA_W_H2 ? "h2" : "h1", rows, n, ms[v][ms[v].size() / 2], ms[v][0], 1e3 * ms[v][ms[v].size() / 2] / n);
       for (int k = 0; k < 8; ++k) printf(" %s %.2f", kinds[k], 1e3 * tot[k] / (cnt[k] ? cnt[k] : 1));
       printf("\n");
     }
@@ -262,6 +270,6 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(st));
   int32_t st1[4];
   CK(hipMemcpy(st1, d.state, sizeof st1, hipMemcpyDeviceToHost));
-  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wd == VAURA_W_F32 ? "f32" : "bf16", rows, pos0, st1[0] - 1);
+  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wd == VAURA_W_H2 ? "h2" : "h1", rows, pos0, st1[0] - 1);
   return st1[0] == pos0 + steps ? 0 : 4;
 }

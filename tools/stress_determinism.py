@@ -29,7 +29,7 @@ def screen(name, fn, n=N):
 
 cfg = synth.FULL_SAMPLER
 feats = synth.video_features(8, seed=0).to(dev)
-for wd, sd in (("bf16", synth.sampler_state_dict(cfg, seed=0, round_bf16=True)), ("f32", synth.sampler_state_dict(cfg, seed=0, round_bf16=False))):
+for wd, sd in (("h1", synth.sampler_state_dict(cfg, seed=0, round_bf16=True)), ("h2", synth.sampler_state_dict(cfg, seed=0, round_bf16=False))):
     eng = DecoderEngine(cfg, sd, dev, wdtype=wd)
     kw = dict(use_sampling=True, temp=1.0, top_k=250, cfg_scale=6.0, seed=7)
     screen(f"decode loop, {wd} storage, 8 clips, top-k 250, cfg 6", lambda: eng.generate_codes(feats, 220, **kw), max(4, N // 4))

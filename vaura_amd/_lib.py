@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvaura_hip.so")
 
-W_F32, W_BF16, W_FP8 = 0, 1, 2
+W_F32, W_BF16, W_FP8, W_H1, W_H2 = 0, 1, 2, 3, 4
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_LOGITS = 0, 1, 2, 3, 4
 KERNEL_KINDS = ("embed", "qkv", "attn", "wo", "w13", "w2", "heads", "sample")
 
@@ -138,7 +138,7 @@ SIGNATURES = {
     "vaura_profile_outliers": (None, [C.POINTER(C.c_int64)]),
     "vaura_gemv": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                              C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
-    "vaura_gemv_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "vaura_gemv_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     "vaura_split_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "vaura_attention_step_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

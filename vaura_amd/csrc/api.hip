@@ -54,9 +54,9 @@ void va_prof_events(hipEvent_t* a, hipEvent_t* b) {
 static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const float* res, float* out, uint16_t* outp,
                     const float* gain_out, float* ss_out, const vaura_decoder* d, int N, int n_pos = 1) {
   Gemv3Args a;
-  // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay bf16.
-  // VAURA_W_F32: fp32 MFMA tiles, split into bf16 planes in registers by the GEMV itself
-  a.wq = d->wdtype == VAURA_W_F32 ? 2 : ((d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0);
+  // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay one fp16 plane.
+  // VAURA_W_H2: (hi, lo) fp16 planes — the A operands as loaded
+  a.wq = d->wdtype == VAURA_W_H2 ? 2 : ((d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0);
   a.wscale = nullptr; a.out2 = nullptr;
   a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
   a.gain_out = gain_out; a.ss_out = ss_out;
@@ -99,8 +99,7 @@ static int enqueue_prefill_chunk_bf16(const vaura_decoder* d, int p0, int n, hip
   return 0;
 }
 
-// plane path (bf16 / fp8 storage, and fp32 storage when the split workspaces are given): activations travel as exact
-// hi/mid/lo bf16 planes, products on the bf16 MFMA
+// pair path (H1 / H2 / FP8 storage): activations travel as (hi, lo) fp16 planes, products on the fp16 MFMA
 static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
@@ -158,9 +157,9 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
 }
 
 static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
-  // fp32 storage: plane path when the caller provides the split workspaces, else the exact-fp32-MFMA GEMVs (gemv_kernel.h)
-  if (d->wdtype == VAURA_W_BF16 || d->wdtype == VAURA_W_FP8 || (d->wdtype == VAURA_W_F32 && d->ws_h_split))
-    return enqueue_step_bf16(d, sp, sample, s);
+  // H1 / H2 / FP8: the pair path; F32 / BF16 tiles: the exact-fp32-MFMA GEMVs (gemv_kernel.h)
+  if (d->wdtype == VAURA_W_H1 || d->wdtype == VAURA_W_H2 || d->wdtype == VAURA_W_FP8) return enqueue_step_bf16(d, sp, sample, s);
+  if (d->wdtype != VAURA_W_F32 && d->wdtype != VAURA_W_BF16) return VAURA_ERR_DTYPE;
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;
   const int rows = d->rows;

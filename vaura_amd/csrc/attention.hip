@@ -173,7 +173,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
 #pragma unroll
     for (int i = 1; i < 4; ++i) o += reinterpret_cast<const f32x4*>(red + i * HD)[tid];
     if (!prefill) o += reinterpret_cast<const f32x4*>(sv)[tid] * (sc[pos] * inv);
-    reinterpret_cast<f32x4*>(out)[packed_quad(vrow, (h * HD) / 4 + tid, D)] = o;
+    va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(vrow, (h * HD) / 4 + tid, D), o);
     if (outp) store_split4(outp, vrow, h * HD + 4 * tid, D, o);
   }
 }
@@ -247,7 +247,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   if (which == 2) y = gx;   // v is not rotated
   sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
   if (tid >= QUADS && tid < 3 * QUADS)
-    reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD)[cq] = y;
+    va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD) + cq, y);
   __syncthreads();
 #ifdef VAURA_STAMPS
   VA_STAMP(stamps, 3);                       // rotated q / k / v parked in LDS (first barrier)
@@ -330,7 +330,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
       o += wacc[w][tid] * f;
     }
     o *= 1.0f / denom;
-    reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
+    va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(row, (h * HD) / 4 + tid, D), o);
     if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
   }
 #ifdef VAURA_STAMPS
@@ -464,7 +464,7 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
   if (which == 2) y = gx;
   sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
   if (last && tid >= QUADS && tid < 3 * QUADS)
-    reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD)[cq] = y;
+    va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD) + cq, y);
   __syncthreads();
   f32x4 qf[QPL];
 #pragma unroll
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void attention_combine_kernel(const float* __re
   }
   o *= 1.0f / denom;
   const int D = n_head * HD;
-  reinterpret_cast<f32x4*>(out)[packed_quad(row, (h * HD) / 4 + tid, D)] = o;
+  va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(row, (h * HD) / 4 + tid, D), o);
   if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
 }
 

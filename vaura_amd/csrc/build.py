@@ -16,6 +16,8 @@ LIB = os.path.join(HERE, "libvaura_hip.so")
 # diagnostic build (--stamps): the same sources with -DVAURA_STAMPS (in-kernel s_memrealtime stamps, common.h); never loaded by the
 # package, only by tools/pmc_driver --stamps
 LIB_STAMPS = os.path.join(HERE, "libvaura_hip_stamps.so")
+# experiment build (--wt): -DVAURA_WT_STORES, write-through output stores (common.h); timed against the product by tools/pmc_driver
+LIB_WT = os.path.join(HERE, "libvaura_hip_wt.so")
 ARCH = "gfx950"
 # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs at wave launch (gfx94x/gfx950); the
 # compiler keeps a compatibility prologue that loads them the old way when the firmware does not preload
@@ -37,11 +39,12 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile(src: str, force: bool, stamps: bool = False) -> str:
-    obj = os.path.join(HERE, src.replace(".hip", ".stamps.o" if stamps else ".o"))
+def _compile(src: str, force: bool, stamps=False) -> str:
+    # stamps: False = product, True = -DVAURA_STAMPS, "wt" = -DVAURA_WT_STORES
+    obj = os.path.join(HERE, src.replace(".hip", ".wt.o" if stamps == "wt" else (".stamps.o" if stamps else ".o")))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, *(["-DVAURA_STAMPS"] if stamps else []), "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *(["-DVAURA_WT_STORES"] if stamps == "wt" else (["-DVAURA_STAMPS"] if stamps else [])), "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -50,9 +53,9 @@ def _compile(src: str, force: bool, stamps: bool = False) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, stamps=False) -> str:
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    LIB = LIB_STAMPS if stamps else globals()["LIB"]
+    LIB = LIB_WT if stamps == "wt" else (LIB_STAMPS if stamps else globals()["LIB"])
     with cf.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, stamps), srcs))
     if force or _stale(LIB, objs):
@@ -66,4 +69,4 @@ def build(force: bool = False, verbose: bool = False, stamps: bool = False) -> s
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True, stamps="--stamps" in sys.argv)
+    build(force="--force" in sys.argv, verbose=True, stamps="wt" if "--wt" in sys.argv else ("--stamps" in sys.argv))

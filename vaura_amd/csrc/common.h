@@ -77,6 +77,19 @@ inline int va_big_lds_once(const void* fn, size_t bytes, unsigned long long* don
 }
 
 
+// ---- output stores of the decode-step kernels.  VAURA_WT_STORES (experiment build, python -m vaura_amd.csrc.build --wt): every
+// store is write-through (sc0 sc1), so that a kernel leaves no dirty lines in its XCD's L2 for the end-of-kernel release to write
+// back (MI355X_MICROARCH.md: a release costs ~1.7 us clean, ~6.5 us behind freshly dirtied lines).  Product build: plain stores.
+#ifdef VAURA_WT_STORES
+__device__ __forceinline__ void va_st16(void* p, const f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void va_st8(void* p, const uint2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void va_st4(void* p, const float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+#else
+__device__ __forceinline__ void va_st16(void* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void va_st8(void* p, const uint2 v) { *reinterpret_cast<uint2*>(p) = v; }
+__device__ __forceinline__ void va_st4(void* p, const float v) { *reinterpret_cast<float*>(p) = v; }
+#endif
+
 // ---- in-kernel time stamps: DIAGNOSTIC BUILD ONLY (python -m vaura_amd.csrc.build --stamps -> libvaura_hip_stamps.so; the product
 // library is compiled without VAURA_STAMPS and contains none of this).  Every wave of the decode-step kernels reads
 // s_memrealtime (100 MHz, one counter for the whole chip: comparable across CUs and across launches) at fixed points and writes
@@ -84,7 +97,7 @@ inline int va_big_lds_once(const void* fn, size_t bytes, unsigned long long* don
 // collects them, tools/stamp_report.py turns them into the per-phase shares of profiles/r03_stage_stamps.json.  The stamps
 // drain the memory pipeline where they wait, so this build's run TIME means nothing; its phase SHARES do.
 #ifdef VAURA_STAMPS
-static __device__ unsigned long long* va_stamp_ptr = nullptr;   // [0] = record counter, [1] = capacity, records from [8]
+static __device__ unsigned long long* va_stamp_ptr = nullptr;   // [0] = record counter, [1] = capacity, [2] = 1: every wave writes a record (0: wave 0 only), records from [8]
 struct VaStamps { unsigned long long t[7]; };
 __device__ __forceinline__ unsigned long long va_now() {
   unsigned long long t;
@@ -96,7 +109,8 @@ __device__ __forceinline__ unsigned long long va_now() {
 #define VA_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 __device__ __forceinline__ void va_stamp_flush(const VaStamps& st, int kind) {
   unsigned long long* p = va_stamp_ptr;
-  if (!p || (threadIdx.x & 63) != 0) return;                 // lane 0 of EVERY wave: one 128-byte record per wave
+  if (!p || (threadIdx.x & 63) != 0) return;                 // lane 0: one 128-byte record per wave
+  if (p[2] == 0 && threadIdx.x != 0) return;                 // [2] = 0: wave 0 only (least perturbation: read spans and gaps from this mode)
   const unsigned long long slot = atomicAdd(p, 1ull);
   const unsigned long long t7 = va_now();                    // the slot counter's round trip is over: what follows is fire-and-forget
   if (slot >= p[1]) return;
@@ -130,6 +144,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
 struct Gemv3Args;
 unsigned va_debug_flags_get();   // vaura_set_debug_flags (gemv3.hip): kernel-variant switches for A/B measurements
 int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s);
+int va_pack_weight_h(const float* src, void* dst, int64_t N, int64_t K, int planes, hipStream_t s);   // fp16 plane(s) + row scales
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t s);
 int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_sampling* sp, const float* noise,

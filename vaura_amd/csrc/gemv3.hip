@@ -1,4 +1,4 @@
-// Launcher of the bf16-weight GEMV (gemv3_kernel.h): the decode-step instances.
+// Launcher of the fp16-pair GEMV (gemv3_kernel.h): the decode-step instances, weight ingress, op-level entry points.
 #include "gemv3_kernel.h"
 #include <cstdlib>
 
@@ -30,9 +30,16 @@ static int launch3h(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
 
 template <int WT>
 static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
-  // fp32 weights are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
+  // two weight planes are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
   // flight) like the K = 4096 instances their four, so that the slice a wave holds fits the register file without spills
   constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
+  if constexpr (WT == 2) {   // debug flag bit 14 (A/B): two-plane weights without batching — every request of a wave issued up front
+    if (va_debug_flags & 16384u) {
+      if (!norm && tiles % 8 == 0 && K == 4096 && epilogue == E3_RESID) return launch3h<2, 8, E3_RESID, 1>(a, tiles, s);
+      if (K == 1536 && epilogue == E3_STORE && norm) return launch3<2, 6, 8, 2, E3_STORE, true, 1>(a, tiles, s);
+      if (K == 1536 && epilogue == E3_SWIGLU && norm) return launch3<2, 6, 8, 2, E3_SWIGLU, true, 1>(a, tiles, s);
+    }
+  }
   if constexpr (WT != 1) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
     if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
       if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1>(a, tiles, s);
@@ -84,34 +91,86 @@ static int dispatch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, int epil
   return VAURA_ERR_SHAPE;
 }
 
+// bytes of one weight element by storage (a.wq): one fp16 plane 2, fp8 1, two fp16 planes 4; float scale[N] follows the tiles
+static const float* weight_scales(const Gemv3Args& a, int64_t n_weight_rows, int64_t K) {
+  const size_t per = a.wq == 1 ? 1 : (a.wq == 2 ? 4 : 2);
+  return reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K * per);
+}
+
 int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s) {
   Gemv3Args a = a0;
   if (!a.W || !a.XP || a.rows <= 0 || (n_weight_rows % 16)) return VAURA_ERR_ARG;
   if (norm && (!a.ss_in || a.n_ss_in <= 0 || a.n_ss_in > 128 || (int64_t)a.n_ss_in * 16 > K)) return VAURA_ERR_ARG;   // one partial per 16 columns of the normed vector
   const int64_t tiles = n_weight_rows / 16;
-  if (a.out2) {   // the caller asked for two K-half partials (decode qkv): bf16 weights, fused norm, K = 1536 only
+  a.wscale = weight_scales(a, n_weight_rows, K);
+  if (a.out2) {   // the caller asked for two K-half partials (decode qkv): fused norm, K = 1536 only
     if (K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
-    if (a.wq == 1) {   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
-      a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
-      return launch3<1, 6, 4, 3, E3_STORE, true, 1, 2>(a, tiles, s);
-    }
-    a.wscale = nullptr;
+    if (a.wq == 1) return launch3<1, 6, 4, 3, E3_STORE, true, 1, 2>(a, tiles, s);   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
     if (a.wq == 2) return launch3<2, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
     return launch3<0, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
   }
   // GEMM tiling only when there are enough row blocks to fill the chip with 64 x 256 tiles (a prompt pass); a decode
   // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
-  if (a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) {
-    a.wscale = a.wq == 1 ? reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K) : nullptr;
-    return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
-  }
-  if (a.wq == 1) {
-    a.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K);
-    return dispatch3<1>(a, tiles, K, epilogue, norm, s);
-  }
-  a.wscale = nullptr;
+  if (a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
+  if (a.wq == 1) return dispatch3<1>(a, tiles, K, epilogue, norm, s);
   if (a.wq == 2) return dispatch3<2>(a, tiles, K, epilogue, norm, s);
   return dispatch3<0>(a, tiles, K, epilogue, norm, s);
+}
+
+// ---------------------------------------------------------------------------- fp16-plane weight ingress
+// power-of-two row scale 2^E with amax / 2^E in [2^13, 2^14): both planes of a weight of ordinary size are normal fp16 numbers
+// (hi ~ 2^13, lo ~ 2^2), four binades of headroom below fp16's 65504
+__global__ void h_row_scale_kernel(const float* __restrict__ src, float* __restrict__ scale, int K) {
+  const float* row = src + (size_t)blockIdx.x * K;
+  float mx = 0.f;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, fabsf(row[k]));
+  mx = wave_max(mx);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    float sc = 1.f;
+    if (mx > 0.f) {
+      int e;
+      (void)frexpf(mx, &e);                     // mx = m * 2^e, m in [0.5, 1)
+      sc = ldexpf(1.f, e - 14);
+    }
+    scale[blockIdx.x] = sc;
+  }
+}
+
+// src row-major (N x K) fp32 -> MFMA-tile order, PL fp16 planes: [N/16][K/32][PL][64 lanes][8 fp16]; lane = n%16 + 16*((k%32)/8)
+template <int PL>
+__global__ void h_pack_kernel(const float* __restrict__ src, const float* __restrict__ scale, u32x4* __restrict__ dst, int64_t N, int64_t K) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t KG = K / 32;
+  if (gid >= (N / 16) * KG * 64) return;
+  const int lane = (int)(gid & 63);
+  const int64_t kg = (gid >> 6) % KG, tile = (gid >> 6) / KG;
+  const int64_t n = tile * 16 + (lane & 15);
+  const float inv = 1.0f / scale[n];            // exact: power of two
+  const float* p = src + n * K + kg * 32 + 8 * (lane >> 4);
+  _Float16 h[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float v = p[i] * inv;
+    h[i] = (_Float16)v;
+    l[i] = (_Float16)(v - (float)h[i]);
+  }
+  dst[((tile * KG + kg) * PL + 0) * 64 + lane] = u32x4{pack_h2(h[0], h[1]), pack_h2(h[2], h[3]), pack_h2(h[4], h[5]), pack_h2(h[6], h[7])};
+  if constexpr (PL == 2)
+    dst[((tile * KG + kg) * PL + 1) * 64 + lane] = u32x4{pack_h2(l[0], l[1]), pack_h2(l[2], l[3]), pack_h2(l[4], l[5]), pack_h2(l[6], l[7])};
+}
+
+int va_pack_weight_h(const float* src, void* dst, int64_t N, int64_t K, int planes, hipStream_t s) {
+  if ((N % 16) || (K % 32)) return VAURA_ERR_SHAPE;
+  float* scale = reinterpret_cast<float*>(static_cast<char*>(dst) + (size_t)N * (size_t)K * 2 * planes);
+  VA_LAUNCH(h_row_scale_kernel, dim3((unsigned)N), dim3(256), 0, s, src, scale, (int)K);
+  const int64_t total = (N / 16) * (K / 32) * 64;
+  if (planes == 2) VA_LAUNCH(h_pack_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, (const float*)scale, reinterpret_cast<u32x4*>(dst), N, K);
+  else VA_LAUNCH(h_pack_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, (const float*)scale, reinterpret_cast<u32x4*>(dst), N, K);
+  return 0;
 }
 
 // ---------------------------------------------------------------------------- fp8 weight ingress
@@ -200,13 +259,13 @@ int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* 
   return 0;
 }
 
-int vaura_gemv_bf16(const void* w, int wdtype, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
+int vaura_gemv_pair(const void* w, int wdtype, const uint16_t* x_split, const float* ss_in, int n_ss_in, const float* residual, float* out,
                     float* out_khalf2, uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s) {
   if (!w || !x_split || rows <= 0) return VAURA_ERR_ARG;
-  if (wdtype != VAURA_W_BF16 && wdtype != VAURA_W_FP8 && wdtype != VAURA_W_F32) return VAURA_ERR_DTYPE;
+  if (wdtype != VAURA_W_H1 && wdtype != VAURA_W_FP8 && wdtype != VAURA_W_H2) return VAURA_ERR_DTYPE;
   Gemv3Args a;
-  a.wq = wdtype == VAURA_W_FP8 ? 1 : (wdtype == VAURA_W_F32 ? 2 : 0); a.wscale = nullptr; a.out2 = out_khalf2;
+  a.wq = wdtype == VAURA_W_FP8 ? 1 : (wdtype == VAURA_W_H2 ? 2 : 0); a.wscale = nullptr; a.out2 = out_khalf2;
   a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
   a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
   a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K;

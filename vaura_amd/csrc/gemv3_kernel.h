@@ -1,16 +1,25 @@
-// Weight-streaming skinny GEMM, bf16-stored weights, exact-fp32 semantics on the bf16 matrix cores.
+// Weight-streaming skinny GEMM on the fp16 matrix cores with (hi, lo) fp16 PAIR operands: fp32 semantics to 22 significand bits.
 //
-// v_mfma_f32_16x16x4_f32 (gemv_kernel.h) is exact but runs at 1/16 of the bf16 MFMA rate: at 16 rows
-// its pipe time per decode GEMV is as long as the HBM stream it should hide under.  Here the fp32
-// activation is split ONCE, by the kernel that produces it, into three bf16 planes
-//        x = hi + mid + lo      hi = trunc_bf16(x), mid = trunc_bf16(x - hi), lo = x - hi - mid
-// which is exact (8 + 8 + 8 significand bits, residuals computed exactly in fp32), and the consumer
-// issues three v_mfma_f32_16x16x32_bf16 per 32-deep k-group: bf16 x bf16 products are exact in fp32,
-// each plane accumulates in its own fp32 accumulator (lo products never align against hi ones) and
-// the three are added once at the end.  Weights stored as bf16 ARE the MFMA A operand as loaded: no
-// VALU touches them.
+// v_mfma_f32_16x16x4_f32 (gemv_kernel.h) is exact but runs at 1/16 of the 16-bit MFMA rate: at 16 rows its pipe time per
+// decode GEMV is as long as the HBM stream it should hide under.  Here the fp32 activation is split ONCE, by the kernel that
+// produces it, into two fp16 planes
+//        x ~ hi + lo      hi = fp16(x) (round to nearest), lo = fp16(x - hi)            |x - hi - lo| <= 2^-23 |x|
+// and the consumer issues one v_mfma_f32_16x16x32_f16 per plane and 32-deep k-group (fp16 x fp16 products are exact in
+// fp32), each plane in its own fp32 accumulator (lo products never align against hi ones), added once at the end.
+// Weights are fp16 planes too, pre-split at pack time with a power-of-two scale per output row (so that neither plane sits
+// in fp16's denormal range; the scale multiplies the fp32 sum in the epilogue, exactly):
+//   one plane  ("h1")  a checkpoint whose weights fit 11 significand bits (bf16-representable ones do): w * x = w*hi + w*lo
+//   two planes ("h2")  fp32 checkpoints: w ~ whi + wlo (22 bits, same 4 bytes per weight as fp32):
+//                      w * x = whi*hi + (whi*lo + wlo*hi); the wlo*lo term (2^-22 relative) is below the operands' own rounding
+//   fp8 e4m3 tile pairs widen to fp16 exactly in registers.
+// Round 2 carried activations as THREE bf16 planes (exact 24-bit split, 6 bytes per element) and split fp32 weights into
+// three bf16 planes in registers (9 MFMAs + ~44 VALU per k-group).  The in-kernel stamps of round 3
+// (profiles/r03_stage_stamps_*.json) showed what that cost: every workgroup pulls the whole activation through its CU's
+// memory pipeline (147 KB per GEMV at K = 1536: more than its weight slice), and the fp32-weight kernels spent 4.5-6 us per
+// launch in the register split.  Pairs move 2/3 of the activation bytes, need no VALU on the weights, and keep the logits
+// within ~1e-5 of the fp32 reference (tokens of every reference golden unchanged; tests/test_gpu_generate.py).
 //
-// "split rows" layout of a (rows x C) activation:  [row_block][plane 0..2][C/8][16 rows][8] bf16
+// "split rows" layout of a (rows x C) activation:  [row_block][plane hi, lo][C/8][16 rows][8] fp16
 //   -> one wave load = the B operand (16 rows x 32 k) of one plane, contiguous 1 KiB.
 // RMSNorm: the producer multiplies by the NEXT norm's gain before splitting and writes per-tile partial
 // sums of squares; the consumer adds the partials in a fixed order and applies rsqrt(mean+eps) in its
@@ -18,14 +27,16 @@
 #pragma once
 #include "common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define VA_NPL 2   // activation planes
 
 enum { E3_STORE = 0, E3_RESID = 1, E3_SWIGLU = 2, E3_LOGITS = 4 };
 
 struct Gemv3Args {
-  const void* W;          // bf16 MFMA tiles, fp8 tile pairs + per-row scales (wq = 1), or fp32 MFMA tiles (wq = 2)
-  int wq;                 // 0: bf16 weights, 1: fp8 e4m3 weights with power-of-two row scales, 2: fp32 weights (split in registers)
-  const float* wscale;    // wq = 1: (weight rows) power-of-two scales (set by the launcher: they follow the tiles)
+  const void* W;          // one fp16 plane of MFMA tiles (wq = 0), fp8 tile pairs (wq = 1) or (hi, lo) fp16 planes (wq = 2); + row scales
+  int wq;                 // 0: one fp16 plane, 1: fp8 e4m3, 2: two fp16 planes — all with a power-of-two scale per output row
+  const float* wscale;    // (weight rows) power-of-two scales (set by the launcher: they follow the tiles)
   const uint16_t* XP;     // split rows (rows x K)
   const float* ss_in;     // NORM: (R, n_ss_in, 16) partial sums of squares of the raw input rows
   int n_ss_in;
@@ -43,107 +54,68 @@ struct Gemv3Args {
 
 __device__ __forceinline__ size_t split_index16(int rb, int plane, int octet, int row16, int C) {
   // index in 16-byte units
-  return (((size_t)rb * 3 + (size_t)plane) * (size_t)(C >> 3) + (size_t)octet) * 16 + (size_t)row16;
+  return (((size_t)rb * VA_NPL + (size_t)plane) * (size_t)(C >> 3) + (size_t)octet) * 16 + (size_t)row16;
 }
 
 // NB: take scalars by value — __builtin_bit_cast applied directly to an ext-vector ELEMENT expression
 // (v[i], u.y) reads element 0 for every index on hipcc 7.2.
 __device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t pack_h2(_Float16 a, _Float16 b) {
+  const f16x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, v);
+}
 
-// exact 3-way split of 4 fp32 values -> three 8-byte bf16 quads
-__device__ __forceinline__ void split3(const f32x4 v, uint2& hi, uint2& mid, uint2& lo) {
-  uint32_t h[4], m[4], l[4];
+// (hi, lo) fp16 split of 4 fp32 values -> two 8-byte fp16 quads.  |x| must stay below fp16's 65504 (activations of the
+// decoder are O(1..100)); values below 2^-14 lose their lo plane to fp16's denormal spacing (absolute error 2^-25).
+__device__ __forceinline__ void split2(const f32x4 v, uint2& hi, uint2& lo) {
+  _Float16 h[4], l[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float x = v[i];
-    const uint32_t uh = f2u(x) & 0xffff0000u;
-    const float r1 = x - u2f(uh);
-    const uint32_t um = f2u(r1) & 0xffff0000u;
-    const float r2 = r1 - u2f(um);
-    h[i] = uh; m[i] = um; l[i] = f2u(r2);
+    h[i] = (_Float16)x;
+    l[i] = (_Float16)(x - (float)h[i]);
   }
-  hi = uint2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-  mid = uint2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-  lo = uint2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+  hi = uint2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
+  lo = uint2{pack_h2(l[0], l[1]), pack_h2(l[2], l[3])};
 }
 
-// store 4 consecutive columns (c0 % 4 == 0) of one row as three planes
+// store 4 consecutive columns (c0 % 4 == 0) of one row as the two planes
 __device__ __forceinline__ void store_split4(uint16_t* base, int row, int c0, int C, const f32x4 v) {
-  uint2 hi, mid, lo;
-  split3(v, hi, mid, lo);
+  uint2 hi, lo;
+  split2(v, hi, lo);
   const int rb = row >> 4, m = row & 15, oct = c0 >> 3, half = (c0 >> 2) & 1;
   uint2* p = reinterpret_cast<uint2*>(base);
-  p[split_index16(rb, 0, oct, m, C) * 2 + half] = hi;
-  p[split_index16(rb, 1, oct, m, C) * 2 + half] = mid;
-  p[split_index16(rb, 2, oct, m, C) * 2 + half] = lo;
+  va_st8(p + split_index16(rb, 0, oct, m, C) * 2 + half, hi);
+  va_st8(p + split_index16(rb, 1, oct, m, C) * 2 + half, lo);
 }
 
 // fp8 weights ("fp8 tile pairs"): [N/16][K/64][64 lanes][16 bytes]; bytes 0..7 of a lane are its 8 e4m3
-// values of the even 32-deep k-group, bytes 8..15 those of the odd one (same lane->(n, k) map as the bf16
-// tiles), followed by float scale[N].  e4m3 -> bf16 is exact (3 significand bits), the row scale is a power
-// of two applied to the fp32 sum, so the kernel computes exactly what the bf16 path computes on the
+// values of the even 32-deep k-group, bytes 8..15 those of the odd one (same lane->(n, k) map as the fp16
+// tiles), followed by float scale[N].  e4m3 -> fp16 is exact (3 significand bits, exponents inside fp16's range), the row
+// scale is a power of two applied to the fp32 sum, so the kernel computes exactly what the one-plane path computes on the
 // dequantised matrix  W_eff = fp8 * scale.
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t a, uint32_t b) {
+__device__ __forceinline__ f16x8 fp8x8_to_f16(uint32_t a, uint32_t b) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2 p0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, false), p1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)a, true);
   const f32x2 p2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, false), p3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)b, true);
   const float e0 = p0[0], e1 = p0[1], e2 = p1[0], e3 = p1[1], e4 = p2[0], e5 = p2[1], e6 = p3[0], e7 = p3[1];
-  const u32x4 r = {(f2u(e0) >> 16) | (f2u(e1) & 0xffff0000u), (f2u(e2) >> 16) | (f2u(e3) & 0xffff0000u),
-                   (f2u(e4) >> 16) | (f2u(e5) & 0xffff0000u), (f2u(e6) >> 16) | (f2u(e7) & 0xffff0000u)};
-  return __builtin_bit_cast(bf16x8, r);
+  const f16x8 r = {(_Float16)e0, (_Float16)e1, (_Float16)e2, (_Float16)e3, (_Float16)e4, (_Float16)e5, (_Float16)e6, (_Float16)e7};
+  return r;
 }
 
-// fp32 weights (VAURA_W_F32 on the plane path): 8 consecutive-k weights of a lane arrive as two 16-byte loads and are
-// split in registers into exact hi / mid / lo bf16 planes (same truncation split as the activations: w = hi + mid + lo,
-// 8 + 8 + 8 significand bits), so every product of the 3 x 3 plane pairs is exact on the bf16 matrix cores.
-__device__ __forceinline__ void split3_w8(const u32x4 a, const u32x4 b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
-  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  uint32_t h[8], m[8], l[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t uh = w[i] & 0xffff0000u;
-    const float r1 = u2f(w[i]) - u2f(uh);
-    const uint32_t um = f2u(r1) & 0xffff0000u;
-    const float r2 = r1 - u2f(um);
-    h[i] = uh; m[i] = um; l[i] = f2u(r2);
-  }
-  const u32x4 ph = {(h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]};
-  const u32x4 pm = {(m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]};
-  const u32x4 pl = {(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u),
-                    (l[4] >> 16) | (l[5] & 0xffff0000u), (l[6] >> 16) | (l[7] & 0xffff0000u)};
-  hi = __builtin_bit_cast(bf16x8, ph);
-  mid = __builtin_bit_cast(bf16x8, pm);
-  lo = __builtin_bit_cast(bf16x8, pl);
-}
-
-// One 32-deep k-group of one 16-column tile: bf16 / fp8 weights -> one product per activation plane (acc[p], p = plane of
-// x); fp32 weights -> all nine plane pairs, accumulated by magnitude class (acc[0] hi.hi, acc[1] 2^-8, acc[2] 2^-16,
-// acc[3] the rest) so that small terms never align against large ones before the final ordered sum.
+// One 32-deep k-group of one 16-column tile.  One weight plane (WT 0 / 1): a product per activation plane, acc[p] for plane p
+// of x.  Two weight planes (WT 2): acc[0] = whi.xhi, acc[1] = whi.xlo + wlo.xhi (both 2^-11 terms share an accumulator; the
+// 2^-22 term wlo.xlo is dropped).  The accumulators are added smallest first, once, in the epilogue.
 template <int WT>
-__device__ __forceinline__ void mfma_group(const bf16x8* wf /* 1 or 3 planes */, const u32x4* x3, f32x4* acc) {
-  const bf16x8 x0 = __builtin_bit_cast(bf16x8, x3[0]), x1 = __builtin_bit_cast(bf16x8, x3[1]), x2 = __builtin_bit_cast(bf16x8, x3[2]);
-  if constexpr (WT == 2) {
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x1, acc[1], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x0, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x2, acc[2], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x1, acc[2], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], x0, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], x2, acc[3], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], x1, acc[3], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2], x2, acc[3], 0, 0, 0);
-  } else {
-    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x1, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], x2, acc[2], 0, 0, 0);
-  }
+__device__ __forceinline__ void mfma_group(const f16x8* wf /* 1 or 2 planes */, const u32x4* x2, f32x4* acc) {
+  const f16x8 x0 = __builtin_bit_cast(f16x8, x2[0]), x1 = __builtin_bit_cast(f16x8, x2[1]);
+  acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], x0, acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], x1, acc[1], 0, 0, 0);
+  if constexpr (WT == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], x0, acc[1], 0, 0, 0);
 }
 template <int WT>
-__device__ __forceinline__ f32x4 acc_sum(const f32x4* acc) {
-  if constexpr (WT == 2) return ((acc[3] + acc[2]) + acc[1]) + acc[0];
-  else return (acc[2] + acc[1]) + acc[0];
-}
+__device__ __forceinline__ f32x4 acc_sum(const f32x4* acc) { return acc[1] + acc[0]; }
 
 __device__ __forceinline__ float silu3_f(float a) { return a / (1.0f + expf(-a)); }
 
@@ -183,7 +155,7 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[2 * pr][r]) * v[2 * pr + 1][r];
       const int tile = tile0 / 2 + pr;   // tile of the ffn dimension
-      if (a.out) reinterpret_cast<f32x4*>(a.out)[((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane] = o;
+      if (a.out) va_st16(reinterpret_cast<f32x4*>(a.out) + ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane, o);
       if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
     }
   } else {
@@ -192,17 +164,17 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
       const int tile = tile0 + t;
       const int c0 = tile * 16 + 4 * q;
       if constexpr (EPI == E3_LOGITS) {
-        if (row < a.rows) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + c0) = v[t];
+        if (row < a.rows) va_st16(a.out + (size_t)row * a.N + c0, v[t]);
       } else {
         const size_t idx = ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane;
         f32x4 o = v[t];
         if constexpr (EPI == E3_RESID) o += (pre && pre->have && T == 1) ? pre->res : reinterpret_cast<const f32x4*>(a.res)[idx];
-        if (a.out) reinterpret_cast<f32x4*>(a.out)[idx] = o;
+        if (a.out) va_st16(reinterpret_cast<f32x4*>(a.out) + idx, o);
         if (a.ss_out) {
           float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
           s += __shfl_xor(s, 16, 64);
           s += __shfl_xor(s, 32, 64);
-          if (q == 0) a.ss_out[((size_t)rb * (a.N / 16) + tile) * 16 + m] = s;
+          if (q == 0) va_st4(a.ss_out + ((size_t)rb * (a.N / 16) + tile) * 16 + m, s);
         }
         if (a.outp) {
           f32x4 u = o;
@@ -215,16 +187,17 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 }
 
 // ABL: ablation bits for tools/microbench only (0 in the product): 1 = no MFMA, 2 = no x loads, 4 = no weight
-// loads, 8 = same k-slice order in every workgroup, 16 = TIMING of "activations as fp32 (4 B per element), split into the
-// three bf16 planes in registers by every workgroup": two of the three plane loads + split3_w8 per k-group (numbers meaningless).
+// loads, 8 = same k-slice order in every workgroup.
 // XB = number of x batches (2: the second half of the k-groups is fetched after the first half has
-// been consumed, for depths whose three planes do not fit the register budget at once)
-// WT = storage of the weights: 0 bf16 MFMA tiles, 1 fp8 tile pairs (+ row scales), 2 fp32 MFMA tiles (two 16-byte halves per
-// lane and k-group), split into bf16 planes in registers (split3_w8).  With WT = 2 and XB > 1 the weights travel in the same
-// batches as the activation planes (two batches in flight) instead of all up front: 8 bytes x 16 k-groups do not fit.
+// been consumed, for depths whose planes do not fit the register budget at once)
+// WT = storage of the weights: 0 one fp16 plane of MFMA tiles, 1 fp8 tile pairs, 2 (hi, lo) fp16 planes (two 16-byte halves
+// per lane and k-group: the A operands as loaded) — each followed by float scale[N].  With WT = 2 and XB > 1 the weights
+// travel in the same batches as the activation planes (two batches in flight) instead of all up front: 8 bytes x 16 k-groups
+// do not fit.
 // KS = 2: two workgroups per tile group, each over one half of K, each writing its own partial output (out / out2)
 // which the CONSUMER adds (attention gathers q, k, v anyway: one more 16-byte load).  For the qkv GEMV this turns
-// 144 workgroups x 245 KB into 192 x 147 KB: more CUs, fewer bytes through each CU's L2 port, no in-kernel seam.
+// 144 workgroups into 192 with half the activation bytes each: more CUs, fewer bytes through each CU's memory pipeline, no
+// in-kernel seam.
 template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, int WT = 0, int KS = 1>
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a) {
   // Wq / XPq duplicate a.W / a.XP as explicit scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs
@@ -244,13 +217,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   constexpr bool WBATCH = F32 && XB > 1;      // weights fetched batch by batch, with the planes
   constexpr int WH = F32 ? 2 : 1;             // 16-byte loads per lane, tile and k-group
   constexpr int GW = FP8 ? G / 2 : (WBATCH ? 2 * GB : G);   // weight register groups per tile
-  constexpr int NACC = F32 ? 4 : 3;
+  constexpr int NACC = 2;
   __shared__ f32x4 red[NW][T][64];
   constexpr int NSS = K / 64;            // partial sums of squares per lane: n_ss_in = K / 16 tiles, 4 lane groups
   constexpr int EWN = (EPI == E3_SWIGLU) ? 1 : T;   // waves that run the epilogue (see below)
-  // where the 24 values fit the register file next to the weight slice (bf16 / fp8 weights, 8 waves) the epilogue waves fetch
-  // them straight into registers; the fp32-weight and 16-wave instances park them in LDS (whole workgroup, one load each)
-  constexpr bool SS_DIRECT = NORM && WT != 2 && NW <= 8;
+  // the epilogue waves fetch them straight into registers (24 VGPRs next to the weight slice); instances with more than 8
+  // waves would park them in LDS instead (whole workgroup, one load each)
+  constexpr bool SS_DIRECT = NORM && NW <= 8;
   constexpr int SSL = (NORM && !SS_DIRECT) ? K : 4;   // n_ss_in * 16 <= K floats
   __shared__ float ssl[SSL];
 
@@ -274,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   // the activation descriptor ends with the last row block: lanes of batch rows that do not exist (a decode step of fewer
   // than 16 rows: configs[3] has 4, a single clip 1 or 2) are sent out of range — they read zeros, as the padding rows of the
   // planes would give them, WITHOUT moving the bytes: every workgroup pulls rows/16 of the 147 KB instead of all of it
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * 3 * (K / 8) * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * VA_NPL * (K / 8) * 256, 0x00020000);
   const int lane16 = lane * 16;
 
   // the weight slice of this wave lives in registers for the whole kernel: the decode step has one row
@@ -301,16 +274,16 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   // activation planes of the current batch of k-groups; the first batch of the NEXT row block is requested as soon as
   // the last MFMA of this one has been issued, so its round trip runs under the reduction / barrier / epilogue
   constexpr int NXB = XB > 1 ? 2 : 1;   // with several batches two are in flight (double buffer)
-  u32x4 xb[NXB][GB][3];
+  u32x4 xb[NXB][GB][VA_NPL];
   auto load_x = [&](int rb, int b) {
     const int xl16 = rb * 16 + m < a.rows ? lane16 : 0x7ffffff0;
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
-      for (int p = 0; p < ((ABL & 16) ? 2 : 3); ++p)
+      for (int p = 0; p < VA_NPL; ++p)
         xb[b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
                                       : __builtin_amdgcn_raw_buffer_load_b128(
-                                            xrs, xl16, (int)(((rb * 3 + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
+                                            xrs, xl16, (int)(((rb * VA_NPL + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
   };
 
   auto row_block = [&](const int rb, const bool first) {
@@ -361,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       for (int p = 0; p < NACC; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (first) {
       VA_STAMP(stamps, 1);                   // every request of the first batch issued
-      VA_WAIT_VM(GB * 3 + (SS_DIRECT ? NSS : (NORM ? SSN : 0)));
+      VA_WAIT_VM(GB * VA_NPL + (SS_DIRECT ? NSS : (NORM ? SSN : 0)));
       VA_STAMP(stamps, 2);                   // the weight tiles (HBM) have landed
       VA_WAIT_VM(0);
       VA_STAMP(stamps, 3);                   // the activation planes / partial sums (written by the previous kernel) have landed
@@ -375,27 +348,21 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
       }
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
-        if constexpr (ABL & 16) {
-          bf16x8 s0, s1, s2;
-          split3_w8(xb[b % NXB][g][0], xb[b % NXB][g][1], s0, s1, s2);
-          xb[b % NXB][g][0] = __builtin_bit_cast(u32x4, s0);
-          xb[b % NXB][g][1] = __builtin_bit_cast(u32x4, s1);
-          xb[b % NXB][g][2] = __builtin_bit_cast(u32x4, s2);
-        }
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          bf16x8 wf[F32 ? 3 : 1];
+          f16x8 wf[F32 ? 2 : 1];
           if constexpr (FP8) {
             const u32x4 pr = wb[t][(b * GB + g) / 2][0];
-            wf[0] = (g & 1) ? fp8x8_to_bf16(pr.z, pr.w) : fp8x8_to_bf16(pr.x, pr.y);
+            wf[0] = (g & 1) ? fp8x8_to_f16(pr.z, pr.w) : fp8x8_to_f16(pr.x, pr.y);
           } else if constexpr (F32) {
             const int slot = WBATCH ? (b & 1) * GB + g : b * GB + g;
-            split3_w8(wb[t][slot][0], wb[t][slot][WH - 1], wf[0], wf[1], wf[2]);
+            wf[0] = __builtin_bit_cast(f16x8, wb[t][slot][0]);          // hi plane
+            wf[1] = __builtin_bit_cast(f16x8, wb[t][slot][WH - 1]);     // lo plane
           } else {
-            wf[0] = __builtin_bit_cast(bf16x8, wb[t][b * GB + g][0]);
+            wf[0] = __builtin_bit_cast(f16x8, wb[t][b * GB + g][0]);
           }
           if constexpr (ABL & 1) {
-            asm volatile("" ::"v"(wf[0]), "v"(xb[b % NXB][g][0]), "v"(xb[b % NXB][g][1]), "v"(xb[b % NXB][g][2]));
+            asm volatile("" ::"v"(wf[0]), "v"(xb[b % NXB][g][0]), "v"(xb[b % NXB][g][1]));
           } else {
             mfma_group<WT>(wf, xb[b % NXB][g], acc[t]);
           }
@@ -452,7 +419,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         f32x4 sacc = red[0][t][lane];
 #pragma unroll
         for (int i = 1; i < NW; ++i) sacc += red[i][t][lane];
-        if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
+        sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);   // power-of-two row scales: exact
         v[e] = sacc * rinv;
       }
       gemv3_epilogue<ET, EPI>(a, rb, (EPI == E3_SWIGLU) ? tile0 : tile0 + wid, lane, v, &pre);
@@ -490,11 +457,11 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   VA_STAMP(stamps, 0);
   a.W = Wq;
   a.XP = XPq;
-  static_assert(WT == 0 || WT == 2, "bf16 or fp32 weights");
+  static_assert(WT == 0 || WT == 2, "one or two fp16 weight planes");
   static_assert(EPI == E3_RESID || EPI == E3_STORE, "independent output tiles only");
   constexpr bool F32 = WT == 2;
   constexpr int WH = F32 ? 2 : 1;
-  constexpr int NACC = F32 ? 4 : 3;
+  constexpr int NACC = 2;
   constexpr int K = 64 * G2 * NW;
   constexpr int KG = K / 32;
   constexpr int GB = G2 / XB;
@@ -513,12 +480,12 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   const int w = (wid + tile) % NW;            // de-phase the k-slices across workgroups
   const int la = lane & 7, sb = (lane >> 3) & 1, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * 3 * (K / 8) * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * VA_NPL * (K / 8) * 256, 0x00020000);
   const int voffw0 = (la + 16 * q) * 16 + sb * BS;          // weight rows 0..7 of the tile; + 128 bytes for rows 8..15
   const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;   // batch row la + 8 h of the block (out of range below when it does not exist)
 
   u32x4 wb[NB][GB][2][WH];
-  u32x4 xb[NB][GB][3];
+  u32x4 xb[NB][GB][VA_NPL];
   auto load_w = [&](int b) {
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
@@ -534,9 +501,9 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < VA_NPL; ++p)
         xb[b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, rb * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0,
-                                                                 ((rb * 3 + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
+                                                                 ((rb * VA_NPL + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
   };
 
   for (int rb = 0; rb < a.R; ++rb) {
@@ -559,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (rb == 0) {
       VA_STAMP(stamps, 1);
-      VA_WAIT_VM(GB * 3 + 2);                // wave 0 also holds the residual / gain requests
+      VA_WAIT_VM(GB * VA_NPL + 2);           // wave 0 also holds the residual / gain requests
       VA_STAMP(stamps, 2);
       VA_WAIT_VM(0);
       VA_STAMP(stamps, 3);
@@ -571,9 +538,9 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       for (int g = 0; g < GB; ++g) {
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
-          bf16x8 wf[F32 ? 3 : 1];
-          if constexpr (F32) split3_w8(wb[b % NB][g][nh][0], wb[b % NB][g][nh][WH - 1], wf[0], wf[1], wf[2]);
-          else wf[0] = __builtin_bit_cast(bf16x8, wb[b % NB][g][nh][0]);
+          f16x8 wf[F32 ? 2 : 1];
+          wf[0] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][0]);
+          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][WH - 1]);
           mfma_group<WT>(wf, xb[b % NB][g], acc[nh]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -603,6 +570,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       f32x4 v = red[0][q >> 1][src];
 #pragma unroll
       for (int i = 1; i < NW; ++i) v += red[i][q >> 1][src];
+      v *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);     // power-of-two row scales: exact
       if (mine) gemv3_epilogue<1, EPI>(a, rb, tile, lane, &v, &pre);
     }
 #ifdef VAURA_STAMPS
@@ -633,27 +601,27 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
   constexpr int RB = RBT, T = G3M_T, NW = G3M_NW;
   constexpr bool FP8 = WT == 1, F32 = WT == 2;
   constexpr int WH = F32 ? 2 : 1;
-  constexpr int NACC = F32 ? 4 : 3;
-  __shared__ u32x4 xs[2][RB * 3 * 64];
+  constexpr int NACC = 2;
+  __shared__ u32x4 xs[2][RB * VA_NPL * 64];
   __shared__ float rinv_s[RB * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rb0 = blockIdx.y * RB;
   const int tile0 = ((int)blockIdx.x * NW + wid) * T;
   const int KG = K / 32;
-  constexpr int XL = (RB * 3 * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group
+  constexpr int XL = (RB * VA_NPL * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group
   // buffer loads (see gemv3_kernel): SGPR descriptor + uniform offset, one VGPR offset per load; the activation descriptor
   // ends with the last row block, so row blocks past a.R read zeros without a branch
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * 3 * (K / 8) * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * VA_NPL * (K / 8) * 256, 0x00020000);
   int xvoff[XL];
 #pragma unroll
   for (int i = 0; i < XL; ++i) {
     const int idx = tid + i * NW * 64;                 // (rbi, plane, lane') with lane' = q * 16 + m
-    const int rbi = idx / 192, p = (idx / 64) % 3, l = idx & 63;
-    xvoff[i] = idx < RB * 192 ? ((rbi * 3 + p) * (K / 8) * 16 + l) * 16 : 0x7ffffff0;     // past the tile: out of range -> 0
+    const int rbi = idx / (64 * VA_NPL), p = (idx / 64) % VA_NPL, l = idx & 63;
+    xvoff[i] = idx < RB * 64 * VA_NPL ? ((rbi * VA_NPL + p) * (K / 8) * 16 + l) * 16 : 0x7ffffff0;     // past the tile: out of range -> 0
   }
-  const int xsoff0 = rb0 * 3 * (K / 8) * 256;
+  const int xsoff0 = rb0 * VA_NPL * (K / 8) * 256;
 
   u32x4 xr[XL], wr[T][WH];
   auto load_x = [&](int kg) {
@@ -664,7 +632,7 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NW * 64;
-      if (idx < RB * 192) xs[buf][idx] = xr[i];
+      if (idx < RB * 64 * VA_NPL) xs[buf][idx] = xr[i];
     }
   };
   auto load_w = [&](int kg) {   // fp8 tile pairs: one 16-byte load carries k-groups kg and kg + 1
@@ -703,19 +671,19 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
 
   for (int kg = 0; kg < KG; ++kg) {
     const int buf = kg & 1;
-    bf16x8 wf[T][F32 ? 3 : 1];
+    f16x8 wf[T][F32 ? 2 : 1];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      if constexpr (FP8) wf[t][0] = (kg & 1) ? fp8x8_to_bf16(wr[t][0].z, wr[t][0].w) : fp8x8_to_bf16(wr[t][0].x, wr[t][0].y);
-      else if constexpr (F32) split3_w8(wr[t][0], wr[t][WH - 1], wf[t][0], wf[t][1], wf[t][2]);
-      else wf[t][0] = __builtin_bit_cast(bf16x8, wr[t][0]);
+      if constexpr (FP8) wf[t][0] = (kg & 1) ? fp8x8_to_f16(wr[t][0].z, wr[t][0].w) : fp8x8_to_f16(wr[t][0].x, wr[t][0].y);
+      else wf[t][0] = __builtin_bit_cast(f16x8, wr[t][0]);
+      if constexpr (F32) wf[t][1] = __builtin_bit_cast(f16x8, wr[t][WH - 1]);
     }
     if (kg + 1 < KG) { load_x(kg + 1); load_w(kg + 1); }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      u32x4 x3[3];
+      u32x4 x3[VA_NPL];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) x3[p] = xs[buf][(r * 3 + p) * 64 + lane];
+      for (int p = 0; p < VA_NPL; ++p) x3[p] = xs[buf][(r * VA_NPL + p) * 64 + lane];
 #pragma unroll
       for (int t = 0; t < T; ++t) mfma_group<WT>(wf[t], x3, acc[r][t]);
     }
@@ -731,7 +699,7 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       f32x4 sacc = acc_sum<WT>(acc[r][t]);
-      if constexpr (FP8) sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * (lane >> 4));
+      sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * (lane >> 4));
       v[t] = sacc * rinv;
     }
     gemv3_epilogue<T, EPI>(a, rb0 + r, tile0, lane, v);

@@ -62,12 +62,12 @@ __global__ __launch_bounds__(64) void embed_kernel(
     for (int k = 0; k < 16; ++k)    // same left-to-right order as the reference's sum([...]) (llama.py:455-460)
       if (k < K) o += e[k];
   }
-  reinterpret_cast<f32x4*>(h)[packed_quad(vrow, cq, D)] = o;
+  va_st16(reinterpret_cast<f32x4*>(h) + packed_quad(vrow, cq, D), o);
   if (hsplit) {
     float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if ((threadIdx.x & 3) == 0) ss[((size_t)(vrow >> 4) * (D / 16) + (cq >> 2)) * 16 + (vrow & 15)] = s;
+    if ((threadIdx.x & 3) == 0) va_st4(ss + ((size_t)(vrow >> 4) * (D / 16) + (cq >> 2)) * 16 + (vrow & 15), s);
     const f32x4 u = o * *reinterpret_cast<const f32x4*>(gain + cq * 4);
     store_split4(hsplit, vrow, cq * 4, D, u);
   }
@@ -77,7 +77,7 @@ int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t
   const vaura_dims& m = d->dims;
   const int D = m.cond_dim + m.tok_dim;
   if (!d->tok_table || (D % 256)) return VAURA_ERR_SHAPE;
-  const bool split = d->wdtype != VAURA_W_F32 || d->ws_h_split != nullptr;   // plane path (api.hip enqueue_step)
+  const bool split = d->wdtype == VAURA_W_H1 || d->wdtype == VAURA_W_H2 || d->wdtype == VAURA_W_FP8;   // pair path (api.hip enqueue_step)
   if (split && (!d->ws_h_split || !d->ws_ss || !d->first_norm)) return VAURA_ERR_ARG;
   VA_LAUNCH(embed_kernel, dim3(d->rows, D / 256, n_pos), dim3(64), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
             d->tok_table, d->ws_h, split ? d->ws_h_split : nullptr, d->first_norm, d->ws_ss, d->batch, m.n_codebooks,

@@ -122,7 +122,7 @@ def split_rows(xp: torch.Tensor, rows: int, Cc: int, gain: Optional[torch.Tensor
     """packed rows fp32 -> (split rows int16 tensor, partial sums of squares or None)."""
     _cuda(xp, gain)
     rp = (rows + 15) // 16 * 16
-    dst = torch.zeros(rp * 3 * Cc, dtype=torch.int16, device=xp.device)
+    dst = torch.zeros(rp * 2 * Cc, dtype=torch.int16, device=xp.device)
     ss = torch.zeros((rp // 16) * (Cc // 16) * 16, dtype=torch.float32, device=xp.device) if want_ss else None
     L.check(L.lib().vaura_split_rows(L.ptr(xp), L.ptr(dst), L.ptr(gain), L.ptr(ss), rows, Cc, L.current_stream()),
             "vaura_split_rows")
@@ -130,17 +130,16 @@ def split_rows(xp: torch.Tensor, rows: int, Cc: int, gain: Optional[torch.Tensor
 
 
 def unsplit_rows(sp: torch.Tensor, rows: int, Cc: int) -> torch.Tensor:
-    """split rows -> (3, rows, C) fp32 planes (layout check helper; plain tensor ops on the device)."""
+    """split rows -> (2, rows, C) fp32 values of the hi and lo fp16 planes (layout check helper; plain tensor ops on the device)."""
     rp = (rows + 15) // 16 * 16
-    v = sp.view(rp // 16, 3, Cc // 8, 16, 8)
-    f = (v.to(torch.int32) << 16).view(torch.float32)
-    return f.permute(1, 0, 3, 2, 4).reshape(3, rp, Cc)[:, :rows]
+    f = sp.view(torch.float16).view(rp // 16, 2, Cc // 8, 16, 8).float()
+    return f.permute(1, 0, 3, 2, 4).reshape(2, rp, Cc)[:, :rows]
 
 
-def gemv_bf16(wp: torch.Tensor, x_split: torch.Tensor, rows: int, N: int, K: int, epilogue: int = L.EPI_STORE,
+def gemv_pair(wp: torch.Tensor, x_split: torch.Tensor, rows: int, N: int, K: int, epilogue: int = L.EPI_STORE,
               ss_in: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
               gain_out: Optional[torch.Tensor] = None, want_split: bool = False, want_ss: bool = False, eps: float = 1e-5,
-              wdtype: int = L.W_BF16, out_khalf2: Optional[torch.Tensor] = None):
+              wdtype: int = L.W_H1, out_khalf2: Optional[torch.Tensor] = None):
     """Returns (out, out_split, ss_out); out is packed rows, or row-major (rows, N) for EPI_LOGITS."""
     _cuda(wp, x_split, ss_in, residual, gain_out)
     n_out = N // 2 if epilogue == L.EPI_SWIGLU else N
@@ -148,10 +147,10 @@ def gemv_bf16(wp: torch.Tensor, x_split: torch.Tensor, rows: int, N: int, K: int
     dev = x_split.device
     out = torch.zeros(rows, N, dtype=torch.float32, device=dev) if epilogue == L.EPI_LOGITS else \
         torch.zeros(rp * n_out, dtype=torch.float32, device=dev)
-    osp = torch.zeros(rp * 3 * n_out, dtype=torch.int16, device=dev) if want_split else None
+    osp = torch.zeros(rp * 2 * n_out, dtype=torch.int16, device=dev) if want_split else None
     oss = torch.zeros((rp // 16) * (n_out // 16) * 16, dtype=torch.float32, device=dev) if want_ss else None
     n_ss = 0 if ss_in is None else K // 16
-    L.check(L.lib().vaura_gemv_bf16(L.ptr(wp), wdtype, L.ptr(x_split), L.ptr(ss_in), n_ss, L.ptr(residual), L.ptr(out), L.ptr(out_khalf2), L.ptr(osp),
+    L.check(L.lib().vaura_gemv_pair(L.ptr(wp), wdtype, L.ptr(x_split), L.ptr(ss_in), n_ss, L.ptr(residual), L.ptr(out), L.ptr(out_khalf2), L.ptr(osp),
                                     L.ptr(gain_out), L.ptr(oss), rows, N, K, epilogue, eps, L.current_stream()),
-            "vaura_gemv_bf16")
+            "vaura_gemv_pair")
     return out, osp, oss

@@ -74,8 +74,8 @@ class Transformer(nn.Module):
                                       norm_eps=layer_norm_eps, rope_base=c.rope_base, initializer_range=0.02)
         self.audio_tokens_per_video_frame: Optional[int] = None
         self.codebook_pattern = None
-        # Storage of the streamed matrices on the device.  "auto" (default): bf16 when that is lossless for the loaded
-        # checkpoint, else f32 — i.e. always the reference's fp32 numbers (engine.resolve_weight_dtype).  "bf16" / "fp8"
+        # Storage of the streamed matrices on the device (engine.resolve_weight_dtype).  "auto" (default): one fp16 plane when
+        # that is lossless for the loaded checkpoint, else two ("h2": 22 significand bits).  "h1" / "fp8"
         # force a smaller storage and ROUND a checkpoint that does not fit it (not token-exact any more); "f32" forces fp32.
         self.weight_dtype = weight_dtype
 
@@ -143,7 +143,7 @@ class Transformer(nn.Module):
 
     @property
     def resolved_weight_dtype(self) -> str:
-        """What "auto" resolved to for the parameters currently loaded ("bf16" | "f32" | "fp8")."""
+        """What "auto" resolved to for the parameters currently loaded ("h1" | "h2" | "fp8" | "f32")."""
         return self.engine().wdtype
 
     # ------------------------------------------------------------------ reference call surface
