@@ -335,6 +335,13 @@ def main():
                                        "unit": "GB/s", "frac": round(lb / (t_loop * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "bytes": lb}
         out["codec_tflops"] = round(B * 1.608e9 * T_FRAMES / (t_codec * 1e-3) / 1e12, 2)   # 1.608 GFLOP per codec frame
+        # codec decode is MFMA-bound: matrix instructions actually issued per algorithmic product x algorithmic FLOP/s against the
+        # dense peak of the instruction used (MI355X_MICROARCH.md: fp32-input MFMA 157 TF, fp16 2.5 PF, block-scaled fp8 5 PF)
+        mpp, cpeak = {"f32": (1, 157.3), "f16pair": (3, 2500.0), "f16pair_w8": (2, 2500.0), "f16": (1, 2500.0), "mx8": (1, 5000.0)}[args.codec]
+        out["codec_roofline"] = {"bound": "mfma", "achieved": round(mpp * out["codec_tflops"], 1), "peak": cpeak, "unit": "TFLOP/s",
+                                 "frac": round(mpp * out["codec_tflops"] / cpeak, 4), "algorithmic_tflops": out["codec_tflops"],
+                                 "matrix_instructions_per_product": mpp, "codec_ms": round(t_codec, 3),
+                                 "counters": "profiles/r03_codec_mfma.json (tools/mfma_driver under rocprofv3 --pmc)"}
 
         # per-kernel: every launch of one eager 228-step pass carries its own start/stop events on the stream
         # it is launched on (hipExtLaunchKernelGGL via vaura_profile_loop) = the interval rocprofv3 reports

@@ -1,26 +1,54 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun) from the repo root.  Usage: tools/profile_round.sh r02
-#   1. rocprofv3 kernel stats of the bench command itself (python) -> gpurun_out/prof_<tag>/stats
-#   2. the same kernels through the PRODUCT library driven by a plain C++ program (tools/pmc_driver.cpp dlopen()s
-#      vaura_amd/csrc/libvaura_hip.so and calls vaura_decode_step): kernel stats + separate --pmc passes for FETCH_SIZE and
-#      WRITE_SIZE (rocprofv3 --pmc crashes at start-up under python on this image; the counters need their own passes,
-#      MI355X_MICROARCH.md §rocprofv3 PMC slots).  The driver is rebuilt every time: no stale binary.
+# Run ON THE GPU BOX (via gpurun) from the repo root.  Usage: tools/profile_round.sh r03
+#   1. rocprofv3 kernel stats of the bench command itself (python) -> gpurun_out/prof_<tag>/stats (+ stats_c4 for configs[3])
+#   2. the decode-step kernels through the PRODUCT library driven by a plain C++ program (tools/pmc_driver.cpp dlopen()s
+#      vaura_amd/csrc/libvaura_hip.so): kernel stats + separate --pmc passes for FETCH_SIZE and WRITE_SIZE, for both storages
+#      (h2 = two fp16 planes, what real checkpoints get; h1 = one plane).  rocprofv3 --pmc crashes at start-up under python on this
+#      image; the counters need their own passes (MI355X_MICROARCH.md §rocprofv3 PMC slots).  Drivers are rebuilt every time.
+#   3. the MFMA-bound stages (codec decode, Segment-AVCLIP extractor) through tools/mfma_driver.cpp: kernel stats + MFMA / LDS /
+#      HBM counter passes
+#   4. in-kernel s_memrealtime stamps of the diagnostic build (wave 0 only, and every wave) -> per-phase json
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 LIB=$ROOT/vaura_amd/csrc/libvaura_hip.so
 DRV=$ROOT/tools/pmc_driver
-/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/pmc_driver.cpp -o $DRV -ldl || exit 1
+MDRV=$ROOT/tools/mfma_driver
+/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/pmc_driver.cpp -o $DRV -ldl -lpthread || exit 1
+/opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/mfma_driver.cpp -o $MDRV -ldl || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32 --no-plugin > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin > $OUT/bench_stats.log 2>&1
 tail -n 1 $OUT/bench_stats.log | cut -c1-300
-for W in bf16 f32; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c4 -- python3 $ROOT/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-second --no-plugin > $OUT/bench_stats_c4.log 2>&1
+tail -n 1 $OUT/bench_stats_c4.log | cut -c1-200
+for W in h2 h1; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights $W --steps 24 --pos0 100 > $OUT/drv_stats_$W.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights $W --steps 24 --pos0 100 > $OUT/drv_${C}_$W.log 2>&1
   done
   tail -n 1 $OUT/drv_stats_$W.log
 done
-find $OUT -name "*.csv" | head -30
+for M in codec avclip; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_stats_$M -- $MDRV $LIB $M 8 > $OUT/mfma_stats_$M.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma_pmcA_$M -- $MDRV $LIB $M 8 > $OUT/mfma_pmcA_$M.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F16 SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $OUT/mfma_pmcB_$M -- $MDRV $LIB $M 8 > $OUT/mfma_pmcB_$M.log 2>&1
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/mfma_${C}_$M -- $MDRV $LIB $M 8 > $OUT/mfma_${C}_$M.log 2>&1
+  done
+  tail -n 1 $OUT/mfma_stats_$M.log
+done
+cd $ROOT
+S=vaura_amd/csrc/libvaura_hip_stamps.so
+if [ -f $S ]; then
+  for W in h2 h1; do
+    $DRV $S --stamps $OUT/st_w0_$W.bin --steps 6 --pos0 100 --weights $W > $OUT/stamps_$W.log 2>&1
+    python3 tools/stamp_report.py $OUT/st_w0_$W.bin $OUT/stamps_wave0_$W.json >> $OUT/stamps_$W.log 2>&1
+    PMC_STAMP_ALL_WAVES=1 $DRV $S --stamps $OUT/st_all_$W.bin --steps 3 --pos0 100 --weights $W >> $OUT/stamps_$W.log 2>&1
+    python3 tools/stamp_report.py $OUT/st_all_$W.bin $OUT/stamps_allwaves_$W.json >> $OUT/stamps_$W.log 2>&1
+    rm -f $OUT/st_*_$W.bin
+    tail -n 8 $OUT/stamps_$W.log
+  done
+fi
+find $OUT -name "*.csv" | wc -l

@@ -2,9 +2,11 @@
 
   <tag>_bench_kernel_stats.csv        rocprofv3 --kernel-trace --stats of the python bench command
   <tag>_bench_under_rocprof.json      the JSON line that run printed
-  <tag>_driver_kernel_stats_<w>.csv   the same kernels through tools/pmc_driver (the product .so), w = bf16 | f32
+  <tag>_driver_kernel_stats_<w>.csv   the same kernels through tools/pmc_driver (the product .so), w = h2 | h1 (fp16 planes per weight)
   <tag>_pmc_hbm_bytes_<w>.json        HBM bytes per launch per kernel from separate FETCH_SIZE / WRITE_SIZE passes on the driver
-  kernel_names.json                   storage -> decode-step stage -> kernel name as rocprofv3 prints it (bench.py quotes it)
+  <tag>_codec_mfma.json, <tag>_avclip_mfma.json   MFMA / LDS / HBM counters of the MFMA-bound stages through tools/mfma_driver
+  <tag>_stage_stamps_<mode>_<w>.json  per-phase decomposition of the decode-step stages (in-kernel s_memrealtime stamps)
+  kernel_names.json                   storage | "c4" -> decode-step stage -> kernel name as rocprofv3 prints it (bench.py quotes it)
 
 The summariser REFUSES to write the PMC record unless every decode-step kernel name of the PMC passes also appears in the
 bench's own kernel stats: counters from an old build or another code object cannot end up next to fresh timings.
@@ -17,7 +19,7 @@ import re
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
@@ -69,7 +71,7 @@ def write_stats(path, dst, header):
 
 stats = newest(f"{src}/stats/**/*kernel_stats.csv")
 rows = write_stats(stats, f"profiles/{tag}_bench_kernel_stats.csv",
-                   "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-f32 --no-plugin")
+                   "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin   (auto -> h2 storage, un-rounded checkpoint)")
 bench_names = {clean(r["Name"]) for r in rows}
 log = [l for l in open(f"{src}/bench_stats.log").read().splitlines() if l.startswith("{")]
 open(f"profiles/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else "{}") + "\n")
@@ -86,7 +88,7 @@ def per_kernel(path, counter):
 
 
 names = {}
-for w in ("bf16", "f32"):
+for w in ("h2", "h1"):
     st = newest(f"{src}/drv_stats_{w}/**/*kernel_stats.csv")
     if not st:
         continue
@@ -97,7 +99,7 @@ for w in ("bf16", "f32"):
     fetch = per_kernel(f"{src}/drv_FETCH_SIZE_{w}", "FETCH_SIZE")
     write = per_kernel(f"{src}/drv_WRITE_SIZE_{w}", "WRITE_SIZE")
     step_kernels = {k for k in fetch if stage_of(k)}
-    if w == "bf16":
+    if w == "h2":
         missing = sorted(step_kernels - bench_names)
         if missing:
             raise SystemExit(f"PMC kernel names not in the bench's kernel stats (stale build?): {missing}")
@@ -115,7 +117,73 @@ for w in ("bf16", "f32"):
     json.dump(out, open(f"profiles/{tag}_pmc_hbm_bytes_{w}.json", "w"), indent=1)
     for k, v in out["kernels"].items():
         print(f"{w} {v['stage']:6s} {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB  {(v['avg_ns_same_driver_run'] or 0) / 1e3:7.2f} us  {k[:80]}")
+stats_c4 = newest(f"{src}/stats_c4/**/*kernel_stats.csv")
+if stats_c4:
+    crow = write_stats(stats_c4, f"profiles/{tag}_c4_kernel_stats.csv",
+                       "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-second --no-plugin")
+    c4 = {}
+    for r in sorted(crow, key=lambda r: -float(r["TotalDurationNs"])):       # per stage: the kernel with the largest total time
+        st_ = stage_of(clean(r["Name"]))
+        if st_ and st_ not in c4:
+            c4[st_] = clean(r["Name"])
+    names["c4"] = c4
 if names:
     json.dump(names, open("profiles/kernel_names.json", "w"), indent=1)
+
+# ---- MFMA-bound stages (tools/mfma_driver): time, MFMA work and busy cycles, LDS conflicts, HBM bytes per kernel
+def counters(path):
+    f = newest(f"{path}/**/*counter_collection.csv")
+    acc = defaultdict(lambda: defaultdict(list))
+    if f:
+        for r in csv.DictReader(open(f)):
+            acc[clean(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+for m in ("codec", "avclip"):
+    st = newest(f"{src}/mfma_stats_{m}/**/*kernel_stats.csv")
+    if not st:
+        continue
+    mrows = write_stats(st, f"profiles/{tag}_{m}_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- tools/mfma_driver libvaura_hip.so {m} 8   (3 passes of the stage)")
+    A, Bc = counters(f"{src}/mfma_pmcA_{m}"), counters(f"{src}/mfma_pmcB_{m}")
+    Fz, Wz = counters(f"{src}/mfma_FETCH_SIZE_{m}"), counters(f"{src}/mfma_WRITE_SIZE_{m}")
+    out = {"stage": m, "clips": 8, "source": f"tools/profile_round.sh {tag}: rocprofv3 --kernel-trace --pmc ... -- tools/mfma_driver libvaura_hip.so {m} 8 "
+                                             "(separate passes A: MFMA ops / busy cycles, B: LDS + MFMA instruction counts, FETCH_SIZE, WRITE_SIZE; averages per launch)",
+           "derived": {"mfma_flops": "SQ_INSTS_VALU_MFMA_MOPS_F16 (or _F32) x 512 (the counter's unit)",
+                       "elapsed_cycles": "GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs)",
+                       "mfma_busy_frac": "SQ_VALU_MFMA_BUSY_CYCLES / (elapsed_cycles x 1024 SIMDs)",
+                       "mfma_tflops": "mfma_flops / AverageNs of the kernel-trace pass of the same command",
+                       "frac_of_dense_fp16_peak": "mfma_tflops / 2500 (MI355X_MICROARCH.md: ~2.5 PFLOP/s dense)",
+                       "lds_conflict_frac": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
+                       "hbm_bytes": "2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024"},
+           "kernels": {}}
+    tot_ns = sum(float(r["TotalDurationNs"]) for r in mrows)
+    for r in sorted(mrows, key=lambda r: -float(r["TotalDurationNs"])):
+        k = clean(r["Name"])
+        a, b2 = A.get(k, {}), Bc.get(k, {})
+        if float(r["TotalDurationNs"]) < 0.005 * tot_ns:
+            continue
+        mops = a.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + a.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
+        cyc = a.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        avg_ns = float(r["AverageNs"])
+        rec = {"calls": int(r["Calls"]), "avg_us": round(avg_ns / 1e3, 2), "share_of_stage_time": round(float(r["TotalDurationNs"]) / tot_ns, 4),
+               "raw": {**{c: a[c] for c in sorted(a)}, **{c: b2[c] for c in sorted(b2)}}}
+        if mops and avg_ns:
+            rec["mfma_tflops"] = round(mops * 512 / avg_ns / 1e3, 1)
+            rec["frac_of_dense_fp16_peak"] = round(mops * 512 / avg_ns / 1e3 / 2500.0, 4)
+        if cyc and a.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            rec["mfma_busy_frac"] = round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0), 4)
+            rec["clock_ghz_from_gui_active"] = round(cyc / avg_ns, 3)
+        if b2.get("SQ_LDS_IDX_ACTIVE"):
+            rec["lds_conflict_frac"] = round(b2.get("SQ_LDS_BANK_CONFLICT", 0.0) / b2["SQ_LDS_IDX_ACTIVE"], 4)
+        if k in Fz:
+            rec["hbm_bytes_per_launch"] = Fz[k].get("FETCH_SIZE", 0.0) * 2048 + Wz.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
+        out["kernels"][k] = rec
+        print(f"{m:6s} {rec['avg_us']:9.2f} us x{rec['calls']:4d} {rec.get('mfma_tflops', 0):7.1f} TF busy {rec.get('mfma_busy_frac', 0):.3f} lds-conf {rec.get('lds_conflict_frac', 0):.3f}  {k[:70]}")
+    json.dump(out, open(f"profiles/{tag}_{m}_mfma.json", "w"), indent=1)
+
+for f in glob.glob(f"{src}/stamps_*.json"):
+    base = os.path.basename(f).replace("stamps_", "")
+    open(f"profiles/{tag}_stage_stamps_{base}", "w").write(open(f).read())
 for r in rows[:14]:
     print(clean(r["Name"])[:70].ljust(70), r["Calls"].rjust(7), "%9.2f us" % (float(r["AverageNs"]) / 1e3), r["Percentage"])

@@ -33,13 +33,6 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
   // two weight planes are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
   // flight) like the K = 4096 instances their four, so that the slice a wave holds fits the register file without spills
   constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
-  if constexpr (WT == 2) {   // debug flag bit 14 (A/B): two-plane weights without batching — every request of a wave issued up front
-    if (va_debug_flags & 16384u) {
-      if (!norm && tiles % 8 == 0 && K == 4096 && epilogue == E3_RESID) return launch3h<2, 8, E3_RESID, 1>(a, tiles, s);
-      if (K == 1536 && epilogue == E3_STORE && norm) return launch3<2, 6, 8, 2, E3_STORE, true, 1>(a, tiles, s);
-      if (K == 1536 && epilogue == E3_SWIGLU && norm) return launch3<2, 6, 8, 2, E3_SWIGLU, true, 1>(a, tiles, s);
-    }
-  }
   if constexpr (WT != 1) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
     if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
       if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1>(a, tiles, s);
