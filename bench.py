@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--checkpoint", choices=["raw", "bf16repr"], default="raw",
                     help="synthetic checkpoint of the headline run: raw = un-rounded fp32 weights (what a real V-AURA checkpoint looks "
                          "like to the storage decision), bf16repr = every streamed weight bf16-representable (one fp16 plane is lossless)")
-    ap.add_argument("--codec", choices=["f32", "f16pair", "f16pair_w8", "mx8"], default=None,
+    ap.add_argument("--codec", choices=["f32", "f16pair", "f16", "f16pair_w8", "mx8"], default=None,
                     help="codec conv precision (default: f16pair; f16pair_w8 with --weights fp8).  mx8 = block-scaled fp8 on "
                          "the fp8 MFMA, BASELINE configs[4] together with --weights fp8 --batch 16")
     ap.add_argument("--no-graph", action="store_true")
@@ -290,6 +290,7 @@ def main():
                                + f" (requested: {args.weights}; checkpoint: {args.checkpoint})"
                                + "; activations as (hi, lo) fp16 planes between kernels, fp32 accumulate / residual stream / KV cache; codec: "
                                + {"f32": "fp32 MFMA", "f16pair": "activations and weights on (hi, lo) fp16 pairs, fp32 accumulate",
+                                  "f16": "plain fp16 operands, fp32 accumulate (the reference's own codec precision class)",
                                   "f16pair_w8": "fp8 weights in one fp16 plane, activations on (hi, lo) fp16 pairs",
                                   "mx8": "fp8 weights and block-scaled fp8 activations on the fp8 MFMA (NOT inside the 1e-4 waveform "
                                          "budget: BASELINE configs[4] option)"}[args.codec]),

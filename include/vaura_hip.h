@@ -289,7 +289,10 @@ typedef struct vaura_codec {
                                           every other conv: per phase, input channels in super-chunks of 128 (the last may
                                           hold nch = 1..3 blocks of 32); inside a super-chunk the k-blocks kb = tap*nch + ch
                                           are taken four per step, so step s holds, for every output channel, 4 x 32 bytes
-                                          (kb = 4s .. 4s+3; zeros past the last k-block): [phase][step][Cout][4][32].     */
+                                          (kb = 4s .. 4s+3; zeros past the last k-block): [phase][step][Cout][4][32].
+                                       4: "f16": buffers and weights as in 1, but ONE matrix instruction per product — hi(w) x hi(x),
+                                          plain fp16 operands with fp32 accumulate (the arithmetic class the reference runs DAC in,
+                                          models/vaura_model.py:92); the lo planes are written but not read                      */
   int32_t _pad1;
 } vaura_codec;
 

@@ -57,31 +57,40 @@ def from_codes(sd: Dict[str, torch.Tensor], codes: torch.Tensor) -> torch.Tensor
 
 
 def decode_latent(sd: Dict[str, torch.Tensor], z: torch.Tensor, rates: Sequence[int] = (8, 8, 4, 2),
-                  dilations: Sequence[int] = (1, 3, 9), act_quant=None) -> torch.Tensor:
-    """z (B, latent, T) -> wav (B, 1, T * prod(rates)).  ``act_quant`` (not in the reference; models the build's fp8 codec
-    option): a function applied to every Snake output, channels last, before the next convolution reads it."""
-    act = snake if act_quant is None else (lambda x, alpha: act_quant(snake(x, alpha).transpose(1, 2)).transpose(1, 2))
-    x = F.conv1d(z, fold(sd, "decoder.model.0."), sd["decoder.model.0.bias"].float(), padding=3)
+                  dilations: Sequence[int] = (1, 3, 9), act_quant=None, weight_quant=None, quant_input: bool = False,
+                  quant_last: bool = True) -> torch.Tensor:
+    """z (B, latent, T) -> wav (B, 1, T * prod(rates)).  The hooks are not in the reference; they model the build's reduced
+    codec precisions: ``act_quant`` is applied to every Snake output (channels last) before the next convolution reads it
+    (``quant_last=False``: not to the last one, whose consumer — the C -> 1 convolution — the kernels keep in fp32), to the
+    quantizer's latent too when ``quant_input``; ``weight_quant`` to every folded convolution weight but the last."""
+    aq = (lambda x: x) if act_quant is None else (lambda x: act_quant(x.transpose(1, 2)).transpose(1, 2))
+    wq = (lambda w: w) if weight_quant is None else weight_quant
+    act = lambda x, alpha: aq(snake(x, alpha))
+    if quant_input:
+        z = aq(z)
+    x = F.conv1d(z, wq(fold(sd, "decoder.model.0.")), sd["decoder.model.0.bias"].float(), padding=3)
     for b, r in enumerate(rates):
         p = f"decoder.model.{b + 1}.block."
         x = act(x, sd[p + "0.alpha"].float())
-        x = F.conv_transpose1d(x, fold(sd, p + "1."), sd[p + "1.bias"].float(), stride=r, padding=math.ceil(r / 2))
+        x = F.conv_transpose1d(x, wq(fold(sd, p + "1.")), sd[p + "1.bias"].float(), stride=r, padding=math.ceil(r / 2))
         for u, d in enumerate(dilations):
             q = p + f"{u + 2}.block."
             y = act(x, sd[q + "0.alpha"].float())
-            y = F.conv1d(y, fold(sd, q + "1."), sd[q + "1.bias"].float(), dilation=d, padding=3 * d)
+            y = F.conv1d(y, wq(fold(sd, q + "1.")), sd[q + "1.bias"].float(), dilation=d, padding=3 * d)
             y = act(y, sd[q + "2.alpha"].float())
-            y = F.conv1d(y, fold(sd, q + "3."), sd[q + "3.bias"].float())
+            y = F.conv1d(y, wq(fold(sd, q + "3.")), sd[q + "3.bias"].float())
             x = x + y
     n = len(rates) + 1
-    x = act(x, sd[f"decoder.model.{n}.alpha"].float())
+    x = snake(x, sd[f"decoder.model.{n}.alpha"].float())
+    if quant_last:
+        x = aq(x)
     x = F.conv1d(x, fold(sd, f"decoder.model.{n + 1}."), sd[f"decoder.model.{n + 1}.bias"].float(), padding=3)
     return torch.tanh(x)
 
 
 @torch.no_grad()
-def decode(sd: Dict[str, torch.Tensor], codes: torch.Tensor, rates: Sequence[int] = (8, 8, 4, 2), act_quant=None) -> torch.Tensor:
-    return decode_latent(sd, from_codes(sd, codes), rates, act_quant=act_quant)
+def decode(sd: Dict[str, torch.Tensor], codes: torch.Tensor, rates: Sequence[int] = (8, 8, 4, 2), act_quant=None, **kw) -> torch.Tensor:
+    return decode_latent(sd, from_codes(sd, codes), rates, act_quant=act_quant, **kw)
 
 
 def preprocess(wav: torch.Tensor, hop: int) -> torch.Tensor:

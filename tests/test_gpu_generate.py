@@ -283,6 +283,35 @@ def test_dac_decode_matches_oracle(precision, tol):
     assert float(ref.abs().max()) > 0.05  # the fixture is not a silent waveform
 
 
+def test_dac_decode_plain_fp16_against_its_emulation_and_the_fp32_oracle():
+    """Codec precision "f16": plain fp16 operands with fp32 accumulate, ONE matrix instruction per product — the arithmetic
+    class the reference itself runs DAC in (models/vaura_model.py:92 `.half()`).  The kernel's arithmetic is pinned per layer
+    (test_gpu_ops.py::test_codec_convolution_per_precision[f16]: 1e-6 of fp64 on the fp16-rounded operands, every geometry).
+    End to end the model is the oracle with every convolution's weights and inputs rounded to fp16 (the last, C -> 1, conv stays
+    fp32 like in the kernels) — but with synthetic Gaussian weights that emulation is itself discontinuous: a relative
+    perturbation of 1e-7 of its pre-rounding activations (what a different fp32 summation order does) moves ITS output by 1.1e-4
+    RMS, because an fp16 rounding flip is a 2^-11 step the random network does not damp (measured on the CPU; the same effect as
+    for mx8 below).  So the end-to-end bar is: no farther from the emulation than the emulation is from the fp32 oracle; both
+    distances are printed — the second is what the reference's own fp16 codec costs.  The default precision stays "f16pair"."""
+    from oracle import dac_oracle
+    ccfg = synth.FULL_CODEC
+    sd = synth.codec_state_dict(ccfg, seed=1)
+    codes = torch.randint(0, 1024, (2, 9, 12), generator=torch.Generator().manual_seed(3))
+    h = lambda t: t.half().float()
+    emu = dac_oracle.decode(sd, codes, ccfg.decoder_rates, act_quant=h, weight_quant=h, quant_input=True, quant_last=False)
+    ref = dac_oracle.decode(sd, codes, ccfg.decoder_rates)
+    got = CodecEngine(ccfg, sd, DEV, precision="f16").decode(codes.to(DEV)).cpu()
+    sig = float((ref ** 2).mean().sqrt())
+    rms_emu = float(((got - emu) ** 2).mean().sqrt())
+    rms_ref = float(((got - ref) ** 2).mean().sqrt())
+    rms_model = float(((emu - ref) ** 2).mean().sqrt())
+    print(f"codec f16: rms vs its fp16-operand emulation {rms_emu:.3e}; vs the fp32 oracle {rms_ref:.3e} (emulation vs fp32 "
+          f"{rms_model:.3e}; signal rms {sig:.3e})")
+    assert torch.isfinite(got).all()
+    assert rms_emu <= rms_model, (rms_emu, rms_model)
+    assert rms_ref <= 1.5 * rms_model and rms_ref <= 5e-3 * sig, (rms_ref, rms_model, sig)
+
+
 def test_two_row_blocks_with_cfg_against_live_oracle():
     """B=10 with CFG -> 20 decoder rows = two 16-row blocks (the second one ragged): every GEMV loops
     row blocks, attention / sampler grids grow.  Token-exact vs the oracle."""

@@ -435,7 +435,7 @@ _CONV_SHAPES = [  # (Cin, Cout, k, dilation, stride)  — the decoder's layer ge
 
 
 @pytest.mark.parametrize("shape", _CONV_SHAPES, ids=lambda s: "x".join(map(str, s)))
-@pytest.mark.parametrize("precision", ["f32", "f16pair", "f16pair_w8", "mx8"])
+@pytest.mark.parametrize("precision", ["f32", "f16pair", "f16", "f16pair_w8", "mx8"])
 def test_codec_convolution_per_precision(shape, precision):
     """vaura_dac_conv against torch fp64 on the SAME numbers the kernel multiplies: for "mx8" the input is rounded by
     quant.mx8_effective_activation (what the producing kernel stores) and the weight by quant.fp8_effective_weight (what the
@@ -466,13 +466,15 @@ def test_codec_convolution_per_precision(shape, precision):
         w = unflat(quant.fp8_effective_weight(flat(w))).contiguous()
     if precision == "mx8":
         xe = quant.mx8_effective_activation(x)
+    if precision == "f16":                       # plain fp16 operands: the hi planes of the input and of the weight
+        xe, w = x.half().float(), w.half().float()
     xd, wd = xe.double().transpose(1, 2), w.double()
     if stride > 1:
         ref = F.conv_transpose1d(xd, wd, bias.double(), stride=stride, padding=(stride + 1) // 2)
     else:
         ref = F.conv1d(xd, wd, bias.double(), dilation=dil, padding=(k - 1) // 2 * dil)
     ref = ref.transpose(1, 2)
-    got = CodecConvOp(w, bias, dil, stride, precision, DEV)(x.to(DEV)).cpu().double()
+    got = CodecConvOp(w, bias, dil, stride, precision, DEV)(x.to(DEV)).cpu().double()      # "f16": the op itself drops the lo planes of x
     assert got.shape == ref.shape
     err = float((got - ref).abs().max() / ref.abs().max())
     print(f"codec conv {shape} {precision}: max err / max |ref| = {err:.2e}")

@@ -365,3 +365,17 @@ def test_load_from_checkpoint_like_the_reference_driver(tmp_path):
         VAURAModel.load_from_checkpoint(bad, hparams_file=hp)
     with pytest.raises(L.VauraHipError, match="HIP device only|no CPU"):
         m.generate(frames=torch.zeros(1, 4, 8, 768), max_new_tokens=4, prompt_is_encoded=True)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
+def test_reference_itself_cannot_run_the_trajectory_or_joint_backbone():
+    """Row f2 scope: ``VisionTransformer.forward_features`` passes ``tok_mask=`` to every block (video_model_builder.py:266-268);
+    only ``DividedSpaceTimeBlock.forward`` accepts it — the trajectory / joint ``Block.forward`` (vit_helper.py:379-390) raises
+    TypeError.  So the divided backbone is the only feature extractor the reference can execute, and the only one this build
+    provides (tests/golden/check_reference_backbones.py prints the three outcomes).  Run in a child process: the harness chdirs."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "check_reference_backbones.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "finding holds" in r.stdout

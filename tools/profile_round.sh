@@ -13,6 +13,7 @@ TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+exec > $OUT/round.log 2>&1
 LIB=$ROOT/vaura_amd/csrc/libvaura_hip.so
 DRV=$ROOT/tools/pmc_driver
 MDRV=$ROOT/tools/mfma_driver
@@ -51,4 +52,6 @@ if [ -f $S ]; then
     tail -n 8 $OUT/stamps_$W.log
   done
 fi
-find $OUT -name "*.csv" | wc -l
+# gpurun merges at most 64 MiB back: keep the stats and counter tables, drop the per-dispatch traces and databases
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
+du -sh $OUT; find $OUT -name "*.csv" | wc -l

@@ -38,6 +38,17 @@ with torch.cuda.stream(s):
     e8[1].record()
 torch.cuda.synchronize()
 print(f"B={B}: decode with fp8-quantised conv weights (single fp16 weight plane) {e8[0].elapsed_time(e8[1]) / 5:.2f} ms")
+h16 = CodecEngine(cfg, sd, dev, precision="f16")
+with torch.cuda.stream(s):
+    wav16 = h16.decode(codes)
+    e16 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e16[0].record()
+    for _ in range(5):
+        h16.decode(codes)
+    e16[1].record()
+torch.cuda.synchronize()
+print(f"B={B}: decode with plain fp16 operands (\"f16\": one MFMA per product) {e16[0].elapsed_time(e16[1]) / 5:.2f} ms; rms vs the f16-pair decode "
+      f"{float(((wav16 - wav).float() ** 2).mean().sqrt()):.3e}")
 mx = CodecEngine(cfg, sd, dev, precision="mx8")
 with torch.cuda.stream(s):
     wav_mx = mx.decode(codes)

@@ -62,7 +62,8 @@ class DacModelWrapper(nn.Module):
     def __init__(self, model_sr: int = 24000, ckpt_path: tp.Optional[str] = None, synthetic: bool = False,
                  synthetic_seed: int = 0, precision: str = "f16pair", weights_from_state_dict: bool = False) -> None:
         """``model_sr`` / ``ckpt_path`` as in the reference (dac/model.py:12-25).  Extras understood by this plugin only:
-        ``precision`` of the decode convolutions — "f16pair" (default), "f32" (exact fp32 MFMA), "f16pair_w8" (fp8 conv
+        ``precision`` of the decode convolutions — "f16pair" (default), "f32" (exact fp32 MFMA), "f16" (plain fp16 operands with
+        fp32 accumulate: what the reference's own `.half()` codec computes in, one matrix instruction per product), "f16pair_w8" (fp8 conv
         weights) or "mx8" (fp8 weights and block-scaled fp8 activations on the fp8 MFMA; both BASELINE configs[4]); ``synthetic=True`` (or env VAURA_SYNTHETIC_CODEC=1) asks for seeded synthetic weights
         (``synthetic_seed``) — benchmarks and tests on machines without checkpoints.  Without it a checkpoint is REQUIRED:
         the reference downloads one when ``ckpt_path`` is absent (dac/model.py:20-23) and never runs on random weights; this

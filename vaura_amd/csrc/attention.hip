@@ -95,9 +95,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
       for (int i = 0; i < QPL; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kf[u][i][c], d);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
+      d += va_dpp<VA_DPP_XOR1>(d);
+      d += va_dpp<VA_DPP_XOR2>(d);
+      d += va_dpp<VA_DPP_HALF_MIRROR>(d);
       const int p = p0 + u * 32 + prow;
       if (sub == 0 && p < ncache) sc[p] = d * scale;
     }
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float v = av[i][c];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      v += va_dpp<VA_DPP_ROR8>(v);
+      v += va_xor16(v);
+      v += va_xor32(v);
       av[i][c] = v;
     }
   const int wv = tid >> 6, lane = tid & 63;
@@ -265,9 +265,9 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
     for (int i = 0; i < QPL; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kv[i][c], d);
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
+    d += va_dpp<VA_DPP_XOR1>(d);
+    d += va_dpp<VA_DPP_XOR2>(d);
+    d += va_dpp<VA_DPP_HALF_MIRROR>(d);
     return d;
   };
   f32x4 knew[QPL];
@@ -301,9 +301,9 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float v = av[i][c];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      v += va_dpp<VA_DPP_ROR8>(v);
+      v += va_xor16(v);
+      v += va_xor32(v);
       av[i][c] = v;
     }
   const int wv = tid >> 6, lane = tid & 63;
@@ -404,9 +404,9 @@ struct AttentionBlock {
       for (int i = 0; i < QPL; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kf[u][i][c], d);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
+      d += va_dpp<VA_DPP_XOR1>(d);
+      d += va_dpp<VA_DPP_XOR2>(d);
+      d += va_dpp<VA_DPP_HALF_MIRROR>(d);
       sc[u] = (b0 + u * 64 + prow < hi) ? d * scale : -INFINITY;
       m = fmaxf(m, sc[u]);
     }
@@ -483,9 +483,9 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
 #pragma unroll
       for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kn[c], d);
     }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
+    d += va_dpp<VA_DPP_XOR1>(d);
+    d += va_dpp<VA_DPP_XOR2>(d);
+    d += va_dpp<VA_DPP_HALF_MIRROR>(d);
     snew = d * scale;
     m_run = snew;
   }
@@ -506,9 +506,9 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       float v = av[i][c];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      v += va_dpp<VA_DPP_ROR8>(v);
+      v += va_xor16(v);
+      v += va_xor32(v);
       av[i][c] = v;
     }
   const int wv = tid >> 6, lane = tid & 63;
@@ -697,15 +697,15 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
           sc[r] = (key0 + 4 * g + r <= qpos) ? x * scale : -INFINITY;
           tmax = fmaxf(tmax, sc[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, va_xor16(tmax));
+        tmax = fmaxf(tmax, va_xor32(tmax));
         const float mn = fmaxf(m, tmax);                 // finite from the first tile on: key 0 is visible to every query
         const float f = expf(m - mn);
         float p[4], rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { p[r] = expf(sc[r] - mn); rs += p[r]; }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs += va_xor16(rs);
+        rs += va_xor32(rs);
         l = l * f + rs;
         m = mn;
         // ---- rescale O (lane holds O[q' = 4 g + r][d]) by the factor of query q', then O += P . V

@@ -44,14 +44,49 @@ __host__ __device__ __forceinline__ size_t packed_quad(int row, int cq, int C) {
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
+// ---- cross-lane exchanges on the VALU (DPP modifiers + gfx950's v_permlane{16,32}_swap) instead of ds_bpermute: __shfl_xor
+// compiles to an LDS-crossbar round trip (~60+ cycles of latency each, and the LDS pipe is shared by the 8 waves of a workgroup);
+// the decode attention kernel issued ~50 of them per wave, the GEMV epilogues 4-8 on their post-barrier critical path.
+template <int CTRL>
+__device__ __forceinline__ float va_dpp(float x) {   // x as seen through DPP control CTRL (all rows / banks enabled)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+#define VA_DPP_XOR1 0xB1    /* quad_perm [1,0,3,2] */
+#define VA_DPP_XOR2 0x4E    /* quad_perm [2,3,0,1] */
+#define VA_DPP_HALF_MIRROR 0x141   /* lane i <-> 7 - i of its 8: pairs the two quads (== xor 4 on quad-uniform values) */
+#define VA_DPP_ROR8 0x128   /* rotate a 16-lane row by 8 == xor 8 */
+// the value of lane ^ 16 / lane ^ 32.  v_permlane{16,32}_swap exchanges the odd rows of its first register with the even rows of
+// its second.  Written as inline asm: with the builtin, hipcc 7.2 folds `select(lane bit, r[0], r[1])` of swap(x, x) to r[0] (and
+// may give both operands one physical register) — tools/microbench/lane_exchange_probe.hip is the passing check of THIS form.  The
+// s_nop covers the VALU-write -> permlane-read wait states the compiler would otherwise insert.
+__device__ __forceinline__ float va_xor16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return ((threadIdx.x >> 4) & 1) ? a : b;
+}
+__device__ __forceinline__ float va_xor32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return ((threadIdx.x >> 5) & 1) ? a : b;
+}
+// all-reduce over the 64 lanes, butterfly order 1, 2, 4, 8, 16, 32 (after the xor-1 and xor-2 steps the values are uniform per quad,
+// so the half-mirror pairs exactly what xor 4 would)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += va_dpp<VA_DPP_XOR1>(v);
+  v += va_dpp<VA_DPP_XOR2>(v);
+  v += va_dpp<VA_DPP_HALF_MIRROR>(v);
+  v += va_dpp<VA_DPP_ROR8>(v);
+  v += va_xor16(v);
+  v += va_xor32(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, va_dpp<VA_DPP_XOR1>(v));
+  v = fmaxf(v, va_dpp<VA_DPP_XOR2>(v));
+  v = fmaxf(v, va_dpp<VA_DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, va_dpp<VA_DPP_ROR8>(v));
+  v = fmaxf(v, va_xor16(v));
+  v = fmaxf(v, va_xor32(v));
   return v;
 }
 

@@ -172,8 +172,8 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
         if (a.out) va_st16(reinterpret_cast<f32x4*>(a.out) + idx, o);
         if (a.ss_out) {
           float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
-          s += __shfl_xor(s, 16, 64);
-          s += __shfl_xor(s, 32, 64);
+          s += va_xor16(s);
+          s += va_xor32(s);
           if (q == 0) va_st4(a.ss_out + ((size_t)rb * (a.N / 16) + tile) * 16 + m, s);
         }
         if (a.outp) {
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         float ssp = 0.f;
 #pragma unroll
         for (int j = 0; j < NSS; ++j) ssp += ssv[j];      // tile order q, q + 4, ... (slots past n_ss_in hold 0)
-        ssp += __shfl_xor(ssp, 16, 64);
-        ssp += __shfl_xor(ssp, 32, 64);
+        ssp += va_xor16(ssp);
+        ssp += va_xor32(ssp);
         rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
       }
     } else if constexpr (NORM) {
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         float ssp = 0.f;
 #pragma unroll
         for (int j = 0; j < NSS; ++j) ssp += pv[j];
-        ssp += __shfl_xor(ssp, 16, 64);
-        ssp += __shfl_xor(ssp, 32, 64);
+        ssp += va_xor16(ssp);
+        ssp += va_xor32(ssp);
         rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
       }
       f32x4 v[ET];
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float x = v[r];
-        o[r] = x + __shfl_xor(x, 40, 64);
+        o[r] = x + va_dpp<VA_DPP_ROR8>(va_xor32(x));      // lane ^ 40
       }
       red[wid][nh][lane] = o;
     }

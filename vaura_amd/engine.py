@@ -459,7 +459,8 @@ class CodecEngine:
 
     def __init__(self, cfg: CodecCfg, sd: Dict[str, torch.Tensor], device="cuda:0", precision: str = "f16pair"):
         """precision: "f16pair" (default; activations/weights as (hi, lo) fp16 pairs on the fp16 MFMA, error
-        ~1e-6 RMS), "f32" (exact fp32 MFMA), or "f16pair_w8" (BASELINE configs[4]: conv weights quantised to fp8 e4m3 with
+        ~1e-6 RMS), "f32" (exact fp32 MFMA), "f16" (plain fp16 operands, fp32 accumulate — one matrix instruction per product:
+        the arithmetic class the reference runs DAC in, vaura_model.py:92; error ~1e-4 of the signal), or "f16pair_w8" (BASELINE configs[4]: conv weights quantised to fp8 e4m3 with
         a power-of-two scale per output channel — a different model, ``quant.fp8_effective_codec_state_dict`` says which;
         such weights are exact in one fp16 plane, so a product costs two MFMAs instead of three), or "mx8" (configs[4] on the
         fp8 matrix instruction: those fp8 weights AND e4m3 activations with one power-of-two scale per 32 channels of a row,
@@ -467,8 +468,8 @@ class CodecEngine:
         _require_cuda(device)
         self.cfg, self.dev, self.lib = cfg, torch.device(device), L.lib()
         self._keep = []
-        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2, "mx8": 3}[precision]
-        if self.pairs >= 2:
+        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2, "mx8": 3, "f16": 4}[precision]
+        if self.pairs in (2, 3):
             from .quant import fp8_effective_codec_state_dict
             sd = fp8_effective_codec_state_dict(sd)
         c = L.Codec()
@@ -573,7 +574,7 @@ class CodecConvOp:
                  device="cuda:0", mx8_weights: bool = True):
         _require_cuda(device)
         self.dev, self.lib, self._keep = torch.device(device), L.lib(), []
-        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2, "mx8": 3}[precision]
+        self.pairs = {"f32": 0, "f16pair": 1, "f16pair_w8": 2, "mx8": 3, "f16": 4}[precision]
         self.cv = L.Conv()
         CodecEngine._pack_conv(self, self.cv, weight.float(), bias.float(), dilation, stride, mx8_weights)
         self.stride = stride
