@@ -74,8 +74,8 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
         # the host's best: torch's default (one thread per logical CPU) oversubscribes a 16-row GEMV; sweep and keep the fastest
         default_threads = torch.get_num_threads()
         sweep = {}
-        for nt in sorted({8, 16, 32, 64, max(1, (os.cpu_count() or 1) // 2), os.cpu_count() or 1, default_threads}):
-            if nt > (os.cpu_count() or 1):
+        for nt in sorted({8, 16, 32, 64, max(1, default_threads // 2), default_threads}):
+            if nt > default_threads:      # torch's default = the physical cores; SMT siblings only oversubscribe (256 threads: 45 s per step)
                 continue
             torch.set_num_threads(nt)
             cd.pos = 1

@@ -95,6 +95,9 @@ typedef struct vaura_sampling {
   float   cfg_scale;      /* > 1 -> rows [B,2B) are the null-condition branch (vaura_model.py:786-813) */
   uint64_t seed;          /* Philox key when noise == NULL                          */
   uint64_t clip_base;     /* global index of clip 0 (keeps draws invariant to batch sharding) */
+  int32_t input_is_probs; /* 1: the input rows already are probabilities (utils/utils.py sample_top_k / sample_top_p / multinomial
+                             take probs): no temperature, no softmax, no CFG mix.  0 in the decode loop                       */
+  int32_t _pad;
 } vaura_sampling;
 
 /* ---- everything one decode step touches.  All buffers are owned by the caller (torch tensors). */

@@ -313,6 +313,32 @@ def test_sampler_matches_reference_goldens(golden, name, kw, temp):
         assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("temp", [1.0, 0.7])
+@pytest.mark.parametrize("name,kw", SAMPLE_CASES)
+def test_reference_named_sampling_functions(golden, name, kw, temp):
+    """``vaura_amd.utils.sample_top_k / sample_top_p / multinomial`` — the reference's names and argument (PROBABILITIES, as
+    utils/utils.py:139-196 takes them) — on the probabilities the reference itself fed: softmax(logits / temp) computed the way
+    vaura_model.py:816-817 does.  Same goldens as above."""
+    from vaura_amd import utils as vu
+    g = golden("sampling.npz")
+    probs = torch.softmax(torch.from_numpy(g["logits"]) / temp, dim=-1).to(DEV)
+    noise = synth.exp_noise(1, 27, 1024, int(g["noise_seed"]))[0].to(DEV)
+    if kw["top_p"] > 0:
+        tok = vu.sample_top_p(probs, kw["top_p"], noise=noise)
+    elif kw["top_k"] > 0:
+        tok = vu.sample_top_k(probs, kw["top_k"], noise=noise)
+    else:
+        tok = vu.multinomial(probs, num_samples=1, noise=noise)
+    got, ref = tok.cpu().numpy(), g[f"{name}_t{temp}_tok"]
+    assert got.shape == ref.shape == (3, 9, 1)
+    keep = np.ones((3, 9), dtype=bool)
+    if kw["top_p"] > 0:
+        keep[0, 0] = keep[1, 3] = False          # exact ties: the reference's unstable sort leaves their ranks unspecified
+    assert np.array_equal(got[keep], ref[keep])
+    with pytest.raises(NotImplementedError):
+        vu.multinomial(probs, num_samples=2)
+
+
 def test_sampler_greedy_cfg_and_ties():
     from oracle import sampling_oracle as so
     g = torch.Generator().manual_seed(5)

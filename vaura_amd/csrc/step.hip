@@ -117,7 +117,7 @@ struct SampleArgs {
   int32_t* tokens_out;   // (B, K) or null
   int32_t* seq;          // (B, K, S) or null
   int B, K, V, T, S;
-  int use_sampling, top_k;
+  int use_sampling, top_k, probs_in;
   float temp, top_p, cfg_scale;
   uint64_t seed, clip_base;
   long long step_host;
@@ -199,16 +199,21 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     block_argmax(bv, bi, sv, si, rv, ri);
     token = ri;
   } else {
-    // softmax(logits / temp)
+    // softmax(logits / temp) — or the input rows themselves when they already are probabilities (utils/utils.py:139-196)
     float p[4];
+    if (a.probs_in) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = x[j] / a.temp;
-    const float mx = block_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), sv);
+      for (int j = 0; j < 4; ++j) p[j] = x[j];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = expf(x[j] - mx);
-    const float den = block_sum((p[0] + p[1]) + (p[2] + p[3]), sv);
+      for (int j = 0; j < 4; ++j) x[j] = x[j] / a.temp;
+      const float mx = block_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), sv);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) p[j] = p[j] / den;
+      for (int j = 0; j < 4; ++j) p[j] = expf(x[j] - mx);
+      const float den = block_sum((p[0] + p[1]) + (p[2] + p[3]), sv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p[j] = p[j] / den;
+    }
 
     // Exp(1) draws for this (clip, codebook, step)
     float q[4];
@@ -358,7 +363,8 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
   a.logits = logits; a.noise = noise; a.state = state; a.state_rw = state_rw; a.tokens_out = tokens_out; a.seq = seq;
   a.B = B; a.K = K; a.V = vocab; a.T = T; a.S = S;
   a.use_sampling = sp->use_sampling; a.top_k = sp->top_k; a.temp = sp->temp; a.top_p = sp->top_p;
-  a.cfg_scale = sp->cfg_scale; a.seed = sp->seed; a.clip_base = sp->clip_base; a.step_host = step_host;
+  a.cfg_scale = sp->input_is_probs ? 1.0f : sp->cfg_scale; a.seed = sp->seed; a.clip_base = sp->clip_base; a.step_host = step_host;
+  a.probs_in = sp->input_is_probs;
   VA_LAUNCH(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a.logits, a.state, a);
   return 0;
 }

@@ -83,12 +83,14 @@ def attention_step_split(qkv_p: torch.Tensor, rope: torch.Tensor, kcache: torch.
 
 def sample(logits: torch.Tensor, batch: int, *, use_sampling: bool, temp: float = 1.0, top_k: int = 0,
            top_p: float = 0.0, cfg_scale: float = 1.0, noise: Optional[torch.Tensor] = None, seed: int = 0,
-           clip_base: int = 0, step: int = 0) -> torch.Tensor:
-    """logits (rows, K, V) with rows = batch (or 2*batch when cfg_scale > 1) -> tokens (batch, K, 1) int64."""
+           clip_base: int = 0, step: int = 0, input_is_probs: bool = False) -> torch.Tensor:
+    """logits (rows, K, V) with rows = batch (or 2*batch when cfg_scale > 1) -> tokens (batch, K, 1) int64.
+    ``input_is_probs``: the rows already are probabilities (no temperature / softmax / CFG mix)."""
     _cuda(logits, noise)
     rows, K, V = logits.shape
     lg = logits.float().contiguous()
-    sp = L.Sampling(int(use_sampling), float(temp), int(top_k), float(top_p), float(cfg_scale), int(seed), int(clip_base))
+    sp = L.Sampling(int(use_sampling), float(temp), int(top_k), float(top_p), float(cfg_scale), int(seed), int(clip_base),
+                    int(bool(input_is_probs)), 0)
     out = torch.zeros(batch, K, dtype=torch.int32, device=logits.device)
     nz = None if noise is None else noise.float().contiguous()
     L.check(L.lib().vaura_sample(L.ptr(lg), batch, K, V, C.byref(sp), L.ptr(nz), step, L.ptr(out), L.current_stream()),

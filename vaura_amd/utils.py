@@ -48,3 +48,37 @@ def sample_from_logits(logits: torch.Tensor, *, use_sampling: bool, temp: float 
     if use_sampling and temp > 0.0:
         nz = _draw_noise((B, K, V), logits.device, noise).reshape(1, B * K, V)
     return ops.sample(logits, B, use_sampling=use_sampling, temp=temp, top_k=top_k, top_p=top_p, cfg_scale=cfg_scale, noise=nz)
+
+
+# ---- the reference's own names (utils/utils.py:139-196): probabilities in, token ids out, on the HIP device
+def _sample_probs(probs: torch.Tensor, top_k: int, top_p: float, noise: Optional[torch.Tensor]) -> torch.Tensor:
+    lead, V = tuple(probs.shape[:-1]), probs.shape[-1]
+    rows = 1
+    for d in lead:
+        rows *= d
+    nz = _draw_noise((rows, V), probs.device, noise).reshape(1, rows, V)
+    tok = ops.sample(probs.reshape(rows, 1, V), rows, use_sampling=True, temp=1.0, top_k=top_k, top_p=top_p, noise=nz,
+                     input_is_probs=True)
+    return tok.reshape(*lead, 1)
+
+
+def multinomial(input: torch.Tensor, num_samples: int = 1, replacement: bool = False, *, generator=None,
+                noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``utils.multinomial`` (utils/utils.py:139-160) for ``num_samples=1``: one draw per row of the last dimension,
+    ``argmax(p / Exp(1))`` like ``torch.multinomial``.  ``noise`` (rows, V): recorded Exp(1) draws; else they are taken from
+    torch's global CPU generator in the reference's order (a ``generator`` object cannot be forwarded to the device sampler)."""
+    if num_samples != 1 or generator is not None:
+        raise NotImplementedError("the device sampler draws one token per row from torch's global CPU stream (or recorded noise)")
+    return _sample_probs(input, 0, 0.0, noise)
+
+
+def sample_top_k(probs: torch.Tensor, k: int, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``utils.sample_top_k`` (utils/utils.py:163-178): keep ``probs >= k-th largest`` (ties kept), renormalise, draw.
+    (The reference also rewrites ``probs`` in place; this one leaves its argument alone.)"""
+    return _sample_probs(probs, int(k), 0.0, noise)
+
+
+def sample_top_p(probs: torch.Tensor, p: float, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``utils.sample_top_p`` (utils/utils.py:181-196): sort descending, keep while ``cumsum - p_i <= p``, renormalise, draw in
+    sorted space, map back."""
+    return _sample_probs(probs, 0, float(p), noise)
