@@ -58,24 +58,61 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
 
 template <int EPI, bool NORM>
 static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
-  const dim3 grid((unsigned)(tiles / (G3M_NW * G3M_T)), (unsigned)((a.R + G3M_RB - 1) / G3M_RB));
-  // 128-row workgroups once there are enough rows to keep the chip busy with them (a prompt of >= 64 positions x 16 rows)
-  const bool big = a.R >= 64 && !(va_debug_flags & 32u);
-  const dim3 grid8(grid.x, (unsigned)((a.R + 7) / 8));
+  const int gx = (int)(tiles / (G3M_NW * G3M_T)), gy4 = (a.R + G3M_RB - 1) / G3M_RB, gy8 = (a.R + 7) / 8;
+  // 128-row workgroups once there are enough of them to fill the chip twice over (debug flag bit 14: at >= 64 row blocks whatever the
+  // count, round 2's rule — wo and w2 of a 166-position prompt then run 126 workgroups on 256 CUs)
+  const bool big = !(va_debug_flags & 32u) && ((va_debug_flags & 0x4000u) ? a.R >= 64 : gx * gy8 >= 320);
+  const int remap = (va_debug_flags & 0x8000u) ? 0 : 1;               // bit 15: blocks in launch order
+  const bool pf2 = !(va_debug_flags & 0x10000u) && (K / 32) % 2 == 0;     // bit 16: one weight k-group in flight
+  const int gy = big ? gy8 : gy4;
+  const dim3 grid((unsigned)(gx * gy)), block(G3M_NW * 64);
   if (a.wq == 1) {
-    if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 1, 8>), grid8, dim3(G3M_NW * 64), 0, s, a, (int)K);
-    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 1>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+    if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 1, 8>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 1>), grid, block, 0, s, a, (int)K, gx, gy, remap);
   } else if (a.wq == 2) {
-    VA_LAUNCH((gemm3_kernel<EPI, NORM, 2>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+    if (big && pf2) VA_LAUNCH((gemm3_kernel<EPI, NORM, 2, 8, 2>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 2, 8, 1>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else if (pf2) VA_LAUNCH((gemm3_kernel<EPI, NORM, 2, G3M_RB, 2>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 2>), grid, block, 0, s, a, (int)K, gx, gy, remap);
   } else {
-    if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 0, 8>), grid8, dim3(G3M_NW * 64), 0, s, a, (int)K);
-    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 0>), grid, dim3(G3M_NW * 64), 0, s, a, (int)K);
+    if (big && pf2) VA_LAUNCH((gemm3_kernel<EPI, NORM, 0, 8, 2>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 0, 8, 1>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else if (pf2) VA_LAUNCH((gemm3_kernel<EPI, NORM, 0, G3M_RB, 2>), grid, block, 0, s, a, (int)K, gx, gy, remap);
+    else VA_LAUNCH((gemm3_kernel<EPI, NORM, 0>), grid, block, 0, s, a, (int)K, gx, gy, remap);
   }
   return 0;
 }
 
+// LDS-DMA pipelined GEMM (gemm4_kernel): fp16-plane weights
+template <int EPI, bool NORM, int WT, int RBW>
+static int launch_gemm4_i(const Gemv3Args& a, int64_t K, int gx, hipStream_t s) {
+  using SH = G4Shape<WT, RBW>;
+  static unsigned long long big = 0;
+  if (va_big_lds_once(reinterpret_cast<const void*>(gemm4_kernel<EPI, NORM, WT, RBW>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  const int gy = (a.R + RBW - 1) / RBW;
+  VA_LAUNCH((gemm4_kernel<EPI, NORM, WT, RBW>), dim3((unsigned)(gx * gy)), dim3(G4_NW * 64), SH::LDS, s, a, (int)K, gx, gy,
+            (va_debug_flags & 0x8000u) ? 0 : 1);
+  return 0;
+}
+template <int EPI, bool NORM>
+static int launch_gemm4(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
+  const int gx = (int)(tiles / G4_CT);
+  // 128-row workgroups when there are enough of them for every CU (wo / w2 of a 166-position prompt: 6 x 21 = 126 -> 64 rows, 252)
+  const bool big = !(va_debug_flags & 32u) && gx * ((a.R + 7) / 8) >= 256;
+  if (a.wq == 2) return big ? launch_gemm4_i<EPI, NORM, 2, 8>(a, K, gx, s) : launch_gemm4_i<EPI, NORM, 2, 4>(a, K, gx, s);
+  return big ? launch_gemm4_i<EPI, NORM, 0, 8>(a, K, gx, s) : launch_gemm4_i<EPI, NORM, 0, 4>(a, K, gx, s);
+}
+
 // many row blocks (a prompt being teacher-forced): GEMM tiling instead of the register-resident GEMV loop
 static int dispatch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
+  if (a.wq != 1 && !(va_debug_flags & 0x20000u)) {     // debug flag bit 17: the register-staged gemm3_kernel for every storage
+    if (epilogue == E3_STORE && norm) return launch_gemm4<E3_STORE, true>(a, tiles, K, s);
+    if (epilogue == E3_STORE && !norm) return launch_gemm4<E3_STORE, false>(a, tiles, K, s);
+    if (epilogue == E3_RESID && !norm) return launch_gemm4<E3_RESID, false>(a, tiles, K, s);
+    if (epilogue == E3_SWIGLU && norm) return launch_gemm4<E3_SWIGLU, true>(a, tiles, K, s);
+    if (epilogue == E3_LOGITS && norm) return launch_gemm4<E3_LOGITS, true>(a, tiles, K, s);
+    return VAURA_ERR_SHAPE;
+  }
   if (epilogue == E3_STORE && norm) return launch_gemm3<E3_STORE, true>(a, tiles, K, s);
   if (epilogue == E3_STORE && !norm) return launch_gemm3<E3_STORE, false>(a, tiles, K, s);
   if (epilogue == E3_RESID && !norm) return launch_gemm3<E3_RESID, false>(a, tiles, K, s);

@@ -25,6 +25,7 @@
 // sums of squares; the consumer adds the partials in a fixed order and applies rsqrt(mean+eps) in its
 // epilogue (W.(g*x*rinv) == rinv * W.(g*x)).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -596,9 +597,15 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 #define G3M_NW 8
 // RBT = row blocks per workgroup: 4 (64 rows) or 8 (128 rows: every weight tile is re-read by half as many workgroups and a
 // k-group carries twice the matrix work per barrier; bf16 / fp8 weights — the fp32-weight accumulators do not fit)
-template <int EPI, bool NORM, int WT = 0, int RBT = G3M_RB>
-__global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) {
+// PF = k-groups of weights in flight ahead of the one being multiplied (register sets).  gx, gy: the tile grid (column tiles of
+// 256, row tiles of 16 RBT rows), launched as gx * gy blocks in one dimension; `remap`: blocks that share an XCD (ids equal
+// mod 8 under round-robin dispatch) take a contiguous range of the tile order, and that order walks panels of 4 row tiles
+// column by column — the 32 workgroups an XCD runs together then cover ~4 row tiles x 8 column tiles, whose current k-slices
+// its L2 serves 8 and 4 times over.
+template <int EPI, bool NORM, int WT = 0, int RBT = G3M_RB, int PF = 1>
+__global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K, int gx, int gy, int remap) {
   constexpr int RB = RBT, T = G3M_T, NW = G3M_NW;
+  static_assert(PF == 1 || (PF == 2 && WT != 1), "two register sets: fp16-plane weights");
   constexpr bool FP8 = WT == 1, F32 = WT == 2;
   constexpr int WH = F32 ? 2 : 1;
   constexpr int NACC = 2;
@@ -606,8 +613,19 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
   __shared__ float rinv_s[RB * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rb0 = blockIdx.y * RB;
-  const int tile0 = ((int)blockIdx.x * NW + wid) * T;
+  int bx, by;
+  if (remap) {
+    const int total = gx * gy, l = blockIdx.x, xcd = l & 7, per = total >> 3, extra = total & 7;
+    const int lp = xcd * per + (xcd < extra ? xcd : extra) + (l >> 3);
+    const int panel = lp / (4 * gx), rem = lp - panel * 4 * gx, pr = min(4, gy - panel * 4);
+    bx = rem / pr;
+    by = panel * 4 + rem - bx * pr;
+  } else {
+    bx = blockIdx.x % gx;
+    by = blockIdx.x / gx;
+  }
+  const int rb0 = by * RB;
+  const int tile0 = (bx * NW + wid) * T;
   const int KG = K / 32;
   constexpr int XL = (RB * VA_NPL * 64 + NW * 64 - 1) / (NW * 64);   // activation quads per thread per k-group
   // buffer loads (see gemv3_kernel): SGPR descriptor + uniform offset, one VGPR offset per load; the activation descriptor
@@ -623,30 +641,39 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
   }
   const int xsoff0 = rb0 * VA_NPL * (K / 8) * 256;
 
-  u32x4 xr[XL], wr[T][WH];
-  auto load_x = [&](int kg) {
+  u32x4 xr[PF][XL], wr[PF][T][WH];
+  auto load_x = [&](int kg, auto slot) {
+    constexpr int S = decltype(slot)::value;
 #pragma unroll
-    for (int i = 0; i < XL; ++i) xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i], xsoff0 + kg * 1024, 0);
+    for (int i = 0; i < XL; ++i) xr[S][i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xvoff[i], xsoff0 + kg * 1024, 0);
   };
-  auto store_x = [&](int buf) {
+  auto store_x = [&](int buf, auto slot) {
+    constexpr int S = decltype(slot)::value;
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int idx = tid + i * NW * 64;
-      if (idx < RB * 64 * VA_NPL) xs[buf][idx] = xr[i];
+      if (idx < RB * 64 * VA_NPL) xs[buf][idx] = xr[S][i];
     }
   };
-  auto load_w = [&](int kg) {   // fp8 tile pairs: one 16-byte load carries k-groups kg and kg + 1
+  auto load_w = [&](int kg, auto slot) {   // fp8 tile pairs: one 16-byte load carries k-groups kg and kg + 1
+    constexpr int S = decltype(slot)::value;
     if (FP8 && (kg & 1)) return;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int hh = 0; hh < WH; ++hh)
-        wr[t][hh] = __builtin_amdgcn_raw_buffer_load_b128(
+        wr[S][t][hh] = __builtin_amdgcn_raw_buffer_load_b128(
             wrs, lane * 16, (int)(((FP8 ? (size_t)(tile0 + t) * (KG / 2) + (kg >> 1) : (size_t)(tile0 + t) * KG + kg) * WH + hh) * 1024), 2);
   };
 
-  load_x(0);
-  load_w(0);
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, PF - 1>;
+  load_x(0, S0{});
+  load_w(0, S0{});
+  if constexpr (PF == 2) {
+    load_x(1, S1{});
+    load_w(1, S1{});
+  }
   if constexpr (NORM) {   // rinv of the 64 rows: ordered sum of the producer's per-tile partial sums of squares
     if (tid < RB * 16) {
       const int rbi = tid >> 4, mm = tid & 15;
@@ -658,7 +685,7 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
       rinv_s[tid] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
     }
   }
-  store_x(0);
+  store_x(0, S0{});
   __syncthreads();
 
   f32x4 acc[RB][T][NACC];
@@ -669,16 +696,22 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
 #pragma unroll
       for (int p = 0; p < NACC; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kg = 0; kg < KG; ++kg) {
+  auto kstep = [&](int kg, auto slot) {
+    constexpr int S = decltype(slot)::value;
     const int buf = kg & 1;
     f16x8 wf[T][F32 ? 2 : 1];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      if constexpr (FP8) wf[t][0] = (kg & 1) ? fp8x8_to_f16(wr[t][0].z, wr[t][0].w) : fp8x8_to_f16(wr[t][0].x, wr[t][0].y);
-      else wf[t][0] = __builtin_bit_cast(f16x8, wr[t][0]);
-      if constexpr (F32) wf[t][1] = __builtin_bit_cast(f16x8, wr[t][WH - 1]);
+      if constexpr (FP8) wf[t][0] = (kg & 1) ? fp8x8_to_f16(wr[S][t][0].z, wr[S][t][0].w) : fp8x8_to_f16(wr[S][t][0].x, wr[S][t][0].y);
+      else wf[t][0] = __builtin_bit_cast(f16x8, wr[S][t][0]);
+      if constexpr (F32) wf[t][1] = __builtin_bit_cast(f16x8, wr[S][t][WH - 1]);
     }
-    if (kg + 1 < KG) { load_x(kg + 1); load_w(kg + 1); }
+    // PF = 2: the planes and weights of k-group kg + 2 go into the register sets k-group kg just left (planes: stored to LDS at
+    // the end of the previous step); a load then has a whole step to land before anything waits for it
+    if (kg + PF < KG) {
+      load_w(kg + PF, slot);
+      load_x(kg + PF, slot);
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       u32x4 x3[VA_NPL];
@@ -687,8 +720,16 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
 #pragma unroll
       for (int t = 0; t < T; ++t) mfma_group<WT>(wf[t], x3, acc[r][t]);
     }
-    if (kg + 1 < KG) store_x(buf ^ 1);
+    if (kg + 1 < KG) store_x(buf ^ 1, std::integral_constant<int, (PF == 2 ? S ^ 1 : 0)>{});
     __syncthreads();
+  };
+  if constexpr (PF == 2) {
+    for (int kg = 0; kg < KG; kg += 2) {     // K / 32 is even for every K the launcher admits
+      kstep(kg, S0{});
+      kstep(kg + 1, S1{});
+    }
+  } else {
+    for (int kg = 0; kg < KG; ++kg) kstep(kg, S0{});
   }
 
 #pragma unroll
@@ -703,5 +744,153 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K) 
       v[t] = sacc * rinv;
     }
     gemv3_epilogue<T, EPI>(a, rb0 + r, tile0, lane, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prefill GEMM, round 3: both operands through an LDS ring filled by LDS-DMA (`global_load_lds_dwordx4`: no register
+// destination, so nothing the compiler has to wait for before a barrier), three stages of one 32-deep k-group each, one raw
+// barrier per k-group with a COUNTED vmcnt in front of it: the pieces of k-group kg + 1 stay in flight across the barrier and
+// every piece has two k-steps to land.  (gemm3_kernel above stages the planes through registers and streams each wave's own
+// weight tiles into registers; hipcc waits vmcnt(0) for both before every barrier, so a load has less than one k-step —
+// the asm shows it — and the MFMA pipe idles ~75 % of the time.)  Both operands are already MFMA fragments in memory (1 KB
+// lane-linear per (row block | column tile, plane, k-group)), so a DMA piece is one fragment, the LDS image needs no swizzle
+// (every ds_read_b128 reads 64 consecutive 16-byte slots) and fragments are shared: a weight fragment by the WM waves along the
+// rows, a plane fragment by the WN waves along the columns.
+//   workgroup = 8 waves = RBW row blocks (16 RBW rows) x 16 column tiles (256 columns); waves WM x WN = (RBW / 4) x (8 / WM);
+//   wave tile = 4 row blocks x T = 16 / WN column tiles; accumulators 4 x T x 2 x 4 registers.
+//   stage = RBW x 2 plane fragments + 16 x WH weight fragments (RBW 8: 32 / 48 KB with one / two weight planes)
+// Same arithmetic and epilogues as gemm3_kernel: the accumulator of an output element sums the same products in the same
+// (k-group) order, so the results are bit-identical to it.
+#define G4_NW 8
+#define G4_CT 16
+#define G4_ST 3
+template <int WT, int RBW>
+struct G4Shape {
+  static constexpr int WH = WT == 2 ? 2 : 1;
+  static constexpr int XP = RBW * VA_NPL, WP = G4_CT * WH;          // DMA pieces (1 KB) per stage
+  static constexpr int PPW = (XP + WP) / G4_NW;                     // per wave
+  static constexpr int STB = (XP + WP) * 1024;                      // bytes per stage
+  static constexpr int LDS = G4_ST * STB + RBW * 16 * 4;            // + rinv of the workgroup's rows
+  static_assert((XP + WP) % G4_NW == 0, "whole pieces per wave");
+};
+
+template <int N>
+__device__ __forceinline__ void va_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, bool NORM, int WT, int RBW>
+__global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, int gx, int gy, int remap) {
+  using SH = G4Shape<WT, RBW>;
+  constexpr int WH = SH::WH, PPW = SH::PPW, STB = SH::STB;
+  constexpr int WM = RBW / 4, WN = G4_NW / WM, T = G4_CT / WN, NACC = 2;
+  static_assert(WT == 0 || WT == 2, "fp16-plane weights (fp8 tile pairs keep gemm3_kernel)");
+  static_assert(RBW == 4 || RBW == 8, "64 or 128 rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char g4_lds[];      // the ONE LDS object of this kernel (ring + rinv)
+  float* rinv_s = reinterpret_cast<float*>(g4_lds + G4_ST * STB);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid % WM, wn = wid / WM;
+  int bx, by;
+  if (remap) {     // see gemm3_kernel
+    const int total = gx * gy, l = blockIdx.x, xcd = l & 7, per = total >> 3, extra = total & 7;
+    const int lp = xcd * per + (xcd < extra ? xcd : extra) + (l >> 3);
+    const int panel = lp / (4 * gx), rem = lp - panel * 4 * gx, pr = min(4, gy - panel * 4);
+    bx = rem / pr;
+    by = panel * 4 + rem - bx * pr;
+  } else {
+    bx = blockIdx.x % gx;
+    by = blockIdx.x / gx;
+  }
+  const int rb0 = by * RBW, ct0 = bx * G4_CT;
+  const int KG = K / 32;
+
+  // this wave's PPW pieces of a stage: piece p < XP = plane fragment (row block p / 2, plane p % 2), else weight fragment
+  // (column tile (p - XP) / WH, plane (p - XP) % WH).  Row blocks past the last one re-read it (their outputs are not stored).
+  const unsigned char* src[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int p = wid * PPW + j;
+    if (p < SH::XP) {
+      const int rb = min(rb0 + p / VA_NPL, a.R - 1);
+      src[j] = reinterpret_cast<const unsigned char*>(a.XP) + ((size_t)(rb * VA_NPL + p % VA_NPL) * KG) * 1024 + lane * 16;
+    } else {
+      const int pw = p - SH::XP;
+      src[j] = static_cast<const unsigned char*>(a.W) + ((size_t)(ct0 + pw / WH) * KG * WH + pw % WH) * 1024 + lane * 16;
+    }
+  }
+  const int xstep = 1024, wstep = 1024 * WH;      // bytes from one k-group's fragment to the next
+  auto issue = [&](int stage) {                  // the next k-group's pieces of this wave -> LDS stage
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int p = wid * PPW + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[j],
+                                       (__attribute__((address_space(3))) void*)(g4_lds + stage * STB + p * 1024), 16, 0, 0);
+      src[j] += (p < SH::XP) ? xstep : wstep;
+    }
+  };
+  issue(0);
+  if (KG > 1) issue(1);
+
+  if constexpr (NORM) {   // rinv of the workgroup's rows: ordered sum of the producer's per-tile partial sums of squares
+    if (tid < RBW * 16) {
+      const int rbi = tid >> 4, mm = tid & 15;
+      float ssp = 0.f;
+      if (rb0 + rbi < a.R) {
+        const float* sp = a.ss_in + (size_t)(rb0 + rbi) * a.n_ss_in * 16 + mm;
+        for (int i = 0; i < a.n_ss_in; ++i) ssp += sp[i * 16];
+      }
+      rinv_s[tid] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+    }
+  }
+
+  f32x4 acc[4][T][NACC];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int pp = 0; pp < NACC; ++pp) acc[r][t][pp] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int stage = 0, nstage = 2;     // stage of k-group kg, stage that k-group kg + 2 goes to
+  for (int kg = 0; kg < KG; ++kg) {
+    // this wave's pieces of k-group kg have landed (those of kg + 1 may still fly), then everybody's have, and everybody is
+    // done reading the stage k-group kg - 1 lived in: that one takes k-group kg + 2
+    if (kg + 1 < KG) va_wait_vmcnt<PPW>(); else va_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kg + 2 < KG) issue(nstage);
+    const u32x4* xs = reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane;
+    const u32x4* ws = xs + SH::XP * 64;
+    f16x8 wf[T][WH];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int hh = 0; hh < WH; ++hh) wf[t][hh] = __builtin_bit_cast(f16x8, ws[((wn * T + t) * WH + hh) * 64]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      u32x4 x3[VA_NPL];
+#pragma unroll
+      for (int pl = 0; pl < VA_NPL; ++pl) x3[pl] = xs[((wm * 4 + r) * VA_NPL + pl) * 64];
+#pragma unroll
+      for (int t = 0; t < T; ++t) mfma_group<WT>(wf[t], x3, acc[r][t]);
+    }
+    stage = stage == G4_ST - 1 ? 0 : stage + 1;
+    nstage = nstage == G4_ST - 1 ? 0 : nstage + 1;
+  }
+
+  if constexpr (NORM) __syncthreads();      // rinv_s (written before the loop; KG >= 1 barriers passed, but say so)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rb = rb0 + wm * 4 + r;
+    if (rb >= a.R) break;
+    const float rinv = NORM ? rinv_s[(wm * 4 + r) * 16 + (lane & 15)] : 1.f;
+    f32x4 v[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f32x4 sacc = acc_sum<WT>(acc[r][t]);
+      sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(ct0 + wn * T + t) * 16 + 4 * (lane >> 4));
+      v[t] = sacc * rinv;
+    }
+    gemv3_epilogue<T, EPI>(a, rb, ct0 + wn * T, lane, v);
   }
 }
