@@ -91,14 +91,16 @@ static int launch_gemm4_i(const Gemv3Args& a, int64_t K, int gx, hipStream_t s) 
   if (va_big_lds_once(reinterpret_cast<const void*>(gemm4_kernel<EPI, NORM, WT, RBW>), SH::LDS, &big)) return VAURA_ERR_STATE;
   const int gy = (a.R + RBW - 1) / RBW;
   VA_LAUNCH((gemm4_kernel<EPI, NORM, WT, RBW>), dim3((unsigned)(gx * gy)), dim3(G4_NW * 64), SH::LDS, s, a, (int)K, gx, gy,
-            (va_debug_flags & 0x8000u) ? 0 : 1);
+            ((va_debug_flags & 0x8000u) ? 0 : 1) | ((va_debug_flags >> 17) & 6));      // bits 18, 19: ablations (no DMA / no products)
   return 0;
 }
 template <int EPI, bool NORM>
 static int launch_gemm4(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
   const int gx = (int)(tiles / G4_CT);
   // 128-row workgroups when there are enough of them for every CU (wo / w2 of a 166-position prompt: 6 x 21 = 126 -> 64 rows, 252)
-  const bool big = !(va_debug_flags & 32u) && gx * ((a.R + 7) / 8) >= 256;
+  // (one plane: two 64-row workgroups share a CU, 72 KB of LDS each, and cover a ragged count better — qkv: 378 x 128 rows = 1.5
+  // rounds of the chip's 256 slots takes 102 us, 756 x 64 rows on 512 slots 81 us)
+  const bool big = !(va_debug_flags & 32u) && gx * ((a.R + 7) / 8) >= (a.wq == 2 ? 256 : 512);
   if (a.wq == 2) return big ? launch_gemm4_i<EPI, NORM, 2, 8>(a, K, gx, s) : launch_gemm4_i<EPI, NORM, 2, 4>(a, K, gx, s);
   return big ? launch_gemm4_i<EPI, NORM, 0, 8>(a, K, gx, s) : launch_gemm4_i<EPI, NORM, 0, 4>(a, K, gx, s);
 }

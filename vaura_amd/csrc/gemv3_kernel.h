@@ -680,7 +680,16 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K, 
       float ssp = 0.f;
       if (rb0 + rbi < a.R) {
         const float* sp = a.ss_in + (size_t)(rb0 + rbi) * a.n_ss_in * 16 + mm;
-        for (int i = 0; i < a.n_ss_in; ++i) ssp += sp[i * 16];
+        for (int i0 = 0; i0 < a.n_ss_in; i0 += 8) {      // eight loads in flight, summed in order
+          float pv[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const float x = sp[min(i0 + jj, a.n_ss_in - 1) * 16];
+            pv[jj] = i0 + jj < a.n_ss_in ? x : 0.f;
+          }
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) ssp += pv[jj];
+        }
       }
       rinv_s[tid] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
     }
@@ -764,14 +773,20 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K, 
 // (k-group) order, so the results are bit-identical to it.
 #define G4_NW 8
 #define G4_CT 16
-#define G4_ST 3
+#ifndef G4_SCHED
+#define G4_SCHED 1
+#endif
 template <int WT, int RBW>
 struct G4Shape {
   static constexpr int WH = WT == 2 ? 2 : 1;
   static constexpr int XP = RBW * VA_NPL, WP = G4_CT * WH;          // DMA pieces (1 KB) per stage
   static constexpr int PPW = (XP + WP) / G4_NW;                     // per wave
   static constexpr int STB = (XP + WP) * 1024;                      // bytes per stage
-  static constexpr int LDS = G4_ST * STB + RBW * 16 * 4;            // + rinv of the workgroup's rows
+  // stages: a k-group's stage is read during its own step and the one before, so NST stages leave NST - 2 k-steps between a
+  // piece's issue and the barrier that needs it.  Four where they fit in 160 KB without costing a co-resident workgroup
+  // (one weight plane, 128 rows: 128 KB); else three (two planes x 128 rows: 144 KB; one plane x 64 rows: 72 KB, two per CU)
+  static constexpr int NST = (WT == 0 && RBW == 8) ? 4 : 3;
+  static constexpr int LDS = NST * STB + 4 * RBW * 16 * 4;          // + four partial sums of squares per row of the workgroup
   static_assert((XP + WP) % G4_NW == 0, "whole pieces per wave");
 };
 
@@ -781,17 +796,17 @@ __device__ __forceinline__ void va_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(
 template <int EPI, bool NORM, int WT, int RBW>
 __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, int gx, int gy, int remap) {
   using SH = G4Shape<WT, RBW>;
-  constexpr int WH = SH::WH, PPW = SH::PPW, STB = SH::STB;
+  constexpr int WH = SH::WH, PPW = SH::PPW, STB = SH::STB, NST = SH::NST;
   constexpr int WM = RBW / 4, WN = G4_NW / WM, T = G4_CT / WN, NACC = 2;
   static_assert(WT == 0 || WT == 2, "fp16-plane weights (fp8 tile pairs keep gemm3_kernel)");
   static_assert(RBW == 4 || RBW == 8, "64 or 128 rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char g4_lds[];      // the ONE LDS object of this kernel (ring + rinv)
-  float* rinv_s = reinterpret_cast<float*>(g4_lds + G4_ST * STB);
+  float* ssq_s = reinterpret_cast<float*>(g4_lds + NST * STB);      // [4 parts][RBW * 16 rows]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid % WM, wn = wid / WM;
   int bx, by;
-  if (remap) {     // see gemm3_kernel
+  if (remap & 1) {     // see gemm3_kernel
     const int total = gx * gy, l = blockIdx.x, xcd = l & 7, per = total >> 3, extra = total & 7;
     const int lp = xcd * per + (xcd < extra ? xcd : extra) + (l >> 3);
     const int panel = lp / (4 * gx), rem = lp - panel * 4 * gx, pr = min(4, gy - panel * 4);
@@ -828,18 +843,32 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
       src[j] += (p < SH::XP) ? xstep : wstep;
     }
   };
-  issue(0);
-  if (KG > 1) issue(1);
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < KG) issue(st);
 
-  if constexpr (NORM) {   // rinv of the workgroup's rows: ordered sum of the producer's per-tile partial sums of squares
-    if (tid < RBW * 16) {
-      const int rbi = tid >> 4, mm = tid & 15;
+  if constexpr (NORM) {
+    // sum of squares of the workgroup's rows from the producer's per-tile partials, in the decode GEMV's order (part q = tiles
+    // q, q + 4, ... in turn, then (p0 + p1) + (p2 + p3)): the same rinv, bit for bit, as when the position is decoded alone.
+    // Eight loads in flight per thread (round 2's loop over n_ss_in waited for each of its 96 loads: ~20 us per GEMM).
+    if (tid < RBW * 64) {
+      const int row = tid % (RBW * 16), q = tid / (RBW * 16);
       float ssp = 0.f;
-      if (rb0 + rbi < a.R) {
-        const float* sp = a.ss_in + (size_t)(rb0 + rbi) * a.n_ss_in * 16 + mm;
-        for (int i = 0; i < a.n_ss_in; ++i) ssp += sp[i * 16];
+      if (rb0 + (row >> 4) < a.R) {
+        const float* sp = a.ss_in + (size_t)(rb0 + (row >> 4)) * a.n_ss_in * 16 + (row & 15);
+        for (int j0 = 0; 4 * j0 < a.n_ss_in; j0 += 8) {
+          float pv[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const int i = q + 4 * (j0 + jj);
+            const float x = sp[min(i, a.n_ss_in - 1) * 16];      // unconditional load (a select on the load itself makes hipcc branch around it)
+            pv[jj] = i < a.n_ss_in ? x : 0.f;
+          }
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) ssp += pv[jj];
+        }
       }
-      rinv_s[tid] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+      ssq_s[q * (RBW * 16) + row] = ssp;
     }
   }
 
@@ -851,39 +880,89 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
 #pragma unroll
       for (int pp = 0; pp < NACC; ++pp) acc[r][t][pp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int stage = 0, nstage = 2;     // stage of k-group kg, stage that k-group kg + 2 goes to
-  for (int kg = 0; kg < KG; ++kg) {
-    // this wave's pieces of k-group kg have landed (those of kg + 1 may still fly), then everybody's have, and everybody is
-    // done reading the stage k-group kg - 1 lived in: that one takes k-group kg + 2
-    if (kg + 1 < KG) va_wait_vmcnt<PPW>(); else va_wait_vmcnt<0>();
+  // Fragment addresses: plane fragment (row block r of this wave, plane pl) and weight fragment (tile t, plane hh) of a stage
+  auto xfrag = [&](int stage, int r, int pl) -> u32x4 {
+    return (reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane)[((wm * 4 + r) * VA_NPL + pl) * 64];
+  };
+  auto wfrag = [&](int stage, int t, int hh) -> f16x8 {
+    return __builtin_bit_cast(f16x8, (reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane)[(SH::XP + (wn * T + t) * WH + hh) * 64]);
+  };
+  // One k-group.  On entry the weight fragments of k-group kg (register set S) and the planes of its row block 0 are already
+  // requested; during its four row-block steps the wave requests, ahead of their use, the planes of the next row block and — from
+  // stage kg + 1, landed and published by this step's barrier — the weight fragments of k-group kg + 1 (set S ^ 1) and the planes of
+  // ITS row block 0: LDS reads and MFMAs of one wave overlap, and the waves of the workgroup no longer read LDS in one burst
+  // behind the barrier with the matrix pipe idle (compute alone, DMA disabled, ran at 37 % of the MFMA peak that way).
+  // The stage k-group kg - 1 lived in is free at this barrier: it takes k-group kg + NST - 1.
+  f16x8 wf[2][T][WH];
+  u32x4 x3[2][VA_NPL];
+  int st0 = 0;            // stage of k-group kg
+  auto kstep = [&](int kg, auto slot) {
+    constexpr int S = decltype(slot)::value;
+    const int st1 = st0 == NST - 1 ? 0 : st0 + 1;           // stage of k-group kg + 1
+    const int stf = st0 == 0 ? NST - 1 : st0 - 1;           // the free one
+    // this wave's pieces of k-group kg + 1 have landed: the stages issued after it may still fly (none near the end)
+    if (kg + NST - 2 < KG) va_wait_vmcnt<PPW * (NST - 3)>(); else va_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kg + 2 < KG) issue(nstage);
-    const u32x4* xs = reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane;
-    const u32x4* ws = xs + SH::XP * 64;
-    f16x8 wf[T][WH];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int hh = 0; hh < WH; ++hh) wf[t][hh] = __builtin_bit_cast(f16x8, ws[((wn * T + t) * WH + hh) * 64]);
+    if (kg + NST - 1 < KG && !(remap & 2)) issue(stf);       // remap bits 1, 2: ablations for tools/time_prefill_gemm.py (no DMA / no products)
+    if (remap & 4) { st0 = st1; return; }
+    // (the last k-group reads a stale stage here and drops it: no branch in the step)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      u32x4 x3[VA_NPL];
+      if (r + 1 < 4) {
 #pragma unroll
-      for (int pl = 0; pl < VA_NPL; ++pl) x3[pl] = xs[((wm * 4 + r) * VA_NPL + pl) * 64];
+        for (int pl = 0; pl < VA_NPL; ++pl) x3[(r + 1) & 1][pl] = xfrag(st0, r + 1, pl);
+      } else {
 #pragma unroll
-      for (int t = 0; t < T; ++t) mfma_group<WT>(wf[t], x3, acc[r][t]);
+        for (int pl = 0; pl < VA_NPL; ++pl) x3[0][pl] = xfrag(st1, 0, pl);
+      }
+      if (r == 1 || r == 2) {      // next k-group's weight fragments: half with row block 1, half with row block 2
+#pragma unroll
+        for (int i = (r - 1) * (T * WH / 2); i < r * (T * WH / 2); ++i) wf[S ^ 1][i / WH][i % WH] = wfrag(st1, i / WH, i % WH);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) mfma_group<WT>(wf[S][t], x3[r & 1], acc[r][t]);
     }
-    stage = stage == G4_ST - 1 ? 0 : stage + 1;
-    nstage = nstage == G4_ST - 1 ? 0 : nstage + 1;
+    if constexpr (G4_SCHED) {
+      // the order above, pinned: per row block {the reads written with it, its MFMAs}
+      constexpr int MPR = T * (WT == 2 ? 3 : 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL + T * WH / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL + T * WH / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+    }
+    st0 = st1;
+  };
+  // k-group 0's fragments: its stage has landed (NST - 2 younger stages may fly) and is published by a barrier
+  if (KG >= NST - 1) va_wait_vmcnt<PPW * (NST - 2)>(); else va_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int hh = 0; hh < WH; ++hh) wf[0][t][hh] = wfrag(0, t, hh);
+#pragma unroll
+  for (int pl = 0; pl < VA_NPL; ++pl) x3[0][pl] = xfrag(0, 0, pl);
+  for (int kg = 0; kg < KG; kg += 2) {       // K / 32 is even for every K the launcher admits
+    kstep(kg, std::integral_constant<int, 0>{});
+    kstep(kg + 1, std::integral_constant<int, 1>{});
   }
 
-  if constexpr (NORM) __syncthreads();      // rinv_s (written before the loop; KG >= 1 barriers passed, but say so)
+  if constexpr (NORM) __syncthreads();      // ssq_s (written before the loop; KG >= 1 barriers passed, but say so)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int rb = rb0 + wm * 4 + r;
     if (rb >= a.R) break;
-    const float rinv = NORM ? rinv_s[(wm * 4 + r) * 16 + (lane & 15)] : 1.f;
+    float rinv = 1.f;
+    if constexpr (NORM) {
+      const float* pq = ssq_s + (wm * 4 + r) * 16 + (lane & 15);
+      const float ssp = (pq[0] + pq[RBW * 16]) + (pq[2 * RBW * 16] + pq[3 * RBW * 16]);
+      rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+    }
     f32x4 v[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
