@@ -107,6 +107,11 @@ SPLIT_GEMV_CASES = [
     (4096, 1536, L.EPI_RESID, False, 300),
     (1536, 9216, L.EPI_LOGITS, True, 270),
     (1536, 4608, L.EPI_STORE, True, 100),     # 7 row blocks: still the GEMV loop
+    # enough 128-row x 256-column workgroups to fill the chip: the 128-row instances of the LDS-DMA GEMM (ragged last panel of
+    # the XCD tile order: 17 and 21 row tiles)
+    (1536, 8192, L.EPI_SWIGLU, True, 2100),
+    (1536, 9216, L.EPI_LOGITS, True, 2100),
+    (1536, 4608, L.EPI_STORE, True, 2656),
 ]
 
 

@@ -19,9 +19,13 @@ from vaura_amd import _lib as L
 FLAGS = int(os.environ.get("VAURA_DEBUG_FLAGS", "0"))    # A/B: 16 = per-position prefill attention, 32 = 64-row prefill GEMM only
 L.lib().vaura_set_debug_flags(FLAGS)
 print("debug flags:", FLAGS)
+WD = os.environ.get("VAURA_WEIGHTS", "h1")     # h1: one fp16 plane (the checkpoint here is made bf16-representable) | h2: two planes
+if WD == "h1":
+    sd = {k: (synth.to_bf16_exact(v) if v.dtype == torch.float32 and v.dim() == 2 else v) for k, v in sd.items()}
+print("weights:", WD)
 for pp in PASSES:
     DecoderEngine.PREFILL_POSITIONS = pp if pp else 1
-    eng = DecoderEngine(cfg, sd, dev, wdtype="bf16")
+    eng = DecoderEngine(cfg, sd, dev, wdtype=WD)
     kw = dict(prompt=prompt, use_sampling=True, top_k=250, cfg_scale=6.0, seed=3)
     out = eng.generate_codes(feats, 221, **kw)
     torch.cuda.synchronize()
