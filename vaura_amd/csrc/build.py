@@ -16,8 +16,9 @@ LIB = os.path.join(HERE, "libvaura_hip.so")
 # diagnostic build (--stamps): the same sources with -DVAURA_STAMPS (in-kernel s_memrealtime stamps, common.h); never loaded by the
 # package, only by tools/pmc_driver --stamps
 LIB_STAMPS = os.path.join(HERE, "libvaura_hip_stamps.so")
-# experiment build (--wt): -DVAURA_WT_STORES, write-through output stores (common.h); timed against the product by tools/pmc_driver
-LIB_WT = os.path.join(HERE, "libvaura_hip_wt.so")
+# experiment build (--plain-stores): -DVAURA_PLAIN_STORES, ordinary instead of write-through output stores (common.h); timed against
+# the product by tools/pmc_driver
+LIB_WT = os.path.join(HERE, "libvaura_hip_plain.so")
 ARCH = "gfx950"
 # -amdgpu-kernarg-preload-count: the first kernel arguments arrive in SGPRs at wave launch (gfx94x/gfx950); the
 # compiler keeps a compatibility prologue that loads them the old way when the firmware does not preload
@@ -40,11 +41,11 @@ def _stale(target: str, deps) -> bool:
 
 
 def _compile(src: str, force: bool, stamps=False) -> str:
-    # stamps: False = product, True = -DVAURA_STAMPS, "wt" = -DVAURA_WT_STORES
+    # stamps: False = product, True = -DVAURA_STAMPS, "wt" = -DVAURA_PLAIN_STORES
     obj = os.path.join(HERE, src.replace(".hip", ".wt.o" if stamps == "wt" else (".stamps.o" if stamps else ".o")))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
-        cmd = [_hipcc(), *FLAGS, *(["-DVAURA_WT_STORES"] if stamps == "wt" else (["-DVAURA_STAMPS"] if stamps else [])), "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *(["-DVAURA_PLAIN_STORES"] if stamps == "wt" else (["-DVAURA_STAMPS"] if stamps else [])), "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -69,4 +70,4 @@ def build(force: bool = False, verbose: bool = False, stamps=False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True, stamps="wt" if "--wt" in sys.argv else ("--stamps" in sys.argv))
+    build(force="--force" in sys.argv, verbose=True, stamps="wt" if "--plain-stores" in sys.argv else ("--stamps" in sys.argv))

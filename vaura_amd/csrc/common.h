@@ -112,11 +112,14 @@ inline int va_big_lds_once(const void* fn, size_t bytes, unsigned long long* don
 }
 
 
-// ---- output stores of the decode-step kernels.  VAURA_WT_STORES (experiment build, python -m vaura_amd.csrc.build --wt): every
-// store is write-through (sc0 sc1), so that a kernel leaves no dirty lines in its XCD's L2 for the end-of-kernel release to write
-// back (MI355X_MICROARCH.md: a release costs ~1.7 us clean, ~6.5 us behind freshly dirtied lines).  Product build: plain stores.
-#ifdef VAURA_WT_STORES
-__device__ __forceinline__ void va_st16(void* p, const f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+// ---- output stores of the decode-step kernels: write-through (sc0 sc1), so that a kernel leaves no dirty lines in its XCD's L2
+// for the end-of-kernel release to write back (MI355X_MICROARCH.md: a release costs ~1.7 us clean, ~6.5 us behind freshly dirtied
+// lines): -1 % on the decode loop.  Inline asm because no builtin takes a per-lane address with cache-policy bits; hipcc does not
+// know the statement is a store of 4 registers, so the string itself ends with the wait state that keeps the next instruction from
+// overwriting the data registers before the store has read them (cdna_hip_programming.md, inline asm: stores).
+// -DVAURA_PLAIN_STORES (experiment build, python -m vaura_amd.csrc.build --plain-stores): ordinary stores, for the A/B.
+#ifndef VAURA_PLAIN_STORES
+__device__ __forceinline__ void va_st16(void* p, const f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void va_st8(void* p, const uint2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void va_st4(void* p, const float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 #else
