@@ -289,9 +289,19 @@ __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float*
 // XS (codec precision 4, "f16"): ONE matrix instruction per product, hi(w) x hi(x) — plain fp16 operands with fp32 accumulate,
 // the arithmetic class the reference itself runs DAC in (models/vaura_model.py:92 casts the codec to fp16).  The buffers keep the
 // pair layout (the lo planes are simply not read from LDS), so every producer / consumer kernel is shared with precision 1.
-template <int NI, bool WS, bool XS = false>
-__global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
+// MJ = 16-row blocks per wave: 4 (128 rows per workgroup) or 8 (256 rows, round 3).  The kernel is bound by what comes through L2 into
+// LDS, and most of that is the weight tile a workgroup re-stages for every (tap, chunk) — C = 192, 7 taps: 516 KB of weights next
+// to 141 KB of activations per 128 x 96 outputs (the plain-fp16 mode, a third of the matrix work on the same bytes, is only 10 %
+// faster).  With MJ = 8 one staged weight tile serves twice the rows: 756 KB per 256 x 96 outputs against 1 314.  The activation
+// block (256 + halo rows) then has ONE LDS buffer — it is restaged between two barriers once per chunk, every NT steps — so two
+// workgroups still share a CU (70 KB each); the output tile goes out in two 128-row passes.
+template <int NI, bool WS, bool XS = false, int MJ = 4>
+__global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
   constexpr int BN_ = 32 * NI;
+  constexpr int BMT = 32 * MJ;              // rows per workgroup (two waves along the rows)
+  constexpr int XROWS_T = BMT + XHALO;
+  constexpr int NXB = MJ == 4 ? 2 : 1;      // LDS buffers of the activation block
+  static_assert(MJ == 4 || MJ == 8, "128 or 256 rows");
   // one raw LDS block: weight tiles | activation blocks during the main loop, the fp32 output tile afterwards.
   // LDS image [buf][kq][row + c(kq)], kq = 16-byte quad of the 32-channel chunk (octet g: kq = 2g hi plane, 2g + 1 lo plane), plane
   // stride a multiple of 16 rows, c = {0,1,0,1,2,3,2,3}.  Why: a wave's ds_read_b128 of a fragment (lane -> (row r16, octet g)) is
@@ -301,8 +311,8 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   // XROWS + 1): the two halves of every group then overlapped on 2 of 16 rows and every fragment read took 2 x the cycles
   // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.37 for this kernel, profiles/r03_codec_mfma.json).  The staging writes (8 lanes =
   // the 8 quads of one row) now meet pairwise (2-way), which the store's own issue time hides.
-  constexpr int WSTR = (BN_ + 3 + 15) / 16 * 16, XSTR = (XROWS + 3 + 15) / 16 * 16;
-  constexpr int WS_ELEMS = 2 * (BK / 4) * WSTR, XS_ELEMS = 2 * (BK / 4) * XSTR;
+  constexpr int WSTR = (BN_ + 3 + 15) / 16 * 16, XSTR = (XROWS_T + 3 + 15) / 16 * 16;
+  constexpr int WS_ELEMS = 2 * (BK / 4) * WSTR, XS_ELEMS = NXB * (BK / 4) * XSTR;
   constexpr int SP = BN_ + 4;               // padded row stride (floats) of the staged output tile
   static_assert((WS_ELEMS + XS_ELEMS) * 16 >= BM * SP * 4, "the output tile must fit in the main loop's LDS");
   __shared__ u32x4 smem[WS_ELEMS + XS_ELEMS];
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   auto Xs = [&](int buf, int kq, int row) -> u32x4& { return smem[WS_ELEMS + (buf * (BK / 4) + kq) * XSTR + row + coff(kq)]; };
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wn = wv & 1, wm = wv >> 1;
-  const int j0 = blockIdx.x * BM;
+  const int j0 = blockIdx.x * BMT;
   const int n0 = blockIdx.y * BN_;
   const int phases = a.ostride;
   const int b = blockIdx.z / phases, ph = blockIdx.z % phases;
@@ -323,8 +333,8 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   const int nk = NT * kc;
   const int span = (NT - 1) * (a.off_step < 0 ? -a.off_step : a.off_step);
   const int lo_off = a.off_base + (a.off_step < 0 ? (NT - 1) * a.off_step : 0);   // smallest row offset of any tap
-  const int xrows = BM + span;
-  constexpr int XL = (XROWS * (BK / 4) + 255) / 256;   // activation quads per thread per chunk (6)
+  const int xrows = BMT + span;
+  constexpr int XL = (XROWS_T * (BK / 4) + 255) / 256;   // activation quads per thread per chunk (6, or 10 for 256 rows)
 
   u32x4 wreg[NI], xreg[XL];
   auto load_w = [&](int kt) {
@@ -354,15 +364,15 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int qd = tid + 256 * i;
-      if ((qd >> 3) < XROWS) Xs(buf, qd & 7, qd >> 3) = xreg[i];
+      if ((qd >> 3) < XROWS_T) Xs(buf, qd & 7, qd >> 3) = xreg[i];
     }
   };
 
-  f32x4 acc[NI][4];
+  f32x4 acc[NI][MJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   load_w(0);
   load_x(0);
@@ -372,33 +382,43 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   const int g = lane >> 4, r16 = lane & 15;
   int kt = 0;
   for (int c = 0; c < kc; ++c) {
-    const int xb = c & 1;
+    const int xb = NXB == 2 ? (c & 1) : 0;
     for (int t = 0; t < NT; ++t, ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nk) load_w(kt + 1);
-      if (t == 0 && c + 1 < kc) load_x(c + 1);
+      // (256 rows: the next chunk's block is requested at the LAST tap — its registers are free of the step's fragments only there —
+      // and stored between two barriers below)
+      if (t == (NXB == 2 ? 0 : NT - 1) && c + 1 < kc) load_x(c + 1);
       const int shift = a.off_base + t * a.off_step - lo_off;
-      f16x8 wh[NI], wl[NI], xh[4], xl[4];
+      f16x8 wh[NI], wl[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         wh[i] = __builtin_bit_cast(f16x8, Ws(buf, 2 * g, wn * (NI * 16) + i * 16 + r16));
         if constexpr (!WS && !XS) wl[i] = __builtin_bit_cast(f16x8, Ws(buf, 2 * g + 1, wn * (NI * 16) + i * 16 + r16));
       }
+      constexpr int JG = MJ == 4 ? 4 : 2;       // row blocks whose fragments are live together (256 rows: the register budget)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xh[j] = __builtin_bit_cast(f16x8, Xs(xb, 2 * g, shift + wm * 64 + j * 16 + r16));
-        if constexpr (!XS) xl[j] = __builtin_bit_cast(f16x8, Xs(xb, 2 * g + 1, shift + wm * 64 + j * 16 + r16));
-      }
+      for (int jh = 0; jh < MJ; jh += JG) {
+        f16x8 xh[JG], xl[JG];
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if constexpr (!WS && !XS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
-          if constexpr (!XS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < JG; ++j) {
+          xh[j] = __builtin_bit_cast(f16x8, Xs(xb, 2 * g, shift + wm * (16 * MJ) + (jh + j) * 16 + r16));
+          if constexpr (!XS) xl[j] = __builtin_bit_cast(f16x8, Xs(xb, 2 * g + 1, shift + wm * (16 * MJ) + (jh + j) * 16 + r16));
         }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < JG; ++j) {
+            if constexpr (!WS && !XS) acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][jh + j], 0, 0, 0);
+            if constexpr (!XS) acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][jh + j], 0, 0, 0);
+            acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][jh + j], 0, 0, 0);
+          }
+      }
       if (kt + 1 < nk) store_w(buf ^ 1);
-      if (t == NT - 1 && c + 1 < kc) store_x(xb ^ 1);
+      if (t == NT - 1 && c + 1 < kc) {
+        if constexpr (NXB == 1) __syncthreads();        // every wave is done with the block before it is overwritten
+        store_x(NXB == 2 ? (xb ^ 1) : 0);
+      }
       __syncthreads();
     }
   }
@@ -409,14 +429,21 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(ConvPArgs a) {
   // whole 128-byte lines per 4 threads.  (The main loop ended with a barrier: its LDS is free.)
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int h = 0; h < MJ / 4; ++h) {          // 128 rows per pass: row block wm * MJ + j of the workgroup, eight per pass
+    if (h > 0) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int row = wm * 64 + j * 16 + r16, col = wn * (NI * 16) + i * 16 + 4 * g;
-      *reinterpret_cast<f32x4*>(stage + row * SP + col) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + n0 + col);
+    for (int j = 0; j < MJ; ++j) {
+      const int rbk = wm * MJ + j;
+      if (rbk / 8 != h) continue;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int row = (rbk % 8) * 16 + r16, col = wn * (NI * 16) + i * 16 + 4 * g;
+        *reinterpret_cast<f32x4*>(stage + row * SP + col) = acc[i][j] + *reinterpret_cast<const f32x4*>(a.bias + n0 + col);
+      }
     }
-  __syncthreads();
-  conv_tile_store<BN_, SP>(a, stage, b, ph, j0, n0, tid);
+    __syncthreads();
+    conv_tile_store<BN_, SP>(a, stage, b, ph, j0 + h * BM, n0, tid);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,12 +817,21 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       pairs = 2;        // conv_in: fp8-valued weights in one fp16 plane, pair input from the quantizer
     }
     if (pairs == 4) {   // "f16": one matrix instruction per product (hi planes only)
-      if (cv.cout % BN == 0) VA_LAUNCH((conv_pair_kernel<3, true, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      const int g256 = (p.jcount + 2 * BM - 1) / (2 * BM);
+      if (cv.cout % BN == 0 && !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / BN) * B * ph >= 384)
+        VA_LAUNCH((conv_pair_kernel<3, true, true, 8>), dim3(g256, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      else if (cv.cout % BN == 0) VA_LAUNCH((conv_pair_kernel<3, true, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
       else VA_LAUNCH((conv_pair_kernel<2, true, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
       return 0;
     }
     if (cv.cout % BN == 0) {
-      if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      // 256-row workgroups (half the weight bytes through L2 per output) where two per CU still fill the chip; debug flag bit 20: never
+      const int g256 = (p.jcount + 2 * BM - 1) / (2 * BM);
+      const bool big = !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / BN) * B * ph >= 384;
+      if (big) {
+        if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true, false, 8>), dim3(g256, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+        else VA_LAUNCH((conv_pair_kernel<3, false, false, 8>), dim3(g256, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      } else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
       else VA_LAUNCH((conv_pair_kernel<3, false>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
     } else {
       if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
