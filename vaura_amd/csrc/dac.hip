@@ -834,7 +834,12 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       } else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
       else VA_LAUNCH((conv_pair_kernel<3, false>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
     } else {
-      if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
+      const int g256 = (p.jcount + 2 * BM - 1) / (2 * BM);
+      const bool big = !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / 64) * B * ph >= 384;
+      if (big) {
+        if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true, false, 8>), dim3(g256, cv.cout / 64, B * ph), dim3(256), 0, s, p);
+        else VA_LAUNCH((conv_pair_kernel<2, false, false, 8>), dim3(g256, cv.cout / 64, B * ph), dim3(256), 0, s, p);
+      } else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
       else VA_LAUNCH((conv_pair_kernel<2, false>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
     }
     return 0;
