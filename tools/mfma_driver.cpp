@@ -4,6 +4,8 @@
 //   codec    vaura_dac_decode on the DAC-44k geometry (1536 -> 96 channels, rates 8,8,4,2, 9 codebooks), `clips` x 220 frames,
 //            codec precision 0 fp32-MFMA | 1 fp16 pairs (default) | 2 one-plane weights | 4 single fp16 plane ("f16")
 //   avclip   vaura_avclip_forward on ViT-B/16 divided space-time, `clips` x 4 segments of 16 x 224 x 224 frames
+//   prefill  the four GEMMs of one teacher-forced prompt pass of the sliding-window caller (vaura_gemv_pair at 166 positions x
+//            2 `clips` rows: qkv, wo, w1||w3, w2 of one layer), `precision` = weight storage 3 one fp16 plane | 4 two planes
 //
 // Counters do not depend on the VALUES, so every weight / bias / alpha pointer of the descriptors points into one buffer of small
 // finite noise (fp16 values |v| < 0.05; read as fp32 they are finite too): no checkpoint, no packing code to keep in sync.  Shapes,
@@ -63,8 +65,8 @@ static void conv(vaura_conv& cv, int cin, int cout, int taps, int dil, int strid
 }
 
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s <libvaura_hip.so> codec|avclip [clips] [precision] [repeats]\n", argv[0]); return 1; }
-  const bool codec = !strcmp(argv[2], "codec");
+  if (argc < 3) { fprintf(stderr, "usage: %s <libvaura_hip.so> codec|avclip|prefill [clips] [precision] [repeats]\n", argv[0]); return 1; }
+  const bool codec = !strcmp(argv[2], "codec"), prefill = !strcmp(argv[2], "prefill");
   const int clips = argc > 3 ? atoi(argv[3]) : 8;
   const int precision = argc > 4 ? atoi(argv[4]) : 1;
   const int repeats = argc > 5 ? atoi(argv[5]) : 3;
@@ -78,6 +80,58 @@ int main(int argc, char** argv) {
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms = 0;
+  if (prefill) {
+    typedef int (*gemv_pair_t)(const void*, int, const uint16_t*, const float*, int, const float*, float*, float*, uint16_t*, const float*,
+                               float*, int64_t, int64_t, int64_t, int, float, vaura_stream_t);
+    auto gp = (gemv_pair_t)dlsym(lib, "vaura_gemv_pair");
+    auto wbytes = (size_t (*)(int64_t, int64_t, int))dlsym(lib, "vaura_packed_weight_bytes");
+    if (!gp || !wbytes) return 1;
+    const int wd = (argc > 4 && atoi(argv[4]) == 3) ? VAURA_W_H1 : VAURA_W_H2;
+    const int64_t rows = (int64_t)166 * 2 * clips, rp = (rows + 15) / 16 * 16, D = 1536, F = 4096;
+    struct G { const char* name; int64_t N, K; int epi; bool norm; } gs[4] = {
+        {"qkv", 3 * D, D, 0 /* store */, true}, {"wo", D, D, 1 /* + residual */, false}, {"w13", 2 * F, D, 2 /* SwiGLU */, true}, {"w2", D, F, 1 /* + residual */, false}};
+    // packed weights = noise halves followed by N power-of-two row scales; planes = noise halves; sums of squares positive
+    float* ss; CK(hipMalloc(&ss, (size_t)(rp / 16) * (F / 16) * 16 * 4)); fill_f32<<<256, 256>>>(ss, (size_t)(rp / 16) * (F / 16) * 16, 0.0f, 1u);
+    {
+      std::vector<float> one((size_t)(rp / 16) * (F / 16) * 16, 16.0f);
+      CK(hipMemcpy(ss, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+    }
+    float *res, *out, *oss; uint16_t* osp;
+    CK(hipMalloc(&res, (size_t)rp * F * 4)); fill_f32<<<2048, 256>>>(res, (size_t)rp * F, 1.0f, 21u);
+    CK(hipMalloc(&out, (size_t)rp * 3 * D * 4)); CK(hipMalloc(&osp, (size_t)rp * 2 * 3 * D * 2)); CK(hipMalloc(&oss, (size_t)(rp / 16) * (3 * D / 16) * 16 * 4));
+    const float* gout = ones(3 * D);
+    void* wp[4];
+    for (int i = 0; i < 4; ++i) {
+      const size_t wb = wbytes(gs[i].N, gs[i].K, wd);
+      CK(hipMalloc(&wp[i], wb));
+      fill_noise<<<2048, 256>>>((_Float16*)wp[i], (wb - (size_t)gs[i].N * 4) / 2, 100u + i);
+      std::vector<float> sc((size_t)gs[i].N, 1.0f / 8192.0f);
+      CK(hipMemcpy((char*)wp[i] + wb - (size_t)gs[i].N * 4, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+    }
+    const uint16_t* xs = (const uint16_t*)noise((size_t)rp * 2 * F * 2);
+    CK(hipDeviceSynchronize());
+    for (int r = 0; r < repeats; ++r) {
+      if (r == repeats - 1) CK(hipEventRecord(e0, st));
+      for (int i = 0; i < 4; ++i) {
+        const bool sw = gs[i].epi == 2 /* SwiGLU */, rs = gs[i].epi == 1 /* + residual */;
+        const int rc = gp(wp[i], wd, xs, gs[i].norm ? ss : nullptr, gs[i].norm ? (int)(gs[i].K / 16) : 0, rs ? res : nullptr, sw ? nullptr : out, nullptr, osp,
+                          gout, rs ? oss : nullptr, rows, gs[i].N, gs[i].K, gs[i].epi, 1e-5f, st);
+        if (rc) { fprintf(stderr, "vaura_gemv_pair(%s): %d\n", gs[i].name, rc); return 3; }
+      }
+    }
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> h(1024);
+    CK(hipMemcpy(h.data(), out, 4096, hipMemcpyDeviceToHost));
+    bool finite = true;
+    for (float v : h) finite = finite && (v == v) && v > -1e30f && v < 1e30f;
+    double fl = 0;
+    for (int i = 0; i < 4; ++i) fl += 2.0 * rows * gs[i].N * gs[i].K;
+    printf("mfma_driver prefill: %lld rows, weights %s, one layer's four GEMMs %.1f us (%.1f TF-equiv), output finite: %d\n", (long long)rows,
+           wd == VAURA_W_H1 ? "h1" : "h2", ms * 1e3, fl / (ms * 1e-3) / 1e12, (int)finite);
+    return finite ? 0 : 4;
+  }
   if (codec) {
     auto decode = (int (*)(const vaura_codec*, const int32_t*, int, int, float*, vaura_stream_t))dlsym(lib, "vaura_dac_decode");
     auto wse = (size_t (*)(const vaura_codec*, int, int))dlsym(lib, "vaura_dac_workspace_elems");

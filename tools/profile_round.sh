@@ -5,7 +5,8 @@
 #      vaura_amd/csrc/libvaura_hip.so): kernel stats + separate --pmc passes for FETCH_SIZE and WRITE_SIZE, for both storages
 #      (h2 = two fp16 planes, what real checkpoints get; h1 = one plane).  rocprofv3 --pmc crashes at start-up under python on this
 #      image; the counters need their own passes (MI355X_MICROARCH.md §rocprofv3 PMC slots).  Drivers are rebuilt every time.
-#   3. the MFMA-bound stages (codec decode, Segment-AVCLIP extractor) through tools/mfma_driver.cpp: kernel stats + MFMA / LDS /
+#   3. the MFMA-bound stages (codec decode, Segment-AVCLIP extractor, the four GEMMs of a prompt pass per weight storage) through
+#      tools/mfma_driver.cpp: kernel stats + MFMA / LDS /
 #      HBM counter passes
 #   4. in-kernel s_memrealtime stamps of the diagnostic build (wave 0 only, and every wave) -> per-phase json
 set -u
@@ -31,12 +32,13 @@ for W in h2 h1; do
   done
   tail -n 1 $OUT/drv_stats_$W.log
 done
-for M in codec avclip; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_stats_$M -- $MDRV $LIB $M 8 > $OUT/mfma_stats_$M.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma_pmcA_$M -- $MDRV $LIB $M 8 > $OUT/mfma_pmcA_$M.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F16 SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $OUT/mfma_pmcB_$M -- $MDRV $LIB $M 8 > $OUT/mfma_pmcB_$M.log 2>&1
+for M in codec avclip prefill_h2 prefill_h1; do
+  case $M in prefill_h2) A="prefill 8 4";; prefill_h1) A="prefill 8 3";; *) A="$M 8";; esac
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_stats_$M -- $MDRV $LIB $A > $OUT/mfma_stats_$M.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma_pmcA_$M -- $MDRV $LIB $A > $OUT/mfma_pmcA_$M.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F16 SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $OUT/mfma_pmcB_$M -- $MDRV $LIB $A > $OUT/mfma_pmcB_$M.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/mfma_${C}_$M -- $MDRV $LIB $M 8 > $OUT/mfma_${C}_$M.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/mfma_${C}_$M -- $MDRV $LIB $A > $OUT/mfma_${C}_$M.log 2>&1
   done
   tail -n 1 $OUT/mfma_stats_$M.log
 done

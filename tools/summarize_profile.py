@@ -4,7 +4,8 @@
   <tag>_bench_under_rocprof.json      the JSON line that run printed
   <tag>_driver_kernel_stats_<w>.csv   the same kernels through tools/pmc_driver (the product .so), w = h2 | h1 (fp16 planes per weight)
   <tag>_pmc_hbm_bytes_<w>.json        HBM bytes per launch per kernel from separate FETCH_SIZE / WRITE_SIZE passes on the driver
-  <tag>_codec_mfma.json, <tag>_avclip_mfma.json   MFMA / LDS / HBM counters of the MFMA-bound stages through tools/mfma_driver
+  <tag>_codec_mfma.json, <tag>_avclip_mfma.json, <tag>_prefill_h{1,2}_mfma.json   MFMA / LDS / HBM counters of the MFMA-bound stages
+                                                  through tools/mfma_driver
   <tag>_stage_stamps_<mode>_<w>.json  per-phase decomposition of the decode-step stages (in-kernel s_memrealtime stamps)
   kernel_names.json                   storage | "c4" -> decode-step stage -> kernel name as rocprofv3 prints it (bench.py quotes it)
 
@@ -140,7 +141,7 @@ def counters(path):
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
-for m in ("codec", "avclip"):
+for m in ("codec", "avclip", "prefill_h2", "prefill_h1"):
     st = newest(f"{src}/mfma_stats_{m}/**/*kernel_stats.csv")
     if not st:
         continue
