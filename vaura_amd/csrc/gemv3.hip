@@ -97,12 +97,31 @@ static int launch_gemm4_i(const Gemv3Args& a, int64_t K, int gx, hipStream_t s) 
 template <int EPI, bool NORM>
 static int launch_gemm4(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
   const int gx = (int)(tiles / G4_CT);
-  // 128-row workgroups when there are enough of them for every CU (wo / w2 of a 166-position prompt: 6 x 21 = 126 -> 64 rows, 252)
-  // (one plane: two 64-row workgroups share a CU, 72 KB of LDS each, and cover a ragged count better — qkv: 378 x 128 rows = 1.5
-  // rounds of the chip's 256 slots takes 102 us, 756 x 64 rows on 512 slots 81 us)
-  const bool big = !(va_debug_flags & 32u) && gx * ((a.R + 7) / 8) >= (a.wq == 2 ? 256 : 512);
-  if (a.wq == 2) return big ? launch_gemm4_i<EPI, NORM, 2, 8>(a, K, gx, s) : launch_gemm4_i<EPI, NORM, 2, 4>(a, K, gx, s);
-  return big ? launch_gemm4_i<EPI, NORM, 0, 8>(a, K, gx, s) : launch_gemm4_i<EPI, NORM, 0, 4>(a, K, gx, s);
+  // rows per workgroup (64, 96 or 128): the one with the least work on the busiest CU — ceil(workgroups / 256) rounds of RBW row
+  // blocks — weighted by what the wave tile costs (64 rows: 64 x 32 wave tiles, 0.63 LDS reads per MFMA against 0.38; 96 rows: one
+  // dead DMA slot in eight).  A 166-position prompt: wo / w2 (6 column tiles) 252 x 64 rows, qkv (18) 504 x 96 rows = 1.97
+  // rounds where 378 x 128 rows left the second round half empty, w1||w3 (32) 672 x 128.  Debug flag bit 5: 64 rows only.
+  int rbw = 4;
+  if (!(va_debug_flags & 32u)) {
+    const int cand[3] = {8, 6, 4};
+    // (one weight plane: two 64-row workgroups share a CU — 72 KB of LDS each — and fill each other's barrier gaps: measured
+    // level with 128 rows on w1||w3 and 15 % ahead of 96 rows on qkv)
+    const float eff[3] = {1.0f, 1.03f, a.wq == 2 ? 1.12f : 0.95f};
+    float best = 1e30f;
+    for (int i = 0; i < 3; ++i) {
+      const int wgs = gx * ((a.R + cand[i] - 1) / cand[i]);
+      const float cost = (float)((wgs + 255) / 256) * cand[i] * eff[i];
+      if (cost < best) { best = cost; rbw = cand[i]; }
+    }
+  }
+  if (a.wq == 2) {
+    if (rbw == 8) return launch_gemm4_i<EPI, NORM, 2, 8>(a, K, gx, s);
+    if (rbw == 6) return launch_gemm4_i<EPI, NORM, 2, 6>(a, K, gx, s);
+    return launch_gemm4_i<EPI, NORM, 2, 4>(a, K, gx, s);
+  }
+  if (rbw == 8) return launch_gemm4_i<EPI, NORM, 0, 8>(a, K, gx, s);
+  if (rbw == 6) return launch_gemm4_i<EPI, NORM, 0, 6>(a, K, gx, s);
+  return launch_gemm4_i<EPI, NORM, 0, 4>(a, K, gx, s);
 }
 
 // many row blocks (a prompt being teacher-forced): GEMM tiling instead of the register-resident GEMV loop

@@ -780,14 +780,15 @@ template <int WT, int RBW>
 struct G4Shape {
   static constexpr int WH = WT == 2 ? 2 : 1;
   static constexpr int XP = RBW * VA_NPL, WP = G4_CT * WH;          // DMA pieces (1 KB) per stage
-  static constexpr int PPW = (XP + WP) / G4_NW;                     // per wave
+  // per wave: every wave issues the same number (the counted vmcnt waits are compile-time), so with 96 rows (28 / 44 pieces) the
+  // last slots repeat the stage's first pieces — the same bytes to the same LDS address a second time
+  static constexpr int PPW = (XP + WP + G4_NW - 1) / G4_NW;
   static constexpr int STB = (XP + WP) * 1024;                      // bytes per stage
   // stages: a k-group's stage is read during its own step and the one before, so NST stages leave NST - 2 k-steps between a
   // piece's issue and the barrier that needs it.  Four where they fit in 160 KB without costing a co-resident workgroup
   // (one weight plane, 128 rows: 128 KB); else three (two planes x 128 rows: 144 KB; one plane x 64 rows: 72 KB, two per CU)
-  static constexpr int NST = (WT == 0 && RBW == 8) ? 4 : 3;
+  static constexpr int NST = (WT == 0 && RBW >= 6) ? 4 : 3;
   static constexpr int LDS = NST * STB + 4 * RBW * 16 * 4;          // + four partial sums of squares per row of the workgroup
-  static_assert((XP + WP) % G4_NW == 0, "whole pieces per wave");
 };
 
 template <int N>
@@ -797,9 +798,10 @@ template <int EPI, bool NORM, int WT, int RBW>
 __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, int gx, int gy, int remap) {
   using SH = G4Shape<WT, RBW>;
   constexpr int WH = SH::WH, PPW = SH::PPW, STB = SH::STB, NST = SH::NST;
-  constexpr int WM = RBW / 4, WN = G4_NW / WM, T = G4_CT / WN, NACC = 2;
+  // waves WM x WN, RPW row blocks and T column tiles per wave: 64 rows = 1 x 8 waves of 4 x 2, 96 rows = 2 x 4 of 3 x 4, 128 rows = 2 x 4 of 4 x 4
+  constexpr int WM = RBW == 4 ? 1 : 2, RPW = RBW / WM, WN = G4_NW / WM, T = G4_CT / WN, NACC = 2;
   static_assert(WT == 0 || WT == 2, "fp16-plane weights (fp8 tile pairs keep gemm3_kernel)");
-  static_assert(RBW == 4 || RBW == 8, "64 or 128 rows");
+  static_assert(RBW == 4 || RBW == 6 || RBW == 8, "64, 96 or 128 rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char g4_lds[];      // the ONE LDS object of this kernel (ring + rinv)
   float* ssq_s = reinterpret_cast<float*>(g4_lds + NST * STB);      // [4 parts][RBW * 16 rows]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
   const unsigned char* src[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int p = wid * PPW + j;
+    const int p = (wid * PPW + j) % (SH::XP + SH::WP);
     if (p < SH::XP) {
       const int rb = min(rb0 + p / VA_NPL, a.R - 1);
       src[j] = reinterpret_cast<const unsigned char*>(a.XP) + ((size_t)(rb * VA_NPL + p % VA_NPL) * KG) * 1024 + lane * 16;
@@ -837,7 +839,7 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
   auto issue = [&](int stage) {                  // the next k-group's pieces of this wave -> LDS stage
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-      const int p = wid * PPW + j;
+      const int p = (wid * PPW + j) % (SH::XP + SH::WP);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[j],
                                        (__attribute__((address_space(3))) void*)(g4_lds + stage * STB + p * 1024), 16, 0, 0);
       src[j] += (p < SH::XP) ? xstep : wstep;
@@ -872,9 +874,9 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
     }
   }
 
-  f32x4 acc[4][T][NACC];
+  f32x4 acc[RPW][T][NACC];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
 
   // Fragment addresses: plane fragment (row block r of this wave, plane pl) and weight fragment (tile t, plane hh) of a stage
   auto xfrag = [&](int stage, int r, int pl) -> u32x4 {
-    return (reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane)[((wm * 4 + r) * VA_NPL + pl) * 64];
+    return (reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane)[((wm * RPW + r) * VA_NPL + pl) * 64];
   };
   auto wfrag = [&](int stage, int t, int hh) -> f16x8 {
     return __builtin_bit_cast(f16x8, (reinterpret_cast<const u32x4*>(g4_lds + stage * STB) + lane)[(SH::XP + (wn * T + t) * WH + hh) * 64]);
@@ -907,21 +909,22 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
     if (kg + NST - 1 < KG && !(remap & 2)) issue(stf);       // remap bits 1, 2: ablations for tools/time_prefill_gemm.py (no DMA / no products)
     if (remap & 4) { st0 = st1; return; }
     // (the last k-group reads a stale stage here and drops it: no branch in the step)
+    constexpr int PB = (S * RPW) & 1;       // the two plane-fragment sets alternate per row block, across k-groups too (RPW may be odd)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (r + 1 < 4) {
+    for (int r = 0; r < RPW; ++r) {
+      if (r + 1 < RPW) {
 #pragma unroll
-        for (int pl = 0; pl < VA_NPL; ++pl) x3[(r + 1) & 1][pl] = xfrag(st0, r + 1, pl);
+        for (int pl = 0; pl < VA_NPL; ++pl) x3[(PB + r + 1) & 1][pl] = xfrag(st0, r + 1, pl);
       } else {
 #pragma unroll
-        for (int pl = 0; pl < VA_NPL; ++pl) x3[0][pl] = xfrag(st1, 0, pl);
+        for (int pl = 0; pl < VA_NPL; ++pl) x3[(PB + RPW) & 1][pl] = xfrag(st1, 0, pl);
       }
       if (r == 1 || r == 2) {      // next k-group's weight fragments: half with row block 1, half with row block 2
 #pragma unroll
         for (int i = (r - 1) * (T * WH / 2); i < r * (T * WH / 2); ++i) wf[S ^ 1][i / WH][i % WH] = wfrag(st1, i / WH, i % WH);
       }
 #pragma unroll
-      for (int t = 0; t < T; ++t) mfma_group<WT>(wf[S][t], x3[r & 1], acc[r][t]);
+      for (int t = 0; t < T; ++t) mfma_group<WT>(wf[S][t], x3[(PB + r) & 1], acc[r][t]);
     }
     if constexpr (G4_SCHED) {
       // the order above, pinned: per row block {the reads written with it, its MFMAs}
@@ -932,8 +935,10 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
       __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL + T * WH / 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      if constexpr (RPW == 4) {
+        __builtin_amdgcn_sched_group_barrier(0x100, VA_NPL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+      }
     }
     st0 = st1;
   };
@@ -954,12 +959,12 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
 
   if constexpr (NORM) __syncthreads();      // ssq_s (written before the loop; KG >= 1 barriers passed, but say so)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int rb = rb0 + wm * 4 + r;
+  for (int r = 0; r < RPW; ++r) {
+    const int rb = rb0 + wm * RPW + r;
     if (rb >= a.R) break;
     float rinv = 1.f;
     if constexpr (NORM) {
-      const float* pq = ssq_s + (wm * 4 + r) * 16 + (lane & 15);
+      const float* pq = ssq_s + (wm * RPW + r) * 16 + (lane & 15);
       const float ssp = (pq[0] + pq[RBW * 16]) + (pq[2 * RBW * 16] + pq[3 * RBW * 16]);
       rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
     }
