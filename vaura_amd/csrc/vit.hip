@@ -610,30 +610,46 @@ __global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* _
   const int h = blockIdx.x, f = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x;
   const int L = 1 + nf * np;
   const size_t row0 = (size_t)seg * L;
-  for (int u = tid; u < VP_KEYS * 8; u += 512) {       // K: one octet of one key per item
-    const int j = u >> 3, kq = u & 7;
+  // Staging: EVERY global load of this thread is requested before the first is converted (4 x 2 quads of K, 7 quads of V: 60
+  // registers).  Round 2's loops loaded, converted and stored one item per iteration — 11 dependent global round trips per
+  // workgroup, ~17 of its ~26 us, for 3.5 us of matrix work (MFMA busy 0.14 in profiles/r03_avclip_mfma.json).
+  constexpr int KIT = (VP_KEYS * 8 + 511) / 512, VIT = (VP_VSTRIDE * (VHD / 4) + 511) / 512;
+  f32x4 kreg[KIT][2], vreg[VIT];
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {       // K: one octet of one key per item
+    const int u = tid + it * 512, j = min(u >> 3, nk - 1), kq = u & 7;
+    const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
+    const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + D + h * VHD + 8 * kq);
+    kreg[it][0] = kp[0];
+    kreg[it][1] = kp[1];
+  }
+#pragma unroll
+  for (int it = 0; it < VIT; ++it) {       // V^T: 4 channels of one key per item
+    const int u = tid + it * 512, j = min(u / (VHD / 4), nk - 1), c = u % (VHD / 4);
+    const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
+    vreg[it] = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + 2 * D + h * VHD)[c];
+  }
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int u = tid + it * 512, j = u >> 3, kq = u & 7;
+    if (u >= VP_KEYS * 8) break;
     h8 hi, lo;
-    if (j < nk) {
-      const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
-      const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + D + h * VHD + 8 * kq);
-      const f32x4 a = kp[0], b = kp[1];
-      const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const f32x4 a = kreg[it][0], b = kreg[it][1];
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { hi[i] = (_Float16)v[i]; lo[i] = (_Float16)(v[i] - (float)hi[i]); }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { hi[i] = (_Float16)0.f; lo[i] = (_Float16)0.f; }
+    for (int i = 0; i < 8; ++i) {
+      const float x = j < nk ? v[i] : 0.f;          // keys >= nk: zeros
+      hi[i] = (_Float16)x;
+      lo[i] = (_Float16)(x - (float)hi[i]);
     }
     Kh[kq * VP_KEYS + j] = hi;
     Kl[kq * VP_KEYS + j] = lo;
   }
-  for (int u = tid; u < VP_VSTRIDE * (VHD / 4); u += 512) {   // V^T: 4 channels of one key per item (keys >= nk: zeros)
-    const int j = u / (VHD / 4), c = u % (VHD / 4);
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (j < nk) {
-      const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
-      v = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + 2 * D + h * VHD)[c];
-    }
+#pragma unroll
+  for (int it = 0; it < VIT; ++it) {
+    const int u = tid + it * 512, j = u / (VHD / 4), c = u % (VHD / 4);
+    if (u >= VP_VSTRIDE * (VHD / 4)) break;
+    const f32x4 v = j < nk ? vreg[it] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const _Float16 hi = (_Float16)v[i];
