@@ -112,6 +112,7 @@ SPLIT_GEMV_CASES = [
     (1536, 8192, L.EPI_SWIGLU, True, 2100),
     (1536, 9216, L.EPI_LOGITS, True, 2100),
     (1536, 4608, L.EPI_STORE, True, 2656),
+    (1536, 8192, L.EPI_SWIGLU, True, 2656),   # cut into two launches: 512 x 128 rows, then the last 38 row blocks in 96-row workgroups
 ]
 
 

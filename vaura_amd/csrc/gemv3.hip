@@ -83,45 +83,63 @@ static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_
   return 0;
 }
 
-// LDS-DMA pipelined GEMM (gemm4_kernel): fp16-plane weights
+// LDS-DMA pipelined GEMM (gemm4_kernel): fp16-plane weights.  One launch over row blocks [rb_off, rb_off + n_rb).
 template <int EPI, bool NORM, int WT, int RBW>
-static int launch_gemm4_i(const Gemv3Args& a, int64_t K, int gx, hipStream_t s) {
+static int launch_gemm4_i(const Gemv3Args& a, int64_t K, int gx, int rb_off, int n_rb, hipStream_t s) {
   using SH = G4Shape<WT, RBW>;
   static unsigned long long big = 0;
   if (va_big_lds_once(reinterpret_cast<const void*>(gemm4_kernel<EPI, NORM, WT, RBW>), SH::LDS, &big)) return VAURA_ERR_STATE;
-  const int gy = (a.R + RBW - 1) / RBW;
+  const int gy = (n_rb + RBW - 1) / RBW;
   VA_LAUNCH((gemm4_kernel<EPI, NORM, WT, RBW>), dim3((unsigned)(gx * gy)), dim3(G4_NW * 64), SH::LDS, s, a, (int)K, gx, gy,
-            ((va_debug_flags & 0x8000u) ? 0 : 1) | ((va_debug_flags >> 17) & 6));      // bits 18, 19: ablations (no DMA / no products)
+            ((va_debug_flags & 0x8000u) ? 0 : 1) | ((va_debug_flags >> 17) & 6),      // bits 18, 19: ablations (no DMA / no products)
+            rb_off);
   return 0;
+}
+template <int EPI, bool NORM, int WT>
+static int launch_gemm4_h(const Gemv3Args& a, int64_t K, int gx, int rbw, int rb_off, int n_rb, hipStream_t s) {
+  if (rbw == 8) return launch_gemm4_i<EPI, NORM, WT, 8>(a, K, gx, rb_off, n_rb, s);
+  if (rbw == 6) return launch_gemm4_i<EPI, NORM, WT, 6>(a, K, gx, rb_off, n_rb, s);
+  return launch_gemm4_i<EPI, NORM, WT, 4>(a, K, gx, rb_off, n_rb, s);
 }
 template <int EPI, bool NORM>
 static int launch_gemm4(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_t s) {
   const int gx = (int)(tiles / G4_CT);
-  // rows per workgroup (64, 96 or 128): the one with the least work on the busiest CU — ceil(workgroups / 256) rounds of RBW row
-  // blocks — weighted by what the wave tile costs (64 rows: 64 x 32 wave tiles, 0.63 LDS reads per MFMA against 0.38; 96 rows: one
-  // dead DMA slot in eight).  A 166-position prompt: wo / w2 (6 column tiles) 252 x 64 rows, qkv (18) 504 x 96 rows = 1.97
-  // rounds where 378 x 128 rows left the second round half empty, w1||w3 (32) 672 x 128.  Debug flag bit 5: 64 rows only.
-  int rbw = 4;
+  // Rows per workgroup (64, 96 or 128): the height with the least work on the busiest CU — ceil(workgroups / 256) rounds of that many
+  // row blocks — weighted by what the wave tile costs (64 rows: 64 x 32 wave tiles, 0.63 LDS reads per MFMA against 0.38 — but with one
+  // weight plane two such workgroups share a CU and fill each other's barrier gaps; 96 rows: one dead DMA slot in eight).  And one
+  // cut: whole rounds of tall workgroups, then the remaining rows in ONE round of a lower height (a second launch), when that beats a
+  // last round that is mostly empty.  A 166-position prompt, two planes: wo / w2 (6 column tiles) 252 x 64 rows; qkv (18) 504 x 96
+  // rows = 1.97 rounds; w1||w3 (32) 512 x 128 rows + 224 x 96 rows instead of 672 x 128 = 2.6 rounds.  Debug flag bit 5: 64 rows only;
+  // bit 22: no cut.
+  const int cand[3] = {8, 6, 4};
+  const float eff[3] = {1.0f, 1.03f, a.wq == 2 ? 1.12f : 0.95f};
+  auto rounds = [&](int rb, int h) { return (float)((gx * ((rb + h - 1) / h) + 255) / 256); };
+  int h1 = 4, h2 = 0, cut = 0;
   if (!(va_debug_flags & 32u)) {
-    const int cand[3] = {8, 6, 4};
-    // (one weight plane: two 64-row workgroups share a CU — 72 KB of LDS each — and fill each other's barrier gaps: measured
-    // level with 128 rows on w1||w3 and 15 % ahead of 96 rows on qkv)
-    const float eff[3] = {1.0f, 1.03f, a.wq == 2 ? 1.12f : 0.95f};
     float best = 1e30f;
     for (int i = 0; i < 3; ++i) {
-      const int wgs = gx * ((a.R + cand[i] - 1) / cand[i]);
-      const float cost = (float)((wgs + 255) / 256) * cand[i] * eff[i];
-      if (cost < best) { best = cost; rbw = cand[i]; }
+      const float c1 = rounds(a.R, cand[i]) * cand[i] * eff[i];
+      if (c1 < best) { best = c1; h1 = cand[i]; h2 = 0; cut = 0; }
+      // (one plane: the co-resident 64-row pairs already smooth the last round; a cut measured 3 % slower there)
+      if (cand[i] == 4 || a.wq != 2 || (va_debug_flags & 0x400000u)) continue;
+      const int full = gx * ((a.R + cand[i] - 1) / cand[i]) / 256;        // whole rounds of this height
+      const int gy1 = full * 256 / gx, rb1 = gy1 * cand[i];
+      if (full < 1 || gy1 < 1 || rb1 >= a.R) continue;
+      for (int k = 0; k < 3; ++k) {
+        const float c2 = (float)full * cand[i] * eff[i] + rounds(a.R - rb1, cand[k]) * cand[k] * eff[k] + 0.3f;   // + a kernel boundary
+        if (c2 < best) { best = c2; h1 = cand[i]; h2 = cand[k]; cut = rb1; }
+      }
     }
   }
+  int rc;
   if (a.wq == 2) {
-    if (rbw == 8) return launch_gemm4_i<EPI, NORM, 2, 8>(a, K, gx, s);
-    if (rbw == 6) return launch_gemm4_i<EPI, NORM, 2, 6>(a, K, gx, s);
-    return launch_gemm4_i<EPI, NORM, 2, 4>(a, K, gx, s);
+    rc = launch_gemm4_h<EPI, NORM, 2>(a, K, gx, h1, 0, h2 ? cut : a.R, s);
+    if (!rc && h2) rc = launch_gemm4_h<EPI, NORM, 2>(a, K, gx, h2, cut, a.R - cut, s);
+  } else {
+    rc = launch_gemm4_h<EPI, NORM, 0>(a, K, gx, h1, 0, h2 ? cut : a.R, s);
+    if (!rc && h2) rc = launch_gemm4_h<EPI, NORM, 0>(a, K, gx, h2, cut, a.R - cut, s);
   }
-  if (rbw == 8) return launch_gemm4_i<EPI, NORM, 0, 8>(a, K, gx, s);
-  if (rbw == 6) return launch_gemm4_i<EPI, NORM, 0, 6>(a, K, gx, s);
-  return launch_gemm4_i<EPI, NORM, 0, 4>(a, K, gx, s);
+  return rc;
 }
 
 // many row blocks (a prompt being teacher-forced): GEMM tiling instead of the register-resident GEMV loop

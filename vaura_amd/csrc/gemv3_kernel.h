@@ -794,8 +794,9 @@ struct G4Shape {
 template <int N>
 __device__ __forceinline__ void va_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// rb_off: first row block of this launch (a GEMM may be cut into two launches of different workgroup heights, gemv3.hip)
 template <int EPI, bool NORM, int WT, int RBW>
-__global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, int gx, int gy, int remap) {
+__global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, int gx, int gy, int remap, int rb_off) {
   using SH = G4Shape<WT, RBW>;
   constexpr int WH = SH::WH, PPW = SH::PPW, STB = SH::STB, NST = SH::NST;
   // waves WM x WN, RPW row blocks and T column tiles per wave: 64 rows = 1 x 8 waves of 4 x 2, 96 rows = 2 x 4 of 3 x 4, 128 rows = 2 x 4 of 4 x 4
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
     bx = blockIdx.x % gx;
     by = blockIdx.x / gx;
   }
-  const int rb0 = by * RBW, ct0 = bx * G4_CT;
+  const int rb0 = rb_off + by * RBW, ct0 = bx * G4_CT;
   const int KG = K / 32;
 
   // this wave's PPW pieces of a stage: piece p < XP = plane fragment (row block p / 2, plane p % 2), else weight fragment
