@@ -84,13 +84,13 @@ static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_
 }
 
 // LDS-DMA pipelined GEMM (gemm4_kernel): fp16-plane weights.  One launch over row blocks [rb_off, rb_off + n_rb).
-template <int EPI, bool NORM, int WT, int RBW>
+template <int EPI, bool NORM, int WT, int RBW, int CT = G4_CT>
 static int launch_gemm4_i(const Gemv3Args& a, int64_t K, int gx, int rb_off, int n_rb, hipStream_t s) {
-  using SH = G4Shape<WT, RBW>;
+  using SH = G4Shape<WT, RBW, CT>;
   static unsigned long long big = 0;
-  if (va_big_lds_once(reinterpret_cast<const void*>(gemm4_kernel<EPI, NORM, WT, RBW>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  if (va_big_lds_once(reinterpret_cast<const void*>(gemm4_kernel<EPI, NORM, WT, RBW, CT>), SH::LDS, &big)) return VAURA_ERR_STATE;
   const int gy = (n_rb + RBW - 1) / RBW;
-  VA_LAUNCH((gemm4_kernel<EPI, NORM, WT, RBW>), dim3((unsigned)(gx * gy)), dim3(G4_NW * 64), SH::LDS, s, a, (int)K, gx, gy,
+  VA_LAUNCH((gemm4_kernel<EPI, NORM, WT, RBW, CT>), dim3((unsigned)(gx * gy)), dim3(G4_NW * 64), SH::LDS, s, a, (int)K, gx, gy,
             ((va_debug_flags & 0x8000u) ? 0 : 1) | ((va_debug_flags >> 17) & 6),      // bits 18, 19: ablations (no DMA / no products)
             rb_off);
   return 0;
@@ -132,6 +132,9 @@ static int launch_gemm4(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_
     }
   }
   int rc;
+  // two planes, 64-row workgroups chosen (few column tiles): the same number of 128 x 128 workgroups instead (debug flag bit 23: no)
+  if (a.wq == 2 && h1 == 4 && !h2 && !(va_debug_flags & (0x800000u | 32u)))
+    return launch_gemm4_i<EPI, NORM, 2, 8, 8>(a, K, 2 * gx, 0, a.R, s);
   if (a.wq == 2) {
     rc = launch_gemm4_h<EPI, NORM, 2>(a, K, gx, h1, 0, h2 ? cut : a.R, s);
     if (!rc && h2) rc = launch_gemm4_h<EPI, NORM, 2>(a, K, gx, h2, cut, a.R - cut, s);

@@ -776,10 +776,13 @@ __global__ __launch_bounds__(G3M_NW * 64) void gemm3_kernel(Gemv3Args a, int K, 
 #ifndef G4_SCHED
 #define G4_SCHED 1
 #endif
-template <int WT, int RBW>
+// CT = column tiles per workgroup: 16 (256 columns) or 8 (128 columns: with two weight planes a 128 x 128 workgroup stages 32 KB per
+// k-group where 64 x 256 stages 40 KB, and four stages fit — the instances for wo / w2, whose 6 x 256 columns give too few workgroups
+// for 128 rows)
+template <int WT, int RBW, int CT = G4_CT>
 struct G4Shape {
   static constexpr int WH = WT == 2 ? 2 : 1;
-  static constexpr int XP = RBW * VA_NPL, WP = G4_CT * WH;          // DMA pieces (1 KB) per stage
+  static constexpr int XP = RBW * VA_NPL, WP = CT * WH;             // DMA pieces (1 KB) per stage
   // per wave: every wave issues the same number (the counted vmcnt waits are compile-time), so with 96 rows (28 / 44 pieces) the
   // last slots repeat the stage's first pieces — the same bytes to the same LDS address a second time
   static constexpr int PPW = (XP + WP + G4_NW - 1) / G4_NW;
@@ -787,7 +790,7 @@ struct G4Shape {
   // stages: a k-group's stage is read during its own step and the one before, so NST stages leave NST - 2 k-steps between a
   // piece's issue and the barrier that needs it.  Four where they fit in 160 KB without costing a co-resident workgroup
   // (one weight plane, 128 rows: 128 KB); else three (two planes x 128 rows: 144 KB; one plane x 64 rows: 72 KB, two per CU)
-  static constexpr int NST = (WT == 0 && RBW >= 6) ? 4 : 3;
+  static constexpr int NST = (CT == 8 || (WT == 0 && RBW >= 6)) ? 4 : 3;
   static constexpr int LDS = NST * STB + 4 * RBW * 16 * 4;          // + four partial sums of squares per row of the workgroup
 };
 
@@ -795,12 +798,13 @@ template <int N>
 __device__ __forceinline__ void va_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // rb_off: first row block of this launch (a GEMM may be cut into two launches of different workgroup heights, gemv3.hip)
-template <int EPI, bool NORM, int WT, int RBW>
+template <int EPI, bool NORM, int WT, int RBW, int CT = G4_CT>
 __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, int gx, int gy, int remap, int rb_off) {
-  using SH = G4Shape<WT, RBW>;
+  using SH = G4Shape<WT, RBW, CT>;
   constexpr int WH = SH::WH, PPW = SH::PPW, STB = SH::STB, NST = SH::NST;
   // waves WM x WN, RPW row blocks and T column tiles per wave: 64 rows = 1 x 8 waves of 4 x 2, 96 rows = 2 x 4 of 3 x 4, 128 rows = 2 x 4 of 4 x 4
-  constexpr int WM = RBW == 4 ? 1 : 2, RPW = RBW / WM, WN = G4_NW / WM, T = G4_CT / WN, NACC = 2;
+  constexpr int WM = RBW == 4 ? 1 : 2, RPW = RBW / WM, WN = G4_NW / WM, T = CT / WN, NACC = 2;
+  static_assert(CT % WN == 0 && (T * WH) % 2 == 0, "whole column tiles per wave, weight fragments in two halves");
   static_assert(WT == 0 || WT == 2, "fp16-plane weights (fp8 tile pairs keep gemm3_kernel)");
   static_assert(RBW == 4 || RBW == 6 || RBW == 8, "64, 96 or 128 rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char g4_lds[];      // the ONE LDS object of this kernel (ring + rinv)
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(G4_NW * 64) void gemm4_kernel(Gemv3Args a, int K, i
     bx = blockIdx.x % gx;
     by = blockIdx.x / gx;
   }
-  const int rb0 = rb_off + by * RBW, ct0 = bx * G4_CT;
+  const int rb0 = rb_off + by * RBW, ct0 = bx * CT;
   const int KG = K / 32;
 
   // this wave's PPW pieces of a stage: piece p < XP = plane fragment (row block p / 2, plane p % 2), else weight fragment
