@@ -3,6 +3,7 @@
 //   VAURAModel._sample_next_token      models/vaura_model.py:775-827
 //   Transformer.inference              models/modules/sampler/llama.py:445-504
 //   TransformerBlock.forward           llama.py:272-283
+#include <cstdlib>
 #include "common.h"
 #include <algorithm>
 #include "gemv3_kernel.h"
@@ -213,9 +214,16 @@ static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sa
 }
 
 // one captured decode step; owned by the caller (one per decoder descriptor / sampling setup)
+// One captured decode step, and the same step captured `multi` times in a row (the position, the step counter and the noise index
+// live on the device, so every copy is the same list of launches): the loop replays the long graph while at least `multi` steps
+// remain — one graph launch (host call, packet-queue doorbell, start-of-graph work on the GPU) per `multi` steps instead of per step.
+#ifndef VA_GRAPH_STEPS
+#define VA_GRAPH_STEPS 4
+#endif
 struct StepGraph {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  hipGraph_t graph = nullptr, graphm = nullptr;
+  hipGraphExec_t exec = nullptr, execm = nullptr;
+  int multi = 1;
 };
 
 extern "C" {
@@ -249,6 +257,8 @@ void vaura_step_graph_free(vaura_step_graph_t g_) {
   if (!g) return;
   if (g->exec) (void)hipGraphExecDestroy(g->exec);
   if (g->graph) (void)hipGraphDestroy(g->graph);
+  if (g->execm) (void)hipGraphExecDestroy(g->execm);
+  if (g->graphm) (void)hipGraphDestroy(g->graphm);
   delete g;
 }
 
@@ -267,6 +277,18 @@ int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, v
   if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
   e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
   if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
+  const char* ms = getenv("VAURA_GRAPH_STEPS");
+  g->multi = ms ? atoi(ms) : VA_GRAPH_STEPS;
+  if (g->multi > 1) {
+    e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
+    for (int i = 0; i < g->multi && !rc; ++i) rc = enqueue_step(dec, sp, 1, st);
+    e = hipStreamEndCapture(st, &g->graphm);
+    if (rc) { vaura_step_graph_free(g); return rc; }
+    if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
+    e = hipGraphInstantiate(&g->execm, g->graphm, nullptr, nullptr, 0);
+    if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
+  }
   *out = g;
   return 0;
 }
@@ -298,7 +320,13 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
   if (graph) {
     StepGraph* g = static_cast<StepGraph*>(graph);
     if (!g->exec) return VAURA_ERR_STATE;
-    for (int i = 0; i < n_steps; ++i) {
+    int i = 0;
+    if (g->execm)
+      for (; i + g->multi <= n_steps; i += g->multi) {
+        hipError_t e = hipGraphLaunch(g->execm, st);
+        if (e != hipSuccess) return (int)e;
+      }
+    for (; i < n_steps; ++i) {
       hipError_t e = hipGraphLaunch(g->exec, st);
       if (e != hipSuccess) return (int)e;
     }
