@@ -511,6 +511,35 @@ def test_dac_decode_fp8_weights_against_oracle_on_dequantised_checkpoint():
     assert rms_model > 1e-4        # it IS a different model
 
 
+@pytest.mark.parametrize("precision", ["f16pair", "f16pair_w8", "f16"])
+def test_dac_decode_256_row_workgroups_are_bit_identical(precision):
+    """The codec's convs run in 256-row workgroups wherever enough of them remain (csrc/dac.hip, conv_pair_kernel<..., MJ = 8>):
+    only at full length, which the oracle-checked cases above (12 frames) never reach.  Same products summed in the same order,
+    so the waveform of a full-length decode must equal, bit for bit, the one from 128-row workgroups (debug flag bit 20) — the
+    instances the oracle pins.  Also the encoder's 64-column instances (codes identical)."""
+    from vaura_amd import _lib as L
+    from vaura_amd.engine import CodecEncoderEngine
+    ccfg = synth.FULL_CODEC
+    sd = dict(synth.codec_state_dict(ccfg, seed=1))
+    sd.update(synth.codec_encoder_state_dict(ccfg, seed=1))
+    codes = torch.randint(0, 1024, (4, 9, 220), generator=torch.Generator().manual_seed(5)).to(DEV)
+    dec = CodecEngine(ccfg, sd, DEV, precision=precision)
+    enc = CodecEncoderEngine(ccfg, sd, DEV) if precision == "f16pair" else None
+    out = {}
+    try:
+        for flags in (0, 1 << 20):
+            L.lib().vaura_set_debug_flags(flags)
+            wav = dec.decode(codes)
+            out[flags] = (wav.clone(), enc.encode(wav).clone() if enc else None)
+    finally:
+        L.lib().vaura_set_debug_flags(0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0][0]).all()
+    assert torch.equal(out[0][0], out[1 << 20][0])
+    if enc:
+        assert torch.equal(out[0][1], out[1 << 20][1])
+
+
 def test_dac_decode_block_scaled_fp8_against_its_emulation():
     """BASELINE configs[4], codec part on the fp8 matrix instruction (codec precision 3, csrc/dac.hip::conv_mx8_kernel): e4m3
     weights (per-output-channel power-of-two scale) AND e4m3 activations (one power-of-two scale per 32 channels of a row,
