@@ -176,6 +176,35 @@ def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
             assert rel_err(ssum, (got * got).sum(-1)) < 1e-5
 
 
+@pytest.mark.parametrize("K,N,epi,norm", [(1536, 8192, L.EPI_SWIGLU, True), (4096, 1536, L.EPI_RESID, False), (1536, 4608, L.EPI_STORE, True)])
+def test_prefill_gemm_tilings_are_bit_identical(K, N, epi, norm):
+    """The prefill GEMM picks a workgroup height per GEMM, cuts a GEMM into two launches, or uses 128 x 128 workgroups (gemv3.hip
+    launch_gemm4): every output element is the same sum of the same products in the same k order whatever the tiling, so a
+    prompt-sized GEMM must come out bit-identical with the choices forced off (debug flag bits 5, 22, 23)."""
+    rows = 2656
+    g = torch.Generator().manual_seed(K + N)
+    w = torch.randn(N, K, generator=g) * 0.02
+    x = torch.randn(rows, K, generator=g)
+    gain = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    n_out = N // 2 if epi == L.EPI_SWIGLU else N
+    res = ops.pack_rows(torch.randn(rows, n_out, generator=g).to(DEV)) if epi == L.EPI_RESID else None
+    xs, ss = ops.split_rows(ops.pack_rows(x.to(DEV)), rows, K, gain if norm else None, want_ss=norm)
+    wp = ops.pack_weight(w.to(DEV), L.W_H2)
+    outs = []
+    try:
+        for flags in (0, 1 << 22, 1 << 23, 32):
+            L.lib().vaura_set_debug_flags(flags)
+            out, osp, oss = ops.gemv_pair(wp, xs, rows, N, K, epi, ss_in=ss if norm else None, residual=res, want_split=True,
+                                          want_ss=epi == L.EPI_RESID, wdtype=L.W_H2)
+            outs.append((out.clone(), osp.clone(), None if oss is None else oss.clone()))
+    finally:
+        L.lib().vaura_set_debug_flags(0)
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        assert (o[2] is None and outs[0][2] is None) or torch.equal(o[2], outs[0][2])
+
+
 @pytest.mark.parametrize("rows", [16, 5, 40])
 def test_k_split_gemv_partials_add_up(rows):
     """Decode qkv instance: two workgroup sets over the two halves of K write two partial outputs which the consumer
