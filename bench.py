@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py — V-AURA generation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1 from a plain shell: starts its own N ranks; under
+                                                            torch.distributed.run it is one of them)
 
 One "step" = one pass of the hot path over one batch of synthetic clips on each GPU:
 video-feature MLP -> 228-step KV-cached decode loop (CFG + top-k sampling, delay pattern) ->
@@ -52,31 +53,37 @@ def decode_loop_bytes(cfg: synth.SamplerCfg, wbytes: int, rows: int, steps: int)
     return tot
 
 
-def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
-    """Oracle (CPU port of the reference path) on this box's host cores, bounded sample (~10-30 s).
-    `value`: the KV-cached port at the GPU's own batch (all `n_clips` clips, 2 rows each with CFG), measured over real
-    steps at the start and near the end of a clip (the per-step cost grows with the cache) — so that GPU/CPU is not just
-    the algorithmic gap.  `reference_algorithm_extrapolated`: the reference itself keeps no cache and re-feeds the whole
-    prefix every step (models/vaura_model.py:504-506); its cost is EXTRAPOLATED from the full-prefix forward of ONE clip
-    timed at four prefix lengths and integrated over the 228 steps (a full run is minutes per clip)."""
+def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips, top_k, quick=False):
+    """Oracle (CPU port of the reference path) on this box's host cores, as BASELINE.md §3 defines the baseline: real runs, no
+    extrapolation.
+      reference_faithful  ONE full run of the reference's own algorithm for one clip (configs[0] = C1: B=1, greedy, cfg 1): the whole
+                          prefix re-fed every step, logits for every position, no cache (models/vaura_model.py:504-506) — 228 passes
+                          of lengths 1..228 — plus the CPU DAC restatement's decode of its tokens: end to end, one run (flagged).
+      cached              the same clip through the K/V-cached port: 1 warm-up + 3 full runs, median.
+      value               the K/V-cached port at the GPU's OWN workload (all `n_clips` clips, CFG rows, top-k sampling): one full
+                          228-step run + the codec (one clip timed, x clips), so that GPU / CPU is not just the 114x algorithmic gap.
+    Thread counts are swept first (torch's default of one thread per core oversubscribes a 16-row GEMV 8x); `cores` = the
+    count the `value` run used.  `quick` (bench.py --quick-cpu-baseline): the round-3 bounded sample instead of full runs."""
+    from oracle import dac_oracle
+    from oracle import generate_oracle as go
     from oracle.decoder_oracle import CachedDecoder, DecoderOracle
     cfg = synth.FULL_SAMPLER
+    ccfg = synth.FULL_CODEC
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
     g = torch.Generator().manual_seed(0)
     n_steps = T_FRAMES + K_CB - 1
+    tokens_per_clip = K_CB * T_FRAMES
     with torch.no_grad():
         cond = feats_cpu[:n_clips]
-        cond = torch.cat([cond, dec.null_condition(cond)], 0) if cfg_scale > 1 else cond
-        rows = cond.shape[0]
-        cd = CachedDecoder(dec, cond, n_steps + 1)
+        cond_all = torch.cat([cond, dec.null_condition(cond)], 0) if cfg_scale > 1 else cond
+        rows = cond_all.shape[0]
+        cd = CachedDecoder(dec, cond_all, n_steps + 1)
         tok = torch.randint(0, 1024, (rows, K_CB), generator=g)
         cd.step(tok)                      # warm-up (allocations, thread pool)
-        # the host's best: torch's default (one thread per logical CPU) oversubscribes a 16-row GEMV; sweep and keep the fastest
         default_threads = torch.get_num_threads()
+        cand = [nt for nt in sorted({8, 16, 32, 64, max(1, default_threads // 2), default_threads}) if nt <= default_threads]
         sweep = {}
-        for nt in sorted({8, 16, 32, 64, max(1, default_threads // 2), default_threads}):
-            if nt > default_threads:      # torch's default = the physical cores; SMT siblings only oversubscribe (256 threads: 45 s per step)
-                continue
+        for nt in cand:                   # the GPU batch's decode step (16 rows)
             torch.set_num_threads(nt)
             cd.pos = 1
             cd.step(tok)
@@ -85,58 +92,91 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips):
                 cd.step(tok)
             sweep[nt] = (time.perf_counter() - t0) / 2
         best = min(sweep, key=sweep.get)
-        torch.set_num_threads(best)
-        cd.pos = 1
-        reps = 6
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            cd.step(tok)
-        t_early = (time.perf_counter() - t0) / reps
-        cd.pos = n_steps - reps - 1       # late steps: attention over ~220 cached positions (zeros: same work)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            cd.step(tok)
-        t_late = (time.perf_counter() - t0) / reps
-        cached_s = 0.5 * (t_early + t_late) * n_steps
-        cached_tok_s = n_clips * K_CB * T_FRAMES / cached_s
-        # the reference's cache-less algorithm, one clip
-        cond1 = cond[[0, n_clips]] if cfg_scale > 1 else cond[:1]
-        pts = [8, 64, 128, 228]
-        ts = []
-        for Lq in pts:
-            idx = torch.randint(0, 1024, (cond1.shape[0], K_CB, Lq), generator=g)
+        idx = torch.randint(0, 1024, (1, K_CB, 128), generator=g)
+        sweep_full = {}
+        for nt in cand:                   # the reference's cache-less pass (one clip, 128 positions)
+            torch.set_num_threads(nt)
+            dec.forward_full(idx[:, :, :8], cond[:1])
             t0 = time.perf_counter()
-            dec.forward_full(idx, cond1)
-            ts.append(time.perf_counter() - t0)
-        total = 0.0
-        xs = [1] + pts
-        ys = [ts[0]] + ts
-        for i in range(1, len(xs)):
-            total += 0.5 * (ys[i] + ys[i - 1]) * (xs[i] - xs[i - 1])
-    return {
-        "value": round(cached_tok_s, 2), "unit": "codec tokens/s", "cores": best, "kind": "port",
-        "thread_sweep_ms_per_step": {str(k): round(1e3 * v, 1) for k, v in sweep.items()},
-        "logical_cpus": os.cpu_count(), "torch_default_threads": default_threads,
-        "sample": (f"oracle/ fp32 torch-CPU port with a K/V cache, the GPU's batch ({n_clips} clips, rows={rows}, cfg {cfg_scale}): "
-                   f"{reps} steps at cache length ~1 ({t_early * 1e3:.0f} ms/step) and {reps} at ~{n_steps - reps} "
-                   f"({t_late * 1e3:.0f} ms/step), mean x {n_steps} steps = {cached_s:.1f} s per batch; decode loop only (codec excluded)"),
-        "reference_algorithm_extrapolated": {
-            "value": round(K_CB * T_FRAMES / total, 2), "unit": "codec tokens/s", "clips": 1,
-            "how": (f"cache-less full-prefix forward (what the reference runs every step) of ONE clip (rows={cond1.shape[0]}) timed at "
-                    f"L={pts} -> {['%.3f' % t for t in ts]} s, piecewise-linear integral over {n_steps} steps = {total:.1f} s per clip: "
-                    "an extrapolation, not a full run.  Calibration of the method (build container, 8 threads, BASELINE.md 2): the same "
-                    "integral over the reference's own timed forwards (L=1: 80 ms, 64: 403 ms, 228: 909 ms) gives 122.8 s per clip "
-                    "against 110.5 s for the full reference generate() run there: the extrapolation reads ~11 % slow")},
-    }
+            dec.forward_full(idx, cond[:1])
+            sweep_full[nt] = time.perf_counter() - t0
+        best_full = min(sweep_full, key=sweep_full.get)
+        out = {"unit": "codec tokens/s", "kind": "port", "logical_cpus": os.cpu_count(), "torch_default_threads": default_threads,
+               "thread_sweep_ms_per_step": {str(k): round(1e3 * v, 1) for k, v in sweep.items()},
+               "thread_sweep_ms_full_prefix_L128": {str(k): round(1e3 * v, 1) for k, v in sweep_full.items()}}
+        if quick:
+            torch.set_num_threads(best)
+            ts = []
+            for p0 in (1, n_steps - 7):
+                cd.pos = p0
+                t0 = time.perf_counter()
+                for _ in range(6):
+                    cd.step(tok)
+                ts.append((time.perf_counter() - t0) / 6)
+            cached_s = 0.5 * (ts[0] + ts[1]) * n_steps
+            out.update({"value": round(n_clips * tokens_per_clip / cached_s, 2), "cores": best,
+                        "sample": (f"QUICK: K/V-cached port at the GPU's batch ({n_clips} clips, rows={rows}): 6 steps at cache length ~1 "
+                                   f"({ts[0] * 1e3:.0f} ms/step) and 6 at ~{n_steps - 7} ({ts[1] * 1e3:.0f} ms/step), mean x {n_steps}; "
+                                   "decode loop only")})
+            return out
+        del cd
+        # ---- codec: the CPU DAC restatement on one clip's tokens
+        torch.set_num_threads(best_full)
+        csd = synth.codec_state_dict(ccfg, seed=0)
+        codes1 = torch.randint(0, 1024, (1, K_CB, T_FRAMES), generator=g)
+        dac_oracle.decode(csd, codes1[:, :, :8], ccfg.decoder_rates)
+        t0 = time.perf_counter()
+        dac_oracle.decode(csd, codes1, ccfg.decoder_rates)
+        codec_s = time.perf_counter() - t0
+        # ---- the reference's own algorithm, one clip, ONE full run (C1)
+        t0 = time.perf_counter()
+        tk_full = go.generate(dec, cond[:1], T_FRAMES, mode="full")
+        faithful_s = time.perf_counter() - t0
+        # ---- the same clip through the K/V-cached port: warm-up + 3 runs, median
+        torch.set_num_threads(best)
+        runs = []
+        for i in range(4):
+            t0 = time.perf_counter()
+            tk_c = go.generate(dec, cond[:1], T_FRAMES, mode="cached")
+            runs.append(time.perf_counter() - t0)
+        cached1 = sorted(runs[1:])[1]
+        same = bool(torch.equal(tk_full, tk_c))
+        # ---- the GPU's own workload through the K/V-cached port: ONE full run
+        nz = synth.exp_noise(n_steps, n_clips * K_CB, 1024, 1234)
+        t0 = time.perf_counter()
+        go.generate(dec, cond, T_FRAMES, mode="cached", cfg_scale=cfg_scale, use_sampling=True, temp=1.0, top_k=top_k, noise=nz)
+        cached_batch_s = time.perf_counter() - t0
+    wall = cached_batch_s + n_clips * codec_s
+    out.update({
+        "value": round(n_clips * tokens_per_clip / wall, 2), "cores": best,
+        "sample": (f"oracle/ fp32 torch-CPU port with a K/V cache on the GPU's own workload ({n_clips} clips, rows={rows}, cfg {cfg_scale}, "
+                   f"top-k {top_k}): ONE full {n_steps}-step run = {cached_batch_s:.1f} s on {best} threads, + the CPU DAC restatement "
+                   f"({codec_s:.2f} s for one clip on {best_full} threads, x {n_clips}) = {wall:.1f} s per batch, end to end"),
+        "decode_loop_only_tok_s": round(n_clips * tokens_per_clip / cached_batch_s, 2),
+        "codec_s": round(codec_s, 3),
+        "reference_faithful_s_per_clip": round(faithful_s, 2),
+        "reference_faithful": {
+            "what": ("the reference's algorithm as it is (models/vaura_model.py:502-547: whole prefix re-fed every step, no cache, logits for "
+                     f"every position), configs[0]: ONE clip, greedy, cfg 1.0, fp32, {best_full} threads — ONE full run of {n_steps} passes, "
+                     "not an extrapolation"),
+            "decode_loop_s": round(faithful_s, 2), "codec_s": round(codec_s, 3),
+            "tok_s_end_to_end": round(tokens_per_clip / (faithful_s + codec_s), 2), "threads": best_full, "runs": 1,
+            "tokens_equal_the_cached_port": same},
+        "cached_tok_s": round(tokens_per_clip / cached1, 2),
+        "cached": {"what": f"the same clip (configs[0]) through the K/V-cached port, {best} threads: 1 warm-up + 3 full runs, median",
+                   "runs_s": [round(r, 2) for r in runs[1:]], "median_s": round(cached1, 2),
+                   "tok_s_end_to_end": round(tokens_per_clip / (cached1 + codec_s), 2)},
+    })
+    return out
 
 
 def self_launch(n: int, argv) -> int:
     """Run this script as `n` ranks under torch.distributed.run (child processes) and return their exit status."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = vdist.count_gpus_without_hip()          # sysfs only: this parent never touches torch.cuda / HIP
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if have < n and env.get("VAURA_BENCH_SHARE_GPU") != "1":
+    if have is not None and have < n and env.get("VAURA_BENCH_SHARE_GPU") != "1":
         print(f"bench.py: --gpus {n} but this box has {have} GPU(s); set VAURA_BENCH_SHARE_GPU=1 VAURA_BENCH_BACKEND=gloo to exercise "
               "the control flow on shared GPUs (never a reported number)", file=sys.stderr)
         return 2
@@ -172,6 +212,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="experiment: codec + gather of batch i on a second stream (slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick-cpu-baseline", action="store_true",
+                    help="bounded 12-step sample of the K/V-cached CPU port instead of the full runs of BASELINE.md 3 (~2.5 min)")
     ap.add_argument("--no-second", "--no-f32", dest="no_second", action="store_true",
                     help="skip the second timed region (the bf16-representable checkpoint on one fp16 plane)")
     ap.add_argument("--no-plugin", action="store_true", help="skip timing VAURAModel.generate() through the plugin classes")
@@ -186,8 +228,9 @@ def main():
 
     # VAURA_BENCH_BACKEND=gloo + VAURA_BENCH_SHARE_GPU=1: exercise the multi-rank control flow on a 1-GPU box
     # (all ranks on cuda:0, collectives on host copies).  Never used for reported numbers.
-    rank, local, world = vdist.init(os.environ.get("VAURA_BENCH_BACKEND", "nccl"))
-    if os.environ.get("VAURA_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("VAURA_BENCH_SHARE_GPU") == "1"
+    rank, local, world = vdist.init(os.environ.get("VAURA_BENCH_BACKEND", "nccl"), device_index=0 if share else None)
+    if share:
         local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -259,10 +302,17 @@ def main():
         for _ in range(args.steps):
             res = fn()
         torch.cuda.synchronize(dev)
+        elapsed_local[0] = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
         vdist.barrier()
         return vdist.max_over_ranks(time.perf_counter() - t0, dev), res
 
+    elapsed_local = [0.0]
+
+    if world > 1:
+        args.no_extras = True            # N > 1: the timed region, its split and who took part — nothing else
     elapsed, (codes, wav) = timed(step)
+    seen = vdist.ranks_seen(dev)
+    per_rank_ms = vdist.gather_floats(1e3 * elapsed_local[0] / args.steps, dev)
     main_marks = marks[-args.steps:]
     t_loop = sum(a.elapsed_time(b) for a, b, _ in main_marks) / args.steps
     t_codec = sum(b.elapsed_time(c) for _, b, c in main_marks) / args.steps
@@ -299,7 +349,16 @@ def main():
                               else "one non-null HIP stream"},
         "sec_audio_per_sec": round(world * B * T_FRAMES * HOP / 44100.0 * args.steps / elapsed, 2),
         "value_storage": f"{storage} (weight_dtype={args.weights!r}) on the {'un-rounded (real-checkpoint-shaped)' if args.checkpoint == 'raw' else 'bf16-representable'} synthetic checkpoint",
+        "ranks_seen": len(seen), "ranks": seen, "ms_per_step_per_rank": [round(v, 3) for v in per_rank_ms],
+        "backend": (torch.distributed.get_backend() if world > 1 else None),
     }
+    if rank == 0 and world > 1:
+        # the split of the timed steps on rank 0 (HIP events inside them); per-kernel rooflines / plugin / CPU legs are N=1 work
+        lbN = decode_loop_bytes(cfg, wbytes, rows, T_FRAMES + K_CB - 1)
+        out["split_ms"] = {"decode_loop": round(t_loop, 3), "codec": round(t_codec, 3)}
+        out["decode_loop_roofline"] = {"bound": "hbm", "achieved": round(lbN / (t_loop * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(lbN / (t_loop * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes": lbN,
+                                       "per": "GPU (rank 0)"}
 
     # ---- the same job on the bf16-representable checkpoint, where "auto" resolves to ONE fp16 plane (half the weight bytes,
     #      same real numbers).  Every rank runs it (same barriers).
@@ -464,7 +523,7 @@ def main():
             torch.cuda.empty_cache()
 
         if world == 1 and not args.no_cpu_baseline and not long_ctx:
-            out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale, B)
+            out["cpu_baseline"] = cpu_baseline(sd, feats_cpu, args.cfg_scale, B, args.top_k, quick=args.quick_cpu_baseline)
             out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
 
     if os.environ.get("VAURA_BENCH_SHARE_GPU") == "1" and world > 1:

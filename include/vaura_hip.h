@@ -101,6 +101,8 @@ typedef struct vaura_sampling {
 } vaura_sampling;
 
 /* ---- everything one decode step touches.  All buffers are owned by the caller (torch tensors). */
+#define VAURA_STATUS_NONFINITE_LOGITS 1
+
 typedef struct vaura_decoder {
   vaura_dims dims;
   int32_t wdtype;          /* vaura_wdtype of the streamed matrices                */
@@ -127,7 +129,11 @@ typedef struct vaura_decoder {
   float*   kcache;           /* (n_layer, rows, n_head, max_len, head_dim) fp32, rotated keys */
   float*   vcache;           /* same shape                                          */
   int32_t* seq;              /* (B, K, S) pattern sequence, -1 = unknown            vaura_model.py:485-493 */
-  int32_t* state;            /* [0]=position of the token being fed, [1]=arrival counter, [2]=step index, [3] spare */
+  int32_t* state;            /* 8 words: [0]=position of the token being fed, [1]=arrival counter, [2]=step index, [3] sequence id,
+                                [4]=STATUS bits, sticky until the caller clears them (VAURA_STATUS_*): the sampler raises
+                                VAURA_STATUS_NONFINITE_LOGITS when a logit it is about to sample from is inf / NaN — which is
+                                where every overflow of the fp16-plane activation format ends up (|activation| > 65504 -> inf
+                                in the hi plane -> NaN in the residual stream).  [5..7] spare */
   const float* noise;        /* optional (n_steps, B*K, vocab) Exp(1) draws; NULL -> Philox */
 
   float* ws_h;               /* packed rows (rows x d_model) residual stream        */
@@ -199,7 +205,10 @@ int vaura_decode_step(const vaura_decoder* dec, const vaura_sampling* sp, int sa
  * positions then `n_steps` sampled ones, all enqueued back-to-back.  graph != NULL replays a captured single-step
  * hipGraph per position (the position lives in dec->state); NULL launches every kernel eagerly.
  * vaura_step_graph_build captures one step of (dec, sp) on `s` (not the legacy null stream) into a handle the caller
- * owns: it is valid for exactly the buffers / shapes / sampling parameters it was built from.   */
+ * owns: it is valid for exactly the buffers / shapes / sampling parameters it was built from.  The loop replays the step
+ * `m` at a time where at least m steps remain (one graph launch per m steps; m = 4, or bits 24..27 of vaura_set_debug_flags
+ * at build time, 1..16): that longer graph is captured — same (dec, sp), on `s` — by the first vaura_generate_loop call with
+ * n_steps >= m, so that call must use the dec / sp the handle was built from (it always must).  No process environment is read. */
 typedef void* vaura_step_graph_t;
 int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int n_prefill, int n_steps,
                         vaura_step_graph_t graph, vaura_stream_t s);
@@ -398,6 +407,10 @@ size_t vaura_avclip_workspace_bytes(const vaura_vit* v, int n_seg, int which);
  * per position instead of the MFMA kernel (tools/README.md lists every bit).
  * 0 = the product configuration.                                                          */
 void vaura_set_debug_flags(unsigned flags);
+/* Host-side launch counters for tests that must know WHICH kernel instance a call took (read-and-clear; single caller thread):
+ * 0 = codec conv launches on the 256-row workgroup instances (conv_pair_kernel<..., 8>, csrc/dac.hip) since the last read.
+ * Unknown `which` -> -1. */
+long long vaura_debug_counter(int which);
 
 const char* vaura_version(void);
 /* sizeof() of the descriptor structs as compiled into the library (0 dims, 1 layer_weights, 2 sampling, 3 decoder,

@@ -4,6 +4,8 @@
     python tests/golden/make_golden.py full_greedy   # 24-layer model, B=2, T=220, greedy   (~4 min)
     python tests/golden/make_golden.py full_sample   # 24-layer, B=2, cfg 6, top-k 250      (~8 min)
     python tests/golden/make_golden.py full_greedy_raw   # full_greedy on the UN-rounded checkpoint (~4 min)
+    python tests/golden/make_golden.py full_sample_raw   # UN-rounded checkpoint, B=2, cfg 6, top-k 250 sampled (~8 min)
+    python tests/golden/make_golden.py full_greedy_cfg6_raw   # UN-rounded checkpoint, B=2, cfg 6, greedy      (~8 min)
     python tests/golden/make_golden.py avclip        # Segment-AVCLIP extractor (row f2), reference classes, 1 + 4 segments (~1 min)
     python tests/golden/make_golden.py full_c4       # configs[3]: block_size 1024, Tv=128, B=1, T=880 (~30 min)
     python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
@@ -70,6 +72,14 @@ def gold_patterns():
         out[k + "_ridx"] = ridx.numpy().astype(np.int32)
         out[k + "_rmask"] = rmask.numpy()
         out[k + "_first"] = np.int64(pat.get_first_step_with_timesteps(Tp))
+        # revert_pattern_logits (train-time view of the logits, codebook_patterns.py:287-313): S - 1 output positions, NaN fill
+        S = seq.shape[-1]
+        lg = torch.randn(2, 3, 9, S - 1, generator=g)
+        lv, lidx, lmask = pat.revert_pattern_logits(lg, float("nan"))
+        out[k + "_lg"] = lg.numpy()
+        out[k + "_lg_rev"] = lv.numpy()
+        out[k + "_lg_idx"] = lidx.numpy().astype(np.int32)
+        out[k + "_lg_mask"] = lmask.numpy()
     save("patterns.npz", **out)
 
 
@@ -247,6 +257,65 @@ def gold_full_sample():
     print(f"reference generate(): {dt:.1f}s")
 
 
+def _cfg_run(name, B, cfg_scale, use_sampling, top_k, noise_seed):
+    """CFG generate() of the reference on the UN-rounded checkpoint (what a real fp32 V-AURA checkpoint looks like to the
+    storage decision: 'auto' -> two fp16 planes) with every step's [cond; null] last-position logits captured.  Recorded per
+    step, clip and codebook: the CFG-mixed top-1 / top-2 logit margin (greedy) or, for top-k sampling, the relative margin of
+    argmax(p / Exp(1)) over the kept set and the relative gap at the top-k threshold — the only places where a storage
+    format's logit error can change a token."""
+    model = _full_model(round_bf16=False)
+    feats = synth.video_features(B, seed=0)
+    store = []
+    h = _capture_logits(model, store)
+    if use_sampling:
+        torch.manual_seed(noise_seed)
+    t = time.time()
+    r = model.generate(frames=feats.reshape(B, 4, 8, 768), audio=None, max_new_tokens=220,
+                       return_sampled_indices=True, use_sampling=use_sampling, temp=1.0, top_k=top_k, top_p=0.0,
+                       prompt_is_encoded=True, cfg_scale=cfg_scale)
+    dt = time.time() - t
+    h.remove()
+    tok = r["sampled_indices"].numpy()
+    noise = synth.exp_noise(len(store), B * 9, 1024, noise_seed) if use_sampling else None
+    margins, thr_gap = [], []
+    for i, (L, lg) in enumerate(store):
+        assert lg.shape[0] == 2 * B
+        c, u = lg[:B], lg[B:]
+        mixed = u + (c - u) * cfg_scale                                   # vaura_model.py:810-813
+        if not use_sampling:
+            top2 = torch.topk(mixed, 2, dim=-1).values
+            margins.append((top2[..., 0] - top2[..., 1]).numpy())
+            continue
+        p = torch.softmax(mixed, -1)
+        srt = torch.sort(p, dim=-1, descending=True).values
+        thr = srt[..., top_k - 1:top_k]
+        thr_gap.append(((srt[..., top_k - 1] - srt[..., top_k]) / srt[..., top_k - 1]).numpy())
+        kept = torch.where(p >= thr, p, torch.zeros_like(p))
+        ratio = kept / noise[i].reshape(B, 9, 1024)
+        top2 = torch.topk(ratio, 2, dim=-1).values
+        margins.append(((top2[..., 0] - top2[..., 1]) / top2[..., 0]).numpy())
+    extra = {}
+    if use_sampling:
+        extra = dict(noise_seed=np.int64(noise_seed), threshold_rel_gap=np.stack(thr_gap).astype(np.float32))
+    keep = [1, 9, 10, 100, 228]
+    logits = {L: lg for (L, lg) in store}
+    save(name, tokens=tok.astype(np.int16), sha1=np.array(sha1(tok.astype(np.int16))),
+         margins=np.stack(margins).astype(np.float32), logits_steps=np.array(keep),
+         logits=np.stack([logits[L].numpy() for L in keep]), cfg_scale=np.float64(cfg_scale), top_k=np.int64(top_k),
+         ref_seconds=np.float64(dt), weight_seed=np.int64(0), feat_seed=np.int64(0), round_bf16=np.int64(0), **extra)
+    print(f"reference generate(): {dt:.1f}s  min margin {np.stack(margins).min():.3e}")
+
+
+def gold_full_sample_raw():
+    """The headline configuration's arithmetic (configs/generate_vgg.yaml:23-27 sampling with configs[1]'s top-k): un-rounded
+    checkpoint, cfg 6, top-k 250 sampled, B=2, the reference's own noise stream."""
+    _cfg_run("full_topk250_cfg6_raw_B2_T220.npz", 2, 6.0, True, 250, 2025)
+
+
+def gold_full_greedy_cfg6_raw():
+    _cfg_run("full_greedy_cfg6_raw_B2_T220.npz", 2, 6.0, False, 0, 0)
+
+
 # ------------------------------------------------------------------------------------- codec
 def gold_codec(full: bool = False):
     """DAC decode golden from transformers' independent DacModel (NOT the reference's dependency:
@@ -418,6 +487,10 @@ if __name__ == "__main__":
         gold_avclip()
     elif what == "full_sample":
         gold_full_sample()
+    elif what == "full_sample_raw":
+        gold_full_sample_raw()
+    elif what == "full_greedy_cfg6_raw":
+        gold_full_greedy_cfg6_raw()
     elif what == "codec":
         gold_codec()
     elif what == "codec_full":

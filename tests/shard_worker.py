@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--frames", type=int, default=24)
     a = ap.parse_args()
-    rank, local, world = vdist.init(os.environ.get("VAURA_BENCH_BACKEND", "nccl"))
-    if os.environ.get("VAURA_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("VAURA_BENCH_SHARE_GPU") == "1"
+    rank, local, world = vdist.init(os.environ.get("VAURA_BENCH_BACKEND", "nccl"), device_index=0 if share else None)
+    if share:
         local = 0
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)

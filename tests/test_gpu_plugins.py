@@ -242,3 +242,35 @@ def test_reference_host_call_pattern_is_served_from_a_cache(tiny_sampler_sd, gol
     assert eng.cached_forward_steps == 5 and float((short - full[:, :, :5]).abs().max()) < 1e-5
     other, _, _ = s(tgt=seq[..., :6], memory=feats * 1.5)
     assert eng.cached_forward_steps == 11 and float((other[:, :, :5] - full[:, :, :5]).abs().max()) > 1e-4
+
+
+def test_full_depth_generate_through_the_plugin_surface_matches_reference(golden, full_sampler_sd_raw):
+    """ONE full-depth VAURAModel.generate() through the plugin classes (the call scripts/generate.py:311-324 makes) on the
+    un-rounded checkpoint, cfg 6, top-k 250, seeded like the reference run (noise_mode='torch_cpu' consumes torch's global CPU
+    generator exactly as utils.multinomial does): sampled_indices == the reference's own generate() output
+    (make_golden.py full_sample_raw), waveform of the right shape and finite.  weight_dtype stays the plugin default ("auto" -> h2)."""
+    from vaura_amd.model import VAURAModel
+    from parity_helpers import assert_cfg_tokens_or_recorded_near_tie
+    g = golden("full_topk250_cfg6_raw_B2_T220.npz")
+    cfg = synth.FULL_SAMPLER
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = VAURAModel(
+            feature_extractor_config={"target": "vaura_amd.feature_extractor.MotionFormer"},
+            audio_encoder_config={"target": "vaura_amd.codec.DacModelWrapper", "params": {"model_sr": 44100, "synthetic": True}},
+            sampler_config={"target": "vaura_amd.sampler.Transformer", "params": cfg.yaml_params()},
+            visual_bridge_config={"target": "torch.nn.Identity"},
+            pattern_provider_config={"target": "vaura_amd.patterns.DelayedPatternProvider", "params": {"n_q": 9}},
+            flatten_vis_feats=True, freeze_feature_extractor=True, noise_mode="torch_cpu")
+    m.sampler.load_state_dict(full_sampler_sd_raw, strict=True)
+    m.sampler.audio_tokens_per_video_frame = 7
+    m = m.to(DEV)
+    frames = synth.video_features(2, seed=int(g["feat_seed"])).reshape(2, 4, 8, 768).to(DEV)
+    torch.manual_seed(int(g["noise_seed"]))
+    r = m.generate(frames=frames, audio=None, max_new_tokens=220, return_sampled_indices=True, use_sampling=True, temp=1.0,
+                   top_k=int(g["top_k"]), top_p=0.0, prompt_is_encoded=True, cfg_scale=float(g["cfg_scale"]))
+    assert m.sampler.resolved_weight_dtype == "h2"
+    tok = r["sampled_indices"].cpu()
+    assert_cfg_tokens_or_recorded_near_tie(tok, _ref(g, "tokens"), g["margins"], 5e-4, "plugin surface, full depth",
+                                           g["threshold_rel_gap"])
+    assert r["generated_audio"].shape == (2, 1, 220 * 512) and bool(torch.isfinite(r["generated_audio"]).all())

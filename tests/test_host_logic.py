@@ -110,6 +110,10 @@ def test_pattern_metadata_matches_reference(golden, T, Tp):
     assert pat.get_first_step_with_timesteps(Tp) == int(g[k + "_first"])
     with pytest.raises(L.VauraHipError):
         pat.build_pattern_sequence(torch.zeros(1, 9, T, dtype=torch.long), 1024)
+    # revert_pattern_logits (codebook_patterns.py:287-313, the training loss's view): values incl. the NaN fill, indexes, mask
+    lv, lidx, lmask = pat.revert_pattern_logits(torch.from_numpy(g[k + "_lg"]), float("nan"))
+    assert np.array_equal(lidx.numpy(), g[k + "_lg_idx"]) and np.array_equal(lmask.numpy(), g[k + "_lg_mask"])
+    assert np.array_equal(lv.numpy(), g[k + "_lg_rev"], equal_nan=True)
 
 
 def test_feature_extractor_plugin_surface():

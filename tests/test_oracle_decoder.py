@@ -129,3 +129,26 @@ def test_configs3_golden_first_frames(golden):
         if int(L) in trace["logits"] and int(L) <= 10:
             assert (trace["logits"][int(L)] - torch.from_numpy(ref)).abs().max() < 5e-5
     assert g["tokens"].shape == (1, 9, 880) and float(g["margins"].min()) > 0
+
+
+@pytest.mark.slow
+def test_headline_configuration_golden_first_frames(golden, full_sampler_sd_raw):
+    """The reference's run of the HEADLINE configuration's arithmetic (make_golden.py full_sample_raw: un-rounded checkpoint, cfg 6,
+    top-k 250 sampled with torch's CPU noise stream, B=2): the cached oracle reproduces the recorded first-forward logits (after the
+    CFG mix) and the first 12 frames of tokens (bounded: the whole run at B=8 is the GPU suite's job)."""
+    g = golden("full_topk250_cfg6_raw_B2_T220.npz")
+    cfg = synth.FULL_SAMPLER
+    dec = DecoderOracle(full_sampler_sd_raw, cfg.num_layers, cfg.nhead)
+    feats = synth.video_features(2, seed=int(g["feat_seed"]))
+    nz = synth.exp_noise(29, 18, 1024, int(g["noise_seed"]))            # the first 29 draws of the 228-step stream
+    trace = {}
+    tok = go.generate(dec, feats, 21, mode="cached", cfg_scale=float(g["cfg_scale"]), use_sampling=True, temp=1.0,
+                      top_k=int(g["top_k"]), noise=nz, trace=trace)
+    assert torch.equal(tok[..., :12], torch.from_numpy(g["tokens"].astype(np.int64))[..., :12])
+    s = float(g["cfg_scale"])
+    for L, ref in zip(g["logits_steps"], g["logits"]):
+        if int(L) in trace["logits"] and int(L) <= 10:
+            r = torch.from_numpy(ref)
+            mixed = r[2:] + (r[:2] - r[2:]) * s
+            assert (trace["logits"][int(L)] - mixed).abs().max() < 5e-4
+    assert g["tokens"].shape == (2, 9, 220) and g["margins"].shape == (228, 2, 9) and float(g["margins"].min()) > 1e-5

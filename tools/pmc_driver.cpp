@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
   d.kcache = dev_f32((size_t)NL * rows * H * ML * 96, 0.5f); d.vcache = dev_f32((size_t)NL * rows * H * ML * 96, 0.5f);
   int32_t* seq; CK(hipMalloc(&seq, (size_t)batch * K * S * 4)); fill_i32<<<64, 256>>>(seq, (size_t)batch * K * S, 7);
   d.seq = seq;
-  d.state = dev_zero<int32_t>(4);
+  d.state = dev_zero<int32_t>(8);
   d.noise = nullptr;
   d.ws_h = dev_zero<float>((size_t)rp * D); d.ws_qkv = dev_zero<float>((size_t)rp * 3 * D); d.ws_qkv2 = dev_zero<float>((size_t)rp * 3 * D);
   d.ws_attn = dev_zero<float>((size_t)rp * D); d.ws_ffn = dev_zero<float>((size_t)rp * F); d.ws_logits = dev_zero<float>((size_t)rows * K * V);
@@ -169,7 +169,7 @@ int main(int argc, char** argv) {
       e.cond_proj = dev_f32((size_t)((crow * Tv + 15) / 16 * 16) * 512, 0.3f);
       e.kcache = dev_f32((size_t)NL * crow * H * ML * 96, 0.5f); e.vcache = dev_f32((size_t)NL * crow * H * ML * 96, 0.5f);
       int32_t* sq; CK(hipMalloc(&sq, (size_t)cb * K * S * 4)); fill_i32<<<64, 256>>>(sq, (size_t)cb * K * S, 7);
-      e.seq = sq; e.state = dev_zero<int32_t>(4);
+      e.seq = sq; e.state = dev_zero<int32_t>(8);
       e.ws_h = dev_zero<float>((size_t)crp * D); e.ws_qkv = dev_zero<float>((size_t)crp * 3 * D); e.ws_qkv2 = dev_zero<float>((size_t)crp * 3 * D);
       e.ws_attn = dev_zero<float>((size_t)crp * D); e.ws_ffn = dev_zero<float>((size_t)crp * F); e.ws_logits = dev_zero<float>((size_t)crow * K * V);
       e.ws_h_split = dev_zero<uint16_t>((size_t)crp * 3 * D); e.ws_attn_split = dev_zero<uint16_t>((size_t)crp * 3 * D);

@@ -3,7 +3,6 @@
 //   VAURAModel._sample_next_token      models/vaura_model.py:775-827
 //   Transformer.inference              models/modules/sampler/llama.py:445-504
 //   TransformerBlock.forward           llama.py:272-283
-#include <cstdlib>
 #include "common.h"
 #include <algorithm>
 #include "gemv3_kernel.h"
@@ -226,6 +225,18 @@ struct StepGraph {
   int multi = 1;
 };
 
+static int build_multi(StepGraph* g, const vaura_decoder* dec, const vaura_sampling* sp, hipStream_t st) {
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return (int)e;
+  int rc = 0;
+  for (int i = 0; i < g->multi && !rc; ++i) rc = enqueue_step(dec, sp, 1, st);
+  e = hipStreamEndCapture(st, &g->graphm);
+  if (rc) return rc;
+  if (e != hipSuccess) return (int)e;
+  e = hipGraphInstantiate(&g->execm, g->graphm, nullptr, nullptr, 0);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 extern "C" {
 
 const char* vaura_version(void) { return "vaura_hip 0.1 (gfx950)"; }
@@ -277,18 +288,10 @@ int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, v
   if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
   e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
   if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
-  const char* ms = getenv("VAURA_GRAPH_STEPS");
-  g->multi = ms ? atoi(ms) : VA_GRAPH_STEPS;
-  if (g->multi > 1) {
-    e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
-    for (int i = 0; i < g->multi && !rc; ++i) rc = enqueue_step(dec, sp, 1, st);
-    e = hipStreamEndCapture(st, &g->graphm);
-    if (rc) { vaura_step_graph_free(g); return rc; }
-    if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
-    e = hipGraphInstantiate(&g->execm, g->graphm, nullptr, nullptr, 0);
-    if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
-  }
+  // steps per graph launch: bits 24..27 of vaura_set_debug_flags (0 = the default VA_GRAPH_STEPS), clamped to 1..16.  The long
+  // graph is captured lazily by the first vaura_generate_loop that has at least that many steps to run (build_multi).
+  const int req = (int)((va_debug_flags_get() >> 24) & 15u);
+  g->multi = req ? std::min(16, std::max(1, req)) : VA_GRAPH_STEPS;
   *out = g;
   return 0;
 }
@@ -321,6 +324,10 @@ int vaura_generate_loop(const vaura_decoder* dec, const vaura_sampling* sp, int 
     StepGraph* g = static_cast<StepGraph*>(graph);
     if (!g->exec) return VAURA_ERR_STATE;
     int i = 0;
+    if (!g->execm && g->multi > 1 && n_steps >= g->multi) {   // first loop long enough to use it: capture the multi-step graph now
+      rc = build_multi(g, dec, sp, st);
+      if (rc) return rc;
+    }
     if (g->execm)
       for (; i + g->multi <= n_steps; i += g->multi) {
         hipError_t e = hipGraphLaunch(g->execm, st);

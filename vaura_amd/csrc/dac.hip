@@ -781,6 +781,10 @@ __global__ __launch_bounds__(256) void act_convert_kernel(const float* __restric
   store_act_octet(out, out_scale, fmt, row, co, C, sv);
 }
 
+// host-side count of conv launches that took the 256-row workgroup instances (conv_pair_kernel<..., 8>): a test that claims to
+// check those instances against the oracle asserts that they were the ones launched (vaura_debug_counter(0); read-and-clear)
+static long long va_conv256_launches = 0;
+
 static int launch_conv(const vaura_conv& cv, const float* in, const float* res, const float* alpha, float* out_raw,
                        float* out_act, int B, int Lin, int pairs, hipStream_t s) {
   if (!cv.w || !cv.bias || (cv.cin % BK)) return VAURA_ERR_SHAPE;
@@ -818,9 +822,10 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
     }
     if (pairs == 4) {   // "f16": one matrix instruction per product (hi planes only)
       const int g256 = (p.jcount + 2 * BM - 1) / (2 * BM);
-      if (cv.cout % BN == 0 && !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / BN) * B * ph >= 384)
+      if (cv.cout % BN == 0 && !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / BN) * B * ph >= 384) {
+        ++va_conv256_launches;
         VA_LAUNCH((conv_pair_kernel<3, true, true, 8>), dim3(g256, cv.cout / BN, B * ph), dim3(256), 0, s, p);
-      else if (cv.cout % BN == 0) VA_LAUNCH((conv_pair_kernel<3, true, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
+      } else if (cv.cout % BN == 0) VA_LAUNCH((conv_pair_kernel<3, true, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
       else VA_LAUNCH((conv_pair_kernel<2, true, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
       return 0;
     }
@@ -829,6 +834,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       const int g256 = (p.jcount + 2 * BM - 1) / (2 * BM);
       const bool big = !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / BN) * B * ph >= 384;
       if (big) {
+        ++va_conv256_launches;
         if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true, false, 8>), dim3(g256, cv.cout / BN, B * ph), dim3(256), 0, s, p);
         else VA_LAUNCH((conv_pair_kernel<3, false, false, 8>), dim3(g256, cv.cout / BN, B * ph), dim3(256), 0, s, p);
       } else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / BN, B * ph), dim3(256), 0, s, p);
@@ -837,6 +843,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
       const int g256 = (p.jcount + 2 * BM - 1) / (2 * BM);
       const bool big = !(va_debug_flags_get() & 0x100000u) && (int64_t)g256 * (cv.cout / 64) * B * ph >= 384;
       if (big) {
+        ++va_conv256_launches;
         if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true, false, 8>), dim3(g256, cv.cout / 64, B * ph), dim3(256), 0, s, p);
         else VA_LAUNCH((conv_pair_kernel<2, false, false, 8>), dim3(g256, cv.cout / 64, B * ph), dim3(256), 0, s, p);
       } else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<2, true>), dim3((p.jcount + BM - 1) / BM, cv.cout / 64, B * ph), dim3(256), 0, s, p);
@@ -1133,6 +1140,13 @@ __global__ __launch_bounds__(256) void rvq_stage_kernel(float* __restrict__ resi
 }
 
 extern "C" {
+
+long long vaura_debug_counter(int which) {
+  if (which != 0) return -1;
+  const long long v = va_conv256_launches;
+  va_conv256_launches = 0;
+  return v;
+}
 
 size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T) {
   if (!c || B <= 0 || T <= 0) return 0;

@@ -189,6 +189,12 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = lu[j] + (x[j] - lu[j]) * a.cfg_scale;
   }
+  // Range guard of the fp16-plane activation format (gemv3_kernel.h split2): an activation beyond fp16's 65504 becomes inf in its
+  // hi plane, inf - inf = NaN in the lo plane, and from there NaN in the residual stream of that row for the rest of the clip —
+  // so EVERY overflow anywhere in the step (or in a teacher-forced prefix, through the K/V cache) arrives here as a non-finite
+  // logit.  Raise the sticky status bit the host checks after generate() instead of sampling from garbage.
+  if (a.state_rw && !(fabsf(x[0]) < INFINITY && fabsf(x[1]) < INFINITY && fabsf(x[2]) < INFINITY && fabsf(x[3]) < INFINITY))
+    __hip_atomic_fetch_or(&a.state_rw[4], VAURA_STATUS_NONFINITE_LOGITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   int token;
   if (!(a.use_sampling && a.temp > 0.0f)) {

@@ -21,14 +21,63 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend: str = "nccl") -> Tuple[int, int, int]:
+def init(backend: str = "nccl", device_index: int | None = None) -> Tuple[int, int, int]:
+    """Join the job's process group.  With the product backend ("nccl" = RCCL) the rank first binds its own GPU
+    (``device_index``, default LOCAL_RANK) and hands it to ``init_process_group(device_id=...)``: the communicator is then
+    created eagerly on that device instead of on whatever device the first collective happens to see."""
     rank, local, world = env_rank()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            idx = local if device_index is None else device_index
+            torch.cuda.set_device(idx)
+            kw["device_id"] = torch.device("cuda", idx)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world
+
+
+def count_gpus_without_hip() -> int | None:
+    """GPU agents of this node read from the KFD topology in sysfs — no HIP / torch.cuda call, so a launcher parent that must
+    not initialise the GPU before it spawns its ranks can still refuse an impossible --gpus N.  None when sysfs has no answer."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
+def ranks_seen(device) -> List[dict]:
+    """One all_gather over the job's backend of who took part: rank, local device index and device name of every rank
+    (the bench record carries it, so a reader can check that the collective really spanned N devices)."""
+    dev = torch.device(device)
+    me = {"rank": env_rank()[0], "device": str(dev), "name": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"}
+    if dev.type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        me["uuid"] = str(getattr(props, "uuid", ""))
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [me]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out
+
+
+def gather_floats(x: float, device) -> List[float]:
+    """The same scalar from every rank (per-rank timings of the bench record)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [x]
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
 
 
 def shard(total: int, rank: int, world: int) -> Tuple[int, int]:

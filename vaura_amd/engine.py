@@ -223,7 +223,7 @@ class DecoderEngine:
             self.kcache = torch.zeros(c.num_layers, rows, c.nhead, max_len, c.head_dim, **f32)
             self.vcache = torch.zeros_like(self.kcache)
             self.seq = torch.zeros(batch, K, S, dtype=torch.int32, device=self.dev)
-            self.state = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            self.state = torch.zeros(8, dtype=torch.int32, device=self.dev)   # include/vaura_hip.h: position, arrivals, step, id, STATUS, spare
             self.ws_h = torch.zeros(rp * c.d_model, **f32)
             self.ws_qkv = torch.zeros(rp * 3 * c.d_model, **f32)
             self.ws_qkv2 = torch.zeros(self._rows_padded(rows) * 3 * c.d_model, **f32)   # decode step only
@@ -360,8 +360,23 @@ class DecoderEngine:
         """position / arrivals / step back to 0; state[3] carries a sequence id (reserved for in-launch hand-off epochs)."""
         self._fc = None                       # position 0 again: a cached forward() prefix no longer matches the K/V cache
         DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x7FF
-        self.state.zero_()                                   # two tiny device fills: no host-device synchronisation
-        self.state[3:4].fill_(DecoderEngine._sequence_id)
+        self.state[:4].zero_()                               # two tiny device fills: no host-device synchronisation
+        self.state[3:4].fill_(DecoderEngine._sequence_id)    # state[4] (status bits) is sticky until check_status() reads it
+
+    def check_status(self):
+        """Read AND clear the sticky device status word (one host-device synchronisation; ``VAURAModel.generate`` folds it into
+        the reference's own post-condition checks, vaura_model.py:550-572).  Raises when the sampler met a non-finite logit:
+        with activations carried as (hi, lo) fp16 planes between kernels that is what an activation beyond fp16's range
+        (|x| > 65504: inf in the hi plane, NaN from then on in that row's residual stream) turns into — the tokens decoded
+        after it are garbage, so it is an error, not a result."""
+        st = int(self.state[4].item())
+        if st:
+            self.state[4:5].zero_()
+        if st & 1:
+            raise L.VauraHipError(
+                "decode loop: non-finite logits reached the sampler — an activation left the range of the fp16-plane format "
+                "(|x| > 65504 in the residual stream x next-norm gain, the SwiGLU output or the attention output) or the "
+                "checkpoint holds non-finite weights; weight_dtype='f32' keeps fp32 activations (exact-fp32-MFMA path)")
 
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T

@@ -228,6 +228,7 @@ class VAURAModel(nn.Module):
             top_k=top_k, top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed,
             clip_base=self.clip_base, tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
         # the reference's post-conditions (:550-572), checked once on the finished tensor
+        eng.check_status()        # non-finite logits anywhere in the loop (fp16-plane range guard): raises instead of returning garbage
         bad = (codes < 0) | (codes > self.sampler.d_codebook)
         assert not bool(bad.any()), "generated sequence is incomplete or out of range"
         if check:

@@ -62,6 +62,30 @@ class Pattern:
         idx = torch.where(mask, s + q * seq_steps, torch.full_like(s, self.n_q * seq_steps))
         return idx, mask
 
+    def _revert_logits_indexes(self, seq_steps: int, device) -> tp.Tuple[torch.Tensor, torch.Tensor]:
+        """Indexes of the model's OUTPUT positions (is_model_output=True, codebook_patterns.py:240-242): output position s predicts
+        sequence step s + 1, i.e. timestep t = s - d_q of codebook q."""
+        t = torch.arange(self.timesteps, device=device)[None, :]
+        d = torch.tensor(self.delays, device=device)[:, None]
+        q = torch.arange(self.n_q, device=device)[:, None]
+        s = t + d
+        mask = s < seq_steps
+        idx = torch.where(mask, s + q * seq_steps, torch.full_like(s, self.n_q * seq_steps))
+        return idx, mask
+
+    def revert_pattern_logits(self, logits: torch.Tensor, special_token: float, keep_only_valid_steps: bool = False):
+        """logits (B, card, K, S) on the pattern sequence -> (values (B, card, K, T), indexes (K, T), mask (K, T)) —
+        codebook_patterns.py:287-313 (the training loss's view of the logits, vaura_model.py:185-187).  A float gather with no
+        place on the decode path: plain torch indexing on whatever device the logits live on."""
+        assert not keep_only_valid_steps
+        B, card, K, S = logits.shape
+        assert K == self.n_q and S <= self.seq_steps - 1 + 1
+        idx, mask = self._revert_logits_indexes(S, logits.device)
+        flat = logits.reshape(B, card, -1)
+        flat = torch.cat([flat, torch.zeros_like(flat[:, :, :1]) + special_token], dim=-1)
+        values = flat[:, :, idx.view(-1)].view(B, card, K, idx.shape[-1])
+        return values, idx, mask
+
     # ------------------------------------------------------------------ values (device)
     def _check(self, x: torch.Tensor):
         if not x.is_cuda:
