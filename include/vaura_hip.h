@@ -102,6 +102,7 @@ typedef struct vaura_sampling {
 
 /* ---- everything one decode step touches.  All buffers are owned by the caller (torch tensors). */
 #define VAURA_STATUS_NONFINITE_LOGITS 1
+#define VAURA_STATUS_HANDOFF_TIMEOUT 2    /* a consumer of the one-launch MLP (csrc/mlp_engine.h) gave up waiting for its producers */
 
 typedef struct vaura_decoder {
   vaura_dims dims;
@@ -153,8 +154,8 @@ typedef struct vaura_decoder {
   const float* first_norm;   /* layers[0].attn_norm (device), gain applied by the embed kernel */
   float*    ws_attn_part;    /* optional (rows, n_head, 8, head_dim + 8): partials of the range-split attention used when
                                 rows*n_head < 256 and max_len > 256 (vaura_attention_splits); NULL -> never split       */
-  uint32_t* ws_sync;         /* reserved (NULL): round 2's experimental one-launch MLP used it for hand-off flags; that experiment was measured
-                                no faster than two launches (profiles/r02_ab_fused_mlp.txt) and removed in round 3                    */
+  uint32_t* ws_sync;         /* optional 256 words (zeroed once by the caller): producer flags of the one-launch MLP (csrc/mlp_engine.h: w1||w3 ->
+                                in-launch hand-off -> w2 with w2's weight stream running ahead of the hand-off).  NULL -> always two launches   */
 } vaura_decoder;
 
 /* -------------------------------------------------------------------------------------------

@@ -808,3 +808,37 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
     err = float((lg - lg_ref).abs().max())
     print(f"heavy-tailed rows, {wdtype}: logits max-abs error vs the oracle on the original checkpoint {err:.3e}")
     assert err < 3e-5 * max(1.0, float(lg_ref.abs().max())), err
+
+
+@pytest.mark.parametrize("wdtype", ["h2", "h1"])
+def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
+    """csrc/mlp_engine.h (debug flag bit 2): w1||w3 -> in-launch hand-off of the ffn planes -> w2 as ONE launch per layer, w2's
+    weights requested ahead of the hand-off.  Same products in the same order as the two-launch path: teacher-forced logits must be
+    BIT-identical, tokens (greedy + CFG, and Philox-sampled) identical, through the eager path and through the captured step graph,
+    and no consumer may have given up waiting (status word clean).  12 decoder rows = both row halves live (the eligible shape)."""
+    from vaura_amd import _lib as L
+    cfg = synth.tiny_sampler(3)
+    sd = synth.sampler_state_dict(cfg, seed=101, round_bf16=(wdtype == "h1"))
+    eng = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
+    feats = synth.video_features(6, seed=102).to(DEV)
+    idx = torch.randint(0, 1024, (12, 9, 20), generator=torch.Generator().manual_seed(103)).to(DEV)
+    f12 = synth.video_features(12, seed=104).to(DEV)
+    out = {}
+    try:
+        for flags in (0, 4):
+            L.lib().vaura_set_debug_flags(flags)
+            eng._free_graph()
+            out[flags] = (eng.logits_all_positions(idx, f12).clone(),
+                          eng.generate_codes(feats, 24, cfg_scale=6.0).clone(),
+                          eng.generate_codes(feats, 24, cfg_scale=6.0, use_sampling=True, top_k=250, seed=9).clone(),
+                          eng.generate_codes(feats, 24, cfg_scale=6.0, use_graph=False).clone())
+            eng.check_status()
+    finally:
+        L.lib().vaura_set_debug_flags(0)
+        eng._free_graph()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[4][0]).all()
+    assert torch.equal(out[0][0], out[4][0]), float((out[0][0] - out[4][0]).abs().max())
+    for i in (1, 2, 3):
+        assert torch.equal(out[0][i], out[4][i]), i
+    assert torch.equal(out[4][1], out[4][3])

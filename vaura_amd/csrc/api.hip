@@ -112,6 +112,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
   // K-split qkv (consumer-reduced): fewer than 16 row blocks (otherwise the GEMM tiling takes over)
   float* qkv2 = (d->ws_qkv2 && (rows + 15) / 16 < 16) ? d->ws_qkv2 : nullptr;
+  // debug flag bit 2: the MLP half of every layer as one launch (mlp_engine.h) where the shape is eligible
+  const bool mlp_engine = (va_debug_flags_get() & 4u) && va_mlp_engine_eligible(d);
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -132,14 +134,23 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
                          E3_RESID, false, s);
     PROF_A(VAURA_K_WO);
     if (rc) return rc;
+    const Gemv3Args a13 = g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F);
+    const Gemv3Args a2 = g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D);
+    if (mlp_engine) {
+      // ONE launch: w1||w3 + SwiGLU -> in-launch hand-off of the ffn planes -> w2 + residual, w2's weights requested ahead of the
+      // hand-off (csrc/mlp_engine.h); booked under w13 by the per-launch profiler
+      PROF_B(VAURA_K_W13);
+      rc = va_launch_mlp_engine(a13, a2, d->ws_sync, d->state, l, s);
+      PROF_A(VAURA_K_W13);
+      if (rc) return rc;
+      continue;
+    }
     PROF_B(VAURA_K_W13);   // ffn = silu(W1 x) * (W3 x), x = rmsnorm(h)                  llama.py:282, 177
-    rc = va_launch_gemv3(g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F), 2 * F, D,
-                         E3_SWIGLU, true, s);
+    rc = va_launch_gemv3(a13, 2 * F, D, E3_SWIGLU, true, s);
     PROF_A(VAURA_K_W13);
     if (rc) return rc;
     PROF_B(VAURA_K_W2);    // h += W2.ffn ; emit split(h * next attention_norm) + ss     llama.py:177, 282
-    rc = va_launch_gemv3(g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D), D, F,
-                         E3_RESID, false, s);
+    rc = va_launch_gemv3(a2, D, F, E3_RESID, false, s);
     PROF_A(VAURA_K_W2);
     if (rc) return rc;
   }

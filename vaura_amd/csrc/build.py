@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac.hip", "post.hip", "vit.hip"]
-HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", os.path.join("..", "..", "include", "vaura_hip.h")]
+HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", "mlp_engine.h", os.path.join("..", "..", "include", "vaura_hip.h")]
 LIB = os.path.join(HERE, "libvaura_hip.so")
 # diagnostic build (--stamps): the same sources with -DVAURA_STAMPS (in-kernel s_memrealtime stamps, common.h); never loaded by the
 # package, only by tools/pmc_driver --stamps

@@ -1,5 +1,6 @@
 // Launcher of the fp16-pair GEMV (gemv3_kernel.h): the decode-step instances, weight ingress, op-level entry points.
 #include "gemv3_kernel.h"
+#include "mlp_engine.h"
 #include <cstdlib>
 
 // measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split),
@@ -187,6 +188,45 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   if (a.wq == 1) return dispatch3<1>(a, tiles, K, epilogue, norm, s);
   if (a.wq == 2) return dispatch3<2>(a, tiles, K, epilogue, norm, s);
   return dispatch3<0>(a, tiles, K, epilogue, norm, s);
+}
+
+// ---------------------------------------------------------------------------- the MLP half of a layer as one launch (mlp_engine.h)
+// Eligible: one row block with both row halves live (9..16 decoder rows), fp16-plane weights, the shipped geometry, hand-off flags
+// provided, a device with at least 256 CUs (every workgroup must be resident: consumers wait for producers inside the launch).
+bool va_mlp_engine_eligible(const vaura_decoder* d) {
+  if (!d->ws_sync || !d->state || d->rows <= 8 || d->rows > 16) return false;
+  if (d->wdtype != VAURA_W_H1 && d->wdtype != VAURA_W_H2) return false;
+  if (d->dims.d_model != 1536 || d->dims.ffn_dim != 4096) return false;
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    cus[dev] = n > 0 ? n : -1;
+  }
+  return cus[dev] >= 256;
+}
+
+template <int WT>
+static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
+  using SH = MlpEngineShape<WT>;
+  static unsigned long long big = 0;
+  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  VA_LAUNCH((mlp_engine_kernel<WT>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
+  return 0;
+}
+
+int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer, hipStream_t s) {
+  MlpEngineArgs e;
+  e.p1 = a13;
+  e.p2 = a2;
+  if (!a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || a13.R != 1 || a2.R != 1) return VAURA_ERR_ARG;
+  if (a13.wq != a2.wq || (a13.wq != 0 && a13.wq != 2) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 || a13.n_ss_in != 96) return VAURA_ERR_SHAPE;
+  e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
+  e.p2.wscale = weight_scales(a2, 1536, 4096);
+  e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
+  return a13.wq == 2 ? launch_mlp_engine_t<2>(e, s) : launch_mlp_engine_t<0>(e, s);
 }
 
 // ---------------------------------------------------------------------------- fp16-plane weight ingress

@@ -1,0 +1,310 @@
+// The MLP half of a decoder layer (llama.py:161-177, 282: h += w2( silu(w1 x) * (w3 x) ), x = rmsnorm(h)) as ONE persistent launch:
+//   phase 1   w1||w3 GEMV + SwiGLU  (the arithmetic of gemv3_kernel<6, 8, 2, E3_SWIGLU, NORM>: same products, same order)
+//   run-ahead every wave, as soon as its own phase-1 products are issued, requests its slice of w2's weights — half of it by
+//             LDS-DMA into a ring of 1-KiB fragments (no register destination: the registers still hold phase-1 state), the rest
+//             straight into the registers phase 1 has just released — so w2's weight stream runs under the SwiGLU epilogue, the
+//             hand-off and the planes' round trip instead of after a kernel boundary
+//   hand-off  the ffn planes (16 rows x 4096 columns x (hi, lo) fp16 = 262 KB) go from the 256 producing workgroups to the 192
+//             consuming ones inside the launch: write-through (sc0 sc1) stores, drained, ONE sc1 flag word per producer carrying
+//             an epoch (sequence id, position, layer: no reset between replays of a captured graph); one wave per consumer polls
+//             the 256 flags (bounded, with a give-up status bit), a workgroup barrier releases the others, and every load of the
+//             planes is an sc1 buffer load (MI355X_MICROARCH.md "Hand-offs measured with sc1 loads in place of the acquire", row 1)
+//   phase 2   w2 GEMV + residual + next norm's gain / partial sums of squares / planes (gemv3h_kernel<8, 8, E3_RESID>: same
+//             products, same order) on workgroups 0..191 = (tile, row half); workgroups 192..255 leave after publishing
+// Both phases sum exactly what the two-launch path sums, in its order: results are BIT-IDENTICAL to it (tests run every golden on
+// both).  One workgroup per CU (144 KB of LDS), 256 workgroups: the launcher refuses devices with fewer than 256 CUs, and the
+// hand-off wait is bounded — a consumer that gives up raises VAURA_STATUS_HANDOFF_TIMEOUT and later waits return at once.
+#pragma once
+#include "gemv3_kernel.h"
+
+struct MlpEngineArgs {
+  Gemv3Args p1;            // w1||w3: W, XP (h planes), ss_in, outp (ffn planes), N = ffn_dim, rows, R = 1, eps, k_total, wscale
+  Gemv3Args p2;            // w2: W, XP (= p1.outp), res / out (h), outp (h planes), gain_out, ss_out, N = d_model, wscale
+  uint32_t* flags;         // [256] producer flags
+  const int32_t* state;    // device state: [0] position, [3] sequence id, [4] status bits
+  int32_t* state_rw;
+  int layer;
+};
+
+#define MLPE_NW 8
+#define MLPE_SPIN_LIMIT 20000
+
+template <int WT>
+struct MlpEngineShape {
+  static constexpr int WH = WT == 2 ? 2 : 1;
+  static constexpr int G2 = 8;                         // k-group pairs per wave in phase 2 (K = 4096)
+  static constexpr int PL = WT == 2 ? 4 : 8;           // pairs per wave whose weights wait in LDS (the rest in registers)
+  static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB
+  static constexpr int RED = MLPE_NW * 2 * 64 * 16;    // reduction tiles (both phases)
+  static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 64;
+};
+
+__device__ __forceinline__ uint32_t mlpe_ld_sc1(const uint32_t* p) {
+  uint32_t v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int WT>
+__global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __restrict__ W13q, const uint16_t* __restrict__ XPq,
+                                                                  const void* __restrict__ W2q, MlpEngineArgs e) {
+  using SH = MlpEngineShape<WT>;
+  constexpr bool F32 = WT == 2;
+  constexpr int WH = SH::WH, NW = MLPE_NW, NACC = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char mlpe_lds[];
+  unsigned char* ring = mlpe_lds;
+  f32x4* red = reinterpret_cast<f32x4*>(mlpe_lds + NW * SH::WAVE_RING);            // [NW][2][64]
+  unsigned* arrive = reinterpret_cast<unsigned*>(mlpe_lds + NW * SH::WAVE_RING + SH::RED);
+
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bid = blockIdx.x;
+  // epoch of this hand-off: unique per (sequence, position, layer); the flags hold the previous hand-off's epoch until rewritten
+  const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)e.state[0] + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
+
+  // residual tile / next norm's gain of the phase-2 epilogue (written by the PREVIOUS kernel): requested first thing by the wave
+  // that will need them, landed long before anything waits
+  EpiPre pre;
+  pre.have = false;
+  if (bid < 192 && wid == 0) {
+    const int h2_ = (bid >> 3) & 1, tile2_ = (bid & 7) + 8 * (bid >> 4);
+    if (((lane >> 3) & 1) == h2_) pre = gemv3_epilogue_prefetch<E3_RESID>(e.p2, 0, tile2_, lane);
+  }
+
+  // ================================================================ phase 1: w1||w3 + SwiGLU (gemv3_kernel<6, 8, 2, E3_SWIGLU, true>)
+  {
+    Gemv3Args a = e.p1;
+    a.W = W13q;
+    a.XP = XPq;
+    constexpr int G = 6, T = 2, XB = F32 ? 3 : 1;
+    constexpr int K = 32 * G * NW, KG = K / 32, GB = G / XB;
+    constexpr bool WBATCH = F32 && XB > 1;
+    constexpr int GW = WBATCH ? 2 * GB : G;
+    constexpr int NSS = K / 64;
+    const int w = (wid + bid) % NW;
+    const int m = lane & 15, q = lane >> 4;
+    const int tile0 = bid * T;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * VA_NPL * (K / 8) * 256, 0x00020000);
+    const int lane16 = lane * 16;
+    u32x4 wb[T][GW][WH];
+    auto load_w = [&](int g0, int n, int slot0) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g < g0 || g >= g0 + n) continue;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+#pragma unroll
+          for (int hh = 0; hh < WH; ++hh)
+            wb[t][slot0 + g - g0][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+        }
+      }
+    };
+    constexpr int NXB = XB > 1 ? 2 : 1;
+    u32x4 xb[NXB][GB][VA_NPL];
+    auto load_x = [&](int b) {
+      const int xl16 = m < a.rows ? lane16 : 0x7ffffff0;
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int p = 0; p < VA_NPL; ++p)
+          xb[b % NXB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xl16, (int)((p * (K / 8) * 16 + (w * G + b * GB + g) * 64) * 16), 0);
+    };
+    if constexpr (WBATCH) load_w(0, GB, 0);
+    else load_w(0, G, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(0);
+    float ssv[NSS];                                    // n_ss_in == K / 16 == 4 NSS (checked by the launcher): no bounds to test
+    if (wid == 0) {
+      const float* sp = a.ss_in + m;
+#pragma unroll
+      for (int j = 0; j < NSS; ++j) ssv[j] = sp[(q + 4 * j) * 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // every request of the first batch is out before anything is waited for
+    f32x4 acc[T][NACC];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int p = 0; p < NACC; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < XB; ++b) {
+      if (b + 1 < XB) {
+        if constexpr (WBATCH) load_w((b + 1) * GB, GB, ((b + 1) & 1) * GB);
+        load_x(b + 1);
+      }
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          f16x8 wf[F32 ? 2 : 1];
+          if constexpr (F32) {
+            const int slot = WBATCH ? (b & 1) * GB + g : b * GB + g;
+            wf[0] = __builtin_bit_cast(f16x8, wb[t][slot][0]);
+            wf[1] = __builtin_bit_cast(f16x8, wb[t][slot][WH - 1]);
+          } else {
+            wf[0] = __builtin_bit_cast(f16x8, wb[t][b * GB + g][0]);
+          }
+          mfma_group<WT>(wf, xb[b % NXB][g], acc[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[(wid * T + t) * 64 + lane] = acc_sum<WT>(acc[t]);
+    // arrival words instead of a workgroup barrier: waves 1..7 go on to request their w2 slice at once; wave 0 alone waits for
+    // the tiles.  A wave's word carries this launch's epoch (LDS keeps what the previous launch on this CU left: its epoch, never
+    // this one), so nothing has to be initialised and no barrier opens the kernel.  LDS operations of a wave execute in order:
+    // the word lands behind the tiles.
+    if (lane == 0) __hip_atomic_store(arrive + wid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wid == 0) {
+      float ssp = 0.f;
+#pragma unroll
+      for (int j = 0; j < NSS; ++j) ssp += ssv[j];
+      ssp += va_xor16(ssp);
+      ssp += va_xor32(ssp);
+      const float rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+      for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) all &= __hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == epoch;
+        if (all) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      f32x4 v[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        f32x4 sacc = red[(0 * T + t) * 64 + lane];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) sacc += red[(i * T + t) * 64 + lane];
+        sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
+        v[t] = sacc * rinv;
+      }
+      gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
+      // publish: this wave stored the workgroup's whole ffn tile (write-through); drained, then the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + bid), "v"(epoch) : "memory");
+    }
+  }
+  if (bid >= 192) return;
+
+  // ================================================================ phase 2: w2 + residual (gemv3h_kernel<8, 8, E3_RESID>)
+  {
+    Gemv3Args a = e.p2;
+    a.W = W2q;
+    constexpr int G2 = SH::G2, PL = SH::PL;
+    constexpr int K = 64 * G2 * NW, KG = K / 32, BS = 1024 * WH;
+    const int h = (bid >> 3) & 1;
+    const int tile = (bid & 7) + 8 * (bid >> 4);
+    const int w = (wid + tile) % NW;
+    const int la = lane & 7, sb = (lane >> 3) & 1, q = lane >> 4;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * VA_NPL * (K / 8) * 256, 0x00020000);
+    const int voffw0 = (la + 16 * q) * 16 + sb * BS;
+    const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;
+    unsigned char* myring = ring + wid * SH::WAVE_RING;
+
+    // ---- run-ahead: this wave's w2 slice.  Pairs [0, PL): LDS-DMA, one 1-KiB fragment (k-group c, plane hh) per instruction;
+    //      pairs [PL, G2): straight into registers.  Waves 1..7 come here while wave 0 still reduces / publishes phase 1; wave 0 —
+    //      the wave that polls — requests its slice only behind the hand-off barrier: a wave's vector-memory counter retires in
+    //      order, so a poll behind its own 32 KB of weight requests would see the flags only once those have landed.
+    u32x4 wreg[G2 - PL > 0 ? G2 - PL : 1][2][WH];
+    auto prefetch_w2 = [&]() {
+      const unsigned char* src = static_cast<const unsigned char*>(a.W) + ((size_t)tile * KG + 2 * (size_t)(w * G2)) * BS + lane * 16;
+#pragma unroll
+      for (int c = 0; c < 2 * PL; ++c)
+#pragma unroll
+        for (int hh = 0; hh < WH; ++hh)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(c * WH + hh) * 1024),
+                                           (__attribute__((address_space(3))) void*)(myring + (c * WH + hh) * 1024), 16, 0, 2 /* nt */);
+#pragma unroll
+      for (int j = PL; j < G2; ++j) {
+        const int soff = (tile * KG + 2 * (w * G2 + j)) * BS;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int hh = 0; hh < WH; ++hh)
+            wreg[j - PL][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
+      }
+    };
+    if (wid != 0) prefetch_w2();
+
+    // ---- hand-off: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest
+    if (wid == 0) {
+      const bool broken = (mlpe_ld_sc1(reinterpret_cast<const uint32_t*>(e.state + 4)) & VAURA_STATUS_HANDOFF_TIMEOUT) != 0;
+      int spin = 0;
+      for (;;) {
+        u32x4 f;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(f) : "v"(e.flags + 4 * lane) : "memory");
+        const bool ok = f.x == epoch && f.y == epoch && f.z == epoch && f.w == epoch;
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull || broken) break;
+        if (++spin >= MLPE_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_fetch_or(e.state_rw + 4, VAURA_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    // raw barrier: __syncthreads() would first drain every wave's vector-memory counter — i.e. wait for the whole w2 prefetch —
+    // before anybody may request the planes.  Only control has to pass here: the planes are requested behind it in program order.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (wid == 0) prefetch_w2();
+
+    // ---- the planes of this workgroup's 8 rows over its wave's K slice: every load sc1 (the producers stored write-through)
+    u32x4 xb[G2][VA_NPL];
+    {
+      const int vx = la + 8 * h < a.rows ? voffx : 0x7ffffff0;
+#pragma unroll
+      for (int j = 0; j < G2; ++j)
+#pragma unroll
+        for (int p = 0; p < VA_NPL; ++p)
+          xb[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (p * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
+    }
+    __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
+    f32x4 acc[2][NACC];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < G2; ++j) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        f16x8 wf[F32 ? 2 : 1];
+        if (j < PL) {
+          const u32x4* fr = reinterpret_cast<const u32x4*>(myring + ((2 * j + sb) * WH) * 1024) + (la + 8 * nh + 16 * q);
+          wf[0] = __builtin_bit_cast(f16x8, fr[0]);
+          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, fr[64]);
+        } else {
+          wf[0] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][0]);
+          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][WH - 1]);
+        }
+        mfma_group<WT>(wf, xb[j], acc[nh]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const f32x4 v = acc_sum<WT>(acc[nh]);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = v[r];
+        o[r] = x + va_dpp<VA_DPP_ROR8>(va_xor32(x));
+      }
+      red[(wid * 2 + nh) * 64 + lane] = o;
+    }
+    __syncthreads();
+    if (wid == 0) {
+      const int m = lane & 15;
+      const bool mine = (m >> 3) == h;
+      const int src = (m & 7) + 16 * (q & 1);
+      f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
+#pragma unroll
+      for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
+      v *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);
+      if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
+    }
+  }
+}
