@@ -255,7 +255,8 @@ def main():
     # planes (22 significand bits) there.  `value_h1_lossless_checkpoint` is the same job on a bf16-representable checkpoint,
     # which one fp16 plane holds exactly (half the weight bytes).
     sd = synth.sampler_state_dict(cfg, seed=0, round_bf16=(args.checkpoint == "bf16repr"))
-    eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights)
+    one_launch = not share                   # ranks sharing ONE GPU (control-flow test only): the in-launch hand-off needs the chip to itself
+    eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights, one_launch_mlp=one_launch)
     storage = eng.wdtype                     # what "auto" resolved to
     if args.codec is None:
         args.codec = "f16pair_w8" if storage == "fp8" else "f16pair"
@@ -365,7 +366,7 @@ def main():
     if not args.no_extras and args.weights == "auto" and args.checkpoint == "raw" and not args.no_second:
         eng_main = eng
         sd_b = synth.sampler_state_dict(cfg, seed=0, round_bf16=True)
-        eng = DecoderEngine(cfg, sd_b, dev)                    # wdtype="auto"
+        eng = DecoderEngine(cfg, sd_b, dev, one_launch_mlp=one_launch)                    # wdtype="auto"
         assert eng.wdtype == "h1", eng.wdtype
         del sd_b
         el1, (codes1, wav1) = timed(step)

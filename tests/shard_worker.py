@@ -17,7 +17,8 @@ from vaura_amd.engine import CodecEngine, DecoderEngine  # noqa: E402
 
 def run(total, layers, T, first, n, dev):
     cfg = synth.tiny_sampler(layers)
-    eng = DecoderEngine(cfg, synth.sampler_state_dict(cfg, seed=21, round_bf16=True), dev, wdtype="bf16")
+    eng = DecoderEngine(cfg, synth.sampler_state_dict(cfg, seed=21, round_bf16=True), dev, wdtype="bf16",
+                        one_launch_mlp=os.environ.get("VAURA_BENCH_SHARE_GPU") != "1")      # ranks sharing ONE GPU: two launches
     ccfg = synth.FULL_CODEC
     codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=22), dev)
     feats = synth.video_features(n, seed=23, first_clip=first).to(dev)

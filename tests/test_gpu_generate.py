@@ -812,8 +812,8 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
 
 @pytest.mark.parametrize("wdtype", ["h2", "h1"])
 def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
-    """csrc/mlp_engine.h (debug flag bit 2): w1||w3 -> in-launch hand-off of the ffn planes -> w2 as ONE launch per layer, w2's
-    weights requested ahead of the hand-off.  Same products in the same order as the two-launch path: teacher-forced logits must be
+    """csrc/mlp_engine.h (the default where eligible; debug flag bit 2 = two launches): w1||w3 -> in-launch hand-off of the ffn planes
+    -> w2 as ONE launch per layer, w2's weights requested ahead of the hand-off.  Same products in the same order as the two-launch path: teacher-forced logits must be
     BIT-identical, tokens (greedy + CFG, and Philox-sampled) identical, through the eager path and through the captured step graph,
     and no consumer may have given up waiting (status word clean).  12 decoder rows = both row halves live (the eligible shape)."""
     from vaura_amd import _lib as L

@@ -112,8 +112,9 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   const size_t kv_layer = (size_t)rows * H * (size_t)d->max_len * hd;
   // K-split qkv (consumer-reduced): fewer than 16 row blocks (otherwise the GEMM tiling takes over)
   float* qkv2 = (d->ws_qkv2 && (rows + 15) / 16 < 16) ? d->ws_qkv2 : nullptr;
-  // debug flag bit 2: the MLP half of every layer as one launch (mlp_engine.h) where the shape is eligible
-  const bool mlp_engine = (va_debug_flags_get() & 4u) && va_mlp_engine_eligible(d);
+  // the MLP half of every layer as ONE launch (mlp_engine.h) where the shape is eligible and the caller provided the hand-off
+  // flags (dec->ws_sync); debug flag bit 2: two launches whatever the shape (the A/B, and the path every other shape takes)
+  const bool mlp_engine = !(va_debug_flags_get() & 4u) && va_mlp_engine_eligible(d);
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -234,13 +235,18 @@ struct StepGraph {
   hipGraph_t graph = nullptr, graphm = nullptr;
   hipGraphExec_t exec = nullptr, execm = nullptr;
   int multi = 1;
+  unsigned flags = 0;      // debug flags at build time: the lazily captured multi-step graph is the same variant
 };
 
+extern unsigned va_debug_flags;   // gemv3.hip
 static int build_multi(StepGraph* g, const vaura_decoder* dec, const vaura_sampling* sp, hipStream_t st) {
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return (int)e;
   int rc = 0;
+  const unsigned now = va_debug_flags;
+  va_debug_flags = g->flags;                        // the kernel variants of the handle, whatever the caller has set since
   for (int i = 0; i < g->multi && !rc; ++i) rc = enqueue_step(dec, sp, 1, st);
+  va_debug_flags = now;
   e = hipStreamEndCapture(st, &g->graphm);
   if (rc) return rc;
   if (e != hipSuccess) return (int)e;
@@ -301,7 +307,8 @@ int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, v
   if (e != hipSuccess) { vaura_step_graph_free(g); return (int)e; }
   // steps per graph launch: bits 24..27 of vaura_set_debug_flags (0 = the default VA_GRAPH_STEPS), clamped to 1..16.  The long
   // graph is captured lazily by the first vaura_generate_loop that has at least that many steps to run (build_multi).
-  const int req = (int)((va_debug_flags_get() >> 24) & 15u);
+  g->flags = va_debug_flags_get();
+  const int req = (int)((g->flags >> 24) & 15u);
   g->multi = req ? std::min(16, std::max(1, req)) : VA_GRAPH_STEPS;
   *out = g;
   return 0;

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 // measurement aid (vaura_set_debug_flags): bit 0 = keep the one-workgroup-per-tile kernels for wo / w2 (A/B of the row split),
+// bit 2 = w1||w3 and w2 as two launches even where the one-launch MLP (mlp_engine.h) is eligible, bits 28..31 = its timing ablations,
 // bit 4 = per-position prefill attention,
 // bit 5 = 64-row prefill GEMM workgroups only, bit 6 = row f2's linears on the 128 x 96 conv tile instead of linear_pair_kernel,
 // bit 7 = row f2's space attention with one thread per query instead of the MFMA kernel, bit 8 = 256-row tiles in
@@ -226,6 +227,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* fl
   e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
+  e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
   return a13.wq == 2 ? launch_mlp_engine_t<2>(e, s) : launch_mlp_engine_t<0>(e, s);
 }
 

@@ -287,6 +287,10 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
                                             xrs, xl16, (int)(((rb * VA_NPL + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
   };
 
+  // the power-of-two row scales of the epilogue waves' tiles: requested with the first row block's operands (round 4: they were a
+  // dependent L2 round trip BEHIND the reduction barrier of every GEMV: -0.2 .. -0.9 us per launch)
+  constexpr int EWN_ = (EPI == E3_SWIGLU) ? 1 : T, ET_ = (EPI == E3_SWIGLU) ? T : 1;
+  f32x4 wsc[ET_];
   auto row_block = [&](const int rb, const bool first) {
     if (first || WBATCH) {
       // all weight tiles first (HBM misses), then the planes (L2 hits)
@@ -326,6 +330,11 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
     pre.have = false;
     if constexpr (EPI == E3_RESID && T == 1) {
       if (wid == 0) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile0, lane);
+    }
+    if (first && wid < EWN_) {
+#pragma unroll
+      for (int e = 0; e < ET_; ++e)
+        wsc[e] = *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + ((EPI == E3_SWIGLU) ? e : wid)) * 16 + 4 * q);
     }
 
     f32x4 acc[T][NACC];
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         f32x4 sacc = red[0][t][lane];
 #pragma unroll
         for (int i = 1; i < NW; ++i) sacc += red[i][t][lane];
-        sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);   // power-of-two row scales: exact
+        sacc *= wsc[e];                                   // power-of-two row scales: exact
         v[e] = sacc * rinv;
       }
       gemv3_epilogue<ET, EPI>(a, rb, (EPI == E3_SWIGLU) ? tile0 : tile0 + wid, lane, v, &pre);
@@ -487,6 +496,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 
   u32x4 wb[NB][GB][2][WH];
   u32x4 xb[NB][GB][VA_NPL];
+  f32x4 wsc = f32x4{1.f, 1.f, 1.f, 1.f};
   auto load_w = [&](int b) {
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
@@ -519,6 +529,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
     EpiPre pre;
     pre.have = false;
     if (wid == 0 && ((lane >> 3) & 1) == h) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile, lane);
+    if (wid == 0 && rb == 0) wsc = *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);   // with the operands, not behind the barrier
 
     f32x4 acc[2][NACC];
 #pragma unroll
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
       f32x4 v = red[0][q >> 1][src];
 #pragma unroll
       for (int i = 1; i < NW; ++i) v += red[i][q >> 1][src];
-      v *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);     // power-of-two row scales: exact
+      v *= wsc;                                         // power-of-two row scales: exact
       if (mine) gemv3_epilogue<1, EPI>(a, rb, tile, lane, &v, &pre);
     }
 #ifdef VAURA_STAMPS

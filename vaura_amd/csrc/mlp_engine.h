@@ -24,6 +24,8 @@ struct MlpEngineArgs {
   const int32_t* state;    // device state: [0] position, [3] sequence id, [4] status bits
   int32_t* state_rw;
   int layer;
+  int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights
+                           // requested behind the hand-off barrier)
 };
 
 #define MLPE_NW 8
@@ -36,7 +38,7 @@ struct MlpEngineShape {
   static constexpr int PL = WT == 2 ? 4 : 8;           // pairs per wave whose weights wait in LDS (the rest in registers)
   static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB
   static constexpr int RED = MLPE_NW * 2 * 64 * 16;    // reduction tiles (both phases)
-  static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 64;
+  static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 64;      // + the arrival words
 };
 
 __device__ __forceinline__ uint32_t mlpe_ld_sc1(const uint32_t* p) {
@@ -69,6 +71,14 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   if (bid < 192 && wid == 0) {
     const int h2_ = (bid >> 3) & 1, tile2_ = (bid & 7) + 8 * (bid >> 4);
     if (((lane >> 3) & 1) == h2_) pre = gemv3_epilogue_prefetch<E3_RESID>(e.p2, 0, tile2_, lane);
+  }
+  // the power-of-two row scales of both epilogues too (a dependent L2 round trip behind the reduction otherwise)
+  f32x4 ws1[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}}, ws2 = f32x4{1.f, 1.f, 1.f, 1.f};
+  if (wid == 0) {
+    const int q_ = lane >> 4;
+    ws1[0] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2) * 16 + 4 * q_);
+    ws1[1] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2 + 1) * 16 + 4 * q_);
+    if (bid < 192) ws2 = *reinterpret_cast<const f32x4*>(e.p2.wscale + (size_t)((bid & 7) + 8 * (bid >> 4)) * 16 + 4 * q_);
   }
 
   // ================================================================ phase 1: w1||w3 + SwiGLU (gemv3_kernel<6, 8, 2, E3_SWIGLU, true>)
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         f32x4 sacc = red[(0 * T + t) * 64 + lane];
 #pragma unroll
         for (int i = 1; i < NW; ++i) sacc += red[(i * T + t) * 64 + lane];
-        sacc *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + t) * 16 + 4 * q);
+        sacc *= ws1[t];
         v[t] = sacc * rinv;
       }
       gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
@@ -205,9 +215,10 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     unsigned char* myring = ring + wid * SH::WAVE_RING;
 
     // ---- run-ahead: this wave's w2 slice.  Pairs [0, PL): LDS-DMA, one 1-KiB fragment (k-group c, plane hh) per instruction;
-    //      pairs [PL, G2): straight into registers.  Waves 1..7 come here while wave 0 still reduces / publishes phase 1; wave 0 —
-    //      the wave that polls — requests its slice only behind the hand-off barrier: a wave's vector-memory counter retires in
-    //      order, so a poll behind its own 32 KB of weight requests would see the flags only once those have landed.
+    //      pairs [PL, G2): straight into the registers phase 1 has just released.  Waves 1..7 come here while wave 0 still reduces
+    //      and publishes phase 1; wave 0 follows as soon as it has published — BEFORE it polls: its first poll then comes back
+    //      behind its own weight requests (a wave's vector-memory counter retires in order), which is about when the slowest
+    //      producer has published anyway, and nothing of the weight stream is left for after the hand-off.
     u32x4 wreg[G2 - PL > 0 ? G2 - PL : 1][2][WH];
     auto prefetch_w2 = [&]() {
       const unsigned char* src = static_cast<const unsigned char*>(a.W) + ((size_t)tile * KG + 2 * (size_t)(w * G2)) * BS + lane * 16;
@@ -227,7 +238,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
             wreg[j - PL][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
       }
     };
-    if (wid != 0) prefetch_w2();
+    if (!(e.abl & 4)) prefetch_w2();
 
     // ---- hand-off: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest
     if (wid == 0) {
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         u32x4 f;
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(f) : "v"(e.flags + 4 * lane) : "memory");
         const bool ok = f.x == epoch && f.y == epoch && f.z == epoch && f.w == epoch;
-        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull || broken) break;
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull || broken || (e.abl & 1)) break;
         if (++spin >= MLPE_SPIN_LIMIT) {
           if (lane == 0) __hip_atomic_fetch_or(e.state_rw + 4, VAURA_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           break;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // before anybody may request the planes.  Only control has to pass here: the planes are requested behind it in program order.
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (wid == 0) prefetch_w2();
+    if (e.abl & 4) prefetch_w2();
 
     // ---- the planes of this workgroup's 8 rows over its wave's K slice: every load sc1 (the producers stored write-through)
     u32x4 xb[G2][VA_NPL];
@@ -261,6 +272,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int p = 0; p < VA_NPL; ++p)
           xb[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (p * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
     }
+    __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
     __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
     f32x4 acc[2][NACC];
 #pragma unroll
@@ -303,7 +315,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
 #pragma unroll
       for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
-      v *= *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);
+      v *= ws2;
       if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
     }
   }

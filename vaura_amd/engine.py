@@ -124,8 +124,15 @@ def _require_cuda(dev: torch.device):
 class DecoderEngine:
     _sequence_id = 0
 
-    def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto"):
-        """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "f32" (``resolve_weight_dtype``)."""
+    def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
+                 one_launch_mlp: bool = True):
+        """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "f32" (``resolve_weight_dtype``).
+        one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
+        is eligible (9..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
+        decode loop).  Its consumers wait for producers of the SAME launch, so every workgroup must become resident: pass False
+        when several processes share this GPU (two such launches from two processes can starve each other until their bounded
+        waits give up — reported by ``check_status``, never silent)."""
+        self.one_launch_mlp = bool(one_launch_mlp)
         _require_cuda(device)
         self.cfg = cfg
         self.dev = torch.device(device)
@@ -266,7 +273,7 @@ class DecoderEngine:
             d.ws_h_split = d.ws_attn_split = d.ws_ffn_split = d.ws_ss = 0
         d.first_norm = self.layers[0].attn_norm
         d.ws_attn_part = L.ptr(self.ws_attn_part)
-        d.ws_sync = L.ptr(self.ws_sync)      # producer flags of the one-launch MLP (csrc/mlp_engine.h)
+        d.ws_sync = L.ptr(self.ws_sync) if self.one_launch_mlp else 0      # producer flags of the one-launch MLP (csrc/mlp_engine.h); NULL -> two launches
         self.dec = d
         self._shape = key
         self._graph_key = None
@@ -373,6 +380,11 @@ class DecoderEngine:
         st = int(self.state[4].item())
         if st:
             self.state[4:5].zero_()
+        if st & 2:
+            raise L.VauraHipError(
+                "decode loop: a consumer of the one-launch MLP gave up waiting for its producers (csrc/mlp_engine.h: its 256 workgroups "
+                "must all become resident — is another process running the same kernels on this GPU?); the tokens of this call are "
+                "not valid.  DecoderEngine(..., one_launch_mlp=False) keeps the two-launch path")
         if st & 1:
             raise L.VauraHipError(
                 "decode loop: non-finite logits reached the sampler — an activation left the range of the fp16-plane format "
