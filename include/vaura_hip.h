@@ -154,8 +154,8 @@ typedef struct vaura_decoder {
   const float* first_norm;   /* layers[0].attn_norm (device), gain applied by the embed kernel */
   float*    ws_attn_part;    /* optional (rows, n_head, 8, head_dim + 8): partials of the range-split attention used when
                                 rows*n_head < 256 and max_len > 256 (vaura_attention_splits); NULL -> never split       */
-  uint32_t* ws_sync;         /* optional 256 words (zeroed once by the caller): producer flags of the one-launch MLP (csrc/mlp_engine.h: w1||w3 ->
-                                in-launch hand-off -> w2 with w2's weight stream running ahead of the hand-off).  NULL -> always two launches   */
+  uint32_t* ws_sync;         /* optional 512 words (zeroed once by the caller): producer flags of the one-launch layer tail (csrc/mlp_engine.h: wo ->
+                                hand-off -> w1||w3 -> hand-off -> w2, each phase's weight stream running ahead of its hand-off).  NULL -> separate launches */
 } vaura_decoder;
 
 /* -------------------------------------------------------------------------------------------

@@ -812,10 +812,12 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
 
 @pytest.mark.parametrize("wdtype", ["h2", "h1"])
 def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
-    """csrc/mlp_engine.h (the default where eligible; debug flag bit 2 = two launches): w1||w3 -> in-launch hand-off of the ffn planes
-    -> w2 as ONE launch per layer, w2's weights requested ahead of the hand-off.  Same products in the same order as the two-launch path: teacher-forced logits must be
-    BIT-identical, tokens (greedy + CFG, and Philox-sampled) identical, through the eager path and through the captured step graph,
-    and no consumer may have given up waiting (status word clean).  12 decoder rows = both row halves live (the eligible shape)."""
+    """csrc/mlp_engine.h, the default where eligible: the MLP of a layer (w1||w3 + SwiGLU -> w2 + residual) as ONE launch with an
+    in-launch hand-off, w2's weights requested ahead of it (debug flag bit 2: every GEMV its own launch; bit 3: the experimental
+    three-phase launch that takes wo in as well).  Same products in the same order as the separate launches: teacher-forced
+    logits must be BIT-identical, tokens (greedy + CFG, and Philox-sampled) identical, through the eager path and through the
+    captured step graph, and no consumer may have given up waiting (status word clean).  12 decoder rows = both row halves live
+    (the eligible shape)."""
     from vaura_amd import _lib as L
     cfg = synth.tiny_sampler(3)
     sd = synth.sampler_state_dict(cfg, seed=101, round_bf16=(wdtype == "h1"))
@@ -825,7 +827,7 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
     f12 = synth.video_features(12, seed=104).to(DEV)
     out = {}
     try:
-        for flags in (0, 4):
+        for flags in (0, 8, 4):
             L.lib().vaura_set_debug_flags(flags)
             eng._free_graph()
             out[flags] = (eng.logits_all_positions(idx, f12).clone(),
@@ -838,7 +840,8 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
         eng._free_graph()
     torch.cuda.synchronize()
     assert torch.isfinite(out[4][0]).all()
-    assert torch.equal(out[0][0], out[4][0]), float((out[0][0] - out[4][0]).abs().max())
-    for i in (1, 2, 3):
-        assert torch.equal(out[0][i], out[4][i]), i
+    for flags in (0, 8):
+        assert torch.equal(out[flags][0], out[4][0]), (flags, float((out[flags][0] - out[4][0]).abs().max()))
+        for i in (1, 2, 3):
+            assert torch.equal(out[flags][i], out[4][i]), (flags, i)
     assert torch.equal(out[4][1], out[4][3])

@@ -130,9 +130,22 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
+    const Gemv3Args awo = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
+    if (mlp_engine && (va_debug_flags_get() & 8u)) {
+      // EXPERIMENT (debug flag bit 3): the whole layer TAIL as one launch — wo + residual -> hand-off -> w1||w3 + SwiGLU -> hand-off
+      // -> w2 + residual (csrc/mlp_engine.h tail_engine_kernel).  Bit-identical, and measured no faster than wo + the two-phase
+      // engine (two planes -0.5 %, one plane +1.5 % on the loop): the first hand-off costs what wo's kernel boundary costs, and
+      // w1||w3's stream is HBM-bound wherever it starts.  The default stays wo as its own launch.
+      PROF_B(VAURA_K_W13);
+      rc = va_launch_tail_engine(awo, g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F),
+                                 g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D),
+                                 d->ws_sync, d->state, l, s);
+      PROF_A(VAURA_K_W13);
+      if (rc) return rc;
+      continue;
+    }
     PROF_B(VAURA_K_WO);    // h += Wo.attn ; emit split(h * ffn_norm) + ss               llama.py:259, 279
-    rc = va_launch_gemv3(g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D), D, D,
-                         E3_RESID, false, s);
+    rc = va_launch_gemv3(awo, D, D, E3_RESID, false, s);
     PROF_A(VAURA_K_WO);
     if (rc) return rc;
     const Gemv3Args a13 = g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F);

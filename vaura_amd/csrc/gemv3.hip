@@ -231,6 +231,33 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* fl
   return a13.wq == 2 ? launch_mlp_engine_t<2>(e, s) : launch_mlp_engine_t<0>(e, s);
 }
 
+template <int WT>
+static int launch_tail_engine_t(const TailEngineArgs& e, hipStream_t s) {
+  using SH = MlpEngineShape<WT>;
+  static unsigned long long big = 0;
+  if (va_big_lds_once(reinterpret_cast<const void*>(tail_engine_kernel<WT>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  VA_LAUNCH((tail_engine_kernel<WT>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p0.W, e.p0.XP, e.p1.W, e.p2.W, e);
+  return 0;
+}
+
+// wo -> w1||w3 -> w2 of one layer as ONE launch (tail_engine_kernel); flags: 512 words
+int va_launch_tail_engine(const Gemv3Args& awo, const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer,
+                          hipStream_t s) {
+  TailEngineArgs e;
+  e.p0 = awo; e.p1 = a13; e.p2 = a2;
+  if (!awo.W || !awo.XP || !a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || awo.R != 1 || a13.R != 1 || a2.R != 1) return VAURA_ERR_ARG;
+  if (!awo.res || !awo.out || !awo.outp || !awo.gain_out || !awo.ss_out || !a2.out || !a2.outp || !a2.gain_out || !a2.ss_out || !a13.outp ||
+      !a13.ss_in) return VAURA_ERR_ARG;
+  if (awo.wq != a13.wq || a13.wq != a2.wq || (a13.wq != 0 && a13.wq != 2) || awo.N != 1536 || a13.N != 4096 || a2.N != 1536 ||
+      a13.k_total != 1536 || a13.n_ss_in != 96 || awo.out != a2.res || awo.outp != a13.XP || a13.outp != a2.XP) return VAURA_ERR_SHAPE;
+  e.p0.wscale = weight_scales(awo, 1536, 1536);
+  e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
+  e.p2.wscale = weight_scales(a2, 1536, 4096);
+  e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
+  e.abl = (int)((va_debug_flags >> 28) & 15u);
+  return a13.wq == 2 ? launch_tail_engine_t<2>(e, s) : launch_tail_engine_t<0>(e, s);
+}
+
 // ---------------------------------------------------------------------------- fp16-plane weight ingress
 // power-of-two row scale 2^E with amax / 2^E in [2^13, 2^14): both planes of a weight of ordinary size are normal fp16 numbers
 // (hi ~ 2^13, lo ~ 2^2), four binades of headroom below fp16's 65504

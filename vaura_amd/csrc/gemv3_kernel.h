@@ -145,7 +145,7 @@ __device__ __forceinline__ EpiPre gemv3_epilogue_prefetch(const Gemv3Args& a, in
 
 template <int T, int EPI>
 __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int tile0, int lane, const f32x4* v,
-                                               const EpiPre* pre = nullptr) {
+                                               const EpiPre* pre = nullptr, f32x4* keep = nullptr) {
   const int m = lane & 15, q = lane >> 4;
   const int row = rb * 16 + m;
   if constexpr (EPI == E3_SWIGLU) {
@@ -170,6 +170,7 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
         const size_t idx = ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane;
         f32x4 o = v[t];
         if constexpr (EPI == E3_RESID) o += (pre && pre->have && T == 1) ? pre->res : reinterpret_cast<const f32x4*>(a.res)[idx];
+        if (keep) keep[t] = o;      // the caller keeps the new residual rows in registers (layer-tail engine: wo's output is w2's residual)
         if (a.out) va_st16(reinterpret_cast<f32x4*>(a.out) + idx, o);
         if (a.ss_out) {
           float s = ((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]) + o[3] * o[3];
