@@ -133,6 +133,7 @@ int main(int argc, char** argv) {
     unsigned long long* buf; CK(hipMalloc(&buf, (8 + cap * 16) * 8)); CK(hipMemset(buf, 0, (8 + cap * 16) * 8));
     unsigned long long hdr[3] = {0, cap, getenv("PMC_STAMP_ALL_WAVES") ? 1ull : 0ull};
     vaura_step_graph_t g;
+    if (auto setf = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags")) setf(variants[0]);    // --flags F: the variant to stamp
     if (gbuild(&d, &sp, st, &g)) { fprintf(stderr, "graph build\n"); return 3; }
     const int32_t st0[4] = {pos0, 0, 0, 1};
     CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));

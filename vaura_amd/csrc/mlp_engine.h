@@ -24,8 +24,8 @@ struct MlpEngineArgs {
   const int32_t* state;    // device state: [0] position, [3] sequence id, [4] status bits
   int32_t* state_rw;
   int layer;
-  int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights
-                           // requested behind the hand-off barrier)
+  int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
+                           // behind the hand-off barrier)
 };
 
 #define MLPE_NW 8
@@ -38,7 +38,7 @@ struct MlpEngineShape {
   static constexpr int PL = WT == 2 ? 4 : 8;           // pairs per wave whose weights wait in LDS (the rest in registers)
   static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB
   static constexpr int RED = MLPE_NW * 2 * 64 * 16;    // reduction tiles (both phases)
-  static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 64;      // + the arrival words
+  static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 128;     // + the arrival / hand-shake words
 };
 
 struct TailEngineArgs {
@@ -106,28 +106,17 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   f32x4* red = reinterpret_cast<f32x4*>(mlpe_lds + NW * SH::WAVE_RING);            // [NW][2][64]
   unsigned* arrive = reinterpret_cast<unsigned*>(mlpe_lds + NW * SH::WAVE_RING + SH::RED);
 
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);                       // wave start
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.x;
   // epoch of this hand-off: unique per (sequence, position, layer); the flags hold the previous hand-off's epoch until rewritten
   const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)e.state[0] + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
 
-  // residual tile / next norm's gain of the phase-2 epilogue (written by the PREVIOUS kernel): requested first thing by the wave
-  // that will need them, landed long before anything waits
   EpiPre pre;
   pre.have = false;
-  if (bid < 192 && wid == 0) {
-    const int h2_ = (bid >> 3) & 1, tile2_ = (bid & 7) + 8 * (bid >> 4);
-    if (((lane >> 3) & 1) == h2_) pre = gemv3_epilogue_prefetch<E3_RESID>(e.p2, 0, tile2_, lane);
-  }
-  // the power-of-two row scales of both epilogues too (a dependent L2 round trip behind the reduction otherwise)
   f32x4 ws1[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}}, ws2 = f32x4{1.f, 1.f, 1.f, 1.f};
-  if (wid == 0) {
-    const int q_ = lane >> 4;
-    ws1[0] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2) * 16 + 4 * q_);
-    ws1[1] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2 + 1) * 16 + 4 * q_);
-    if (bid < 192) ws2 = *reinterpret_cast<const f32x4*>(e.p2.wscale + (size_t)((bid & 7) + 8 * (bid >> 4)) * 16 + 4 * q_);
-  }
 
   // ================================================================ phase 1: w1||w3 + SwiGLU (gemv3_kernel<6, 8, 2, E3_SWIGLU, true>)
   {
@@ -179,7 +168,20 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
       for (int j = 0; j < NSS; ++j) ssv[j] = sp[(q + 4 * j) * 16];
     }
+    // wave 0, behind its stream requests (HBM misses first): what the two epilogues need and earlier KERNELS wrote — the residual
+    // tile and next norm's gain of phase 2, the power-of-two row scales of both (a dependent L2 round trip behind the reduction
+    // otherwise)
+    if (wid == 0) {
+      if (bid < 192) {
+        const int h2_ = (bid >> 3) & 1, tile2_ = (bid & 7) + 8 * (bid >> 4);
+        if (((lane >> 3) & 1) == h2_) pre = gemv3_epilogue_prefetch<E3_RESID>(e.p2, 0, tile2_, lane);
+        ws2 = *reinterpret_cast<const f32x4*>(e.p2.wscale + (size_t)tile2_ * 16 + 4 * q);
+      }
+      ws1[0] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2) * 16 + 4 * q);
+      ws1[1] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2 + 1) * 16 + 4 * q);
+    }
     __builtin_amdgcn_sched_barrier(0);                 // every request of the first batch is out before anything is waited for
+    VA_STAMP(stamps, 1);                               // phase 1: first batch requested
     f32x4 acc[T][NACC];
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -213,8 +215,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // arrival words instead of a workgroup barrier: waves 1..7 go on to request their w2 slice at once; wave 0 alone waits for
     // the tiles.  A wave's word carries this launch's epoch (LDS keeps what the previous launch on this CU left: its epoch, never
     // this one), so nothing has to be initialised and no barrier opens the kernel.  LDS operations of a wave execute in order:
-    // the word lands behind the tiles.
-    if (lane == 0) __hip_atomic_store(arrive + wid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // the word lands behind the tiles (release: the compiler keeps that order too).
+    if (lane == 0) __hip_atomic_store(arrive + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    VA_STAMP(stamps, 2);                               // phase 1: products done, tiles in LDS
     if (wid == 0) {
       float ssp = 0.f;
 #pragma unroll
@@ -239,12 +242,21 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         v[t] = sacc * rinv;
       }
       gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
+      // (Measured and rejected, round 4: holding the other waves' run-ahead requests back until these stores are in the CU's memory
+      // pipeline.  A CU serves its vector-memory requests in order, so the publish waits behind the seven waves' 224 KB of requests
+      // — 2.6 us median in the stamps — and with the hold it comes 2.8 us earlier; but the run-ahead then starts 2.3 us later, wave
+      // 0's poll comes back behind its own later requests, and the loop is 1 % (two planes) / 3 % (one) SLOWER: what bounds the
+      // second phase is the 393 KB each CU has to take in, in whatever order.)
       // publish: this wave stored the workgroup's whole ffn tile (write-through); drained, then the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + bid), "v"(epoch) : "memory");
+      VA_STAMP(stamps, 3);                             // wave 0: published
     }
   }
-  if (bid >= 192) return;
+  if (bid >= 192) {
+    VA_STAMP_FLUSH(stamps, 11);
+    return;
+  }
 
   // ================================================================ phase 2: w2 + residual (gemv3h_kernel<8, 8, E3_RESID>)
   {
@@ -287,6 +299,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       }
     };
     if (!(e.abl & 4)) prefetch_w2();
+    if (wid != 0) VA_STAMP(stamps, 3);                 // waves 1..7: w2 slice requested
 
     // ---- hand-off: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest
     if (wid == 0) {
@@ -308,6 +321,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // before anybody may request the planes.  Only control has to pass here: the planes are requested behind it in program order.
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    VA_STAMP(stamps, 4);                               // hand-off barrier passed (wave 0: its poll matched just before)
     if (e.abl & 4) prefetch_w2();
 
     // ---- the planes of this workgroup's 8 rows over its wave's K slice: every load sc1 (the producers stored write-through)
@@ -321,7 +335,8 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
           xb[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (p * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
     }
     __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
-    __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
+    VA_WAIT_VM(0);
+    VA_STAMP(stamps, 5);                               // (diagnostic build) weights and planes landed
     f32x4 acc[2][NACC];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
@@ -366,6 +381,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       v *= ws2;
       if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
     }
+    VA_WAIT_VM(0);
+    VA_STAMP(stamps, 6);                               // done (wave 0: epilogue stores acknowledged)
+    VA_STAMP_FLUSH(stamps, 11);
   }
 }
 
@@ -398,6 +416,8 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
   unsigned* arrive0 = reinterpret_cast<unsigned*>(mlpe_lds + NW * SH::WAVE_RING + SH::RED);
   unsigned* arrive1 = arrive0 + NW;
 
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.x;
@@ -507,6 +527,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
       red[(wid * 2 + nh) * 64 + lane] = o;
     }
     if (lane == 0) __hip_atomic_store(arrive0 + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    VA_STAMP(stamps, 1);                                   // phase 0: products done
     // phase 1's weight stream starts once this wave's phase-0 operands have LANDED (its products are issued): requested at kernel
     // start the 50 MB compete with phase 0's 9 MB for the same HBM pipe and phase 0 — the head of the whole chain — slows down
     if (wid != 0 && !(e.abl & 2)) load_w13();
@@ -522,6 +543,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
       // publish phase 0: h (fp32), its partial sums of squares and its planes are out (write-through), drained, then the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(flags0 + bid), "v"(epoch) : "memory");
+      VA_STAMP(stamps, 2);                                 // wave 0: phase 0 published
     }
   } else {
     load_w13();            // no phase-0 tile: at once (measured: held back until the hand-off these 64 workgroups become phase 1's laggards)
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
   const bool broken0 = mlpe_poll_flags(flags0, 48, epoch, e, wid, lane);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  VA_STAMP(stamps, 3);                                     // hand-off 0 passed
 
   // ================================================================ phase 1: w1||w3 + SwiGLU (gemv3_kernel<6, 8, 2, E3_SWIGLU, true>)
   {
@@ -573,6 +596,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
 #pragma unroll
     for (int t = 0; t < T; ++t) red[(wid * T + t) * 64 + lane] = acc_sum<WT>(acc[t]);
     if (lane == 0) __hip_atomic_store(arrive1 + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    VA_STAMP(stamps, 4);                                   // phase 1: products done
     if (wid == 0) {
       float ssp = 0.f;
 #pragma unroll
@@ -593,9 +617,13 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
       gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(flags1 + bid), "v"(epoch) : "memory");
+      VA_STAMP(stamps, 5);                                 // wave 0: phase 1 published
     }
   }
-  if (!narrow) return;
+  if (!narrow) {
+    VA_STAMP_FLUSH(stamps, 12);
+    return;
+  }
 
   // ================================================================ phase 2: w2 + residual (gemv3h_kernel<8, 8, E3_RESID>)
   {
@@ -631,6 +659,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
     (void)mlpe_poll_flags(flags1, 64, epoch, e, wid, lane, broken0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    VA_STAMP(stamps, 6);                                   // hand-off 1 passed
     u32x4 xb[G2][VA_NPL];
     {
       const int vx = la + 8 * h < a.rows ? voffx : 0x7ffffff0;
@@ -685,5 +714,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
       pre2.res = hkeep;                                    // the rows this wave produced in phase 0
       if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre2);
     }
+    VA_WAIT_VM(0);
+    VA_STAMP_FLUSH(stamps, 12);                            // t7 of the record = done
   }
 }
