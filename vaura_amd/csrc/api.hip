@@ -115,15 +115,21 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // the MLP half of every layer as ONE launch (mlp_engine.h) where the shape is eligible and the caller provided the hand-off
   // flags (dec->ws_sync); debug flag bit 2: two launches whatever the shape (the A/B, and the path every other shape takes)
   const bool mlp_engine = !(va_debug_flags_get() & 4u) && va_mlp_engine_eligible(d);
+  // ... and the NEXT layer's qkv GEMV as a third phase of that launch
+  const bool fuse_qkv = mlp_engine && qkv2 && !(va_debug_flags_get() & 0x2000000u);   // debug flag bit 25: qkv stays its own launch
+  bool qkv_done = false;                     // layer l's qkv partials were written by layer l - 1's engine launch
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
-    PROF_B(VAURA_K_QKV);   // qkv = rinv * Wqkv.(g*h)                                  llama.py:280, 228
-    Gemv3Args aq = g3(L.wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D);
-    aq.out2 = qkv2;        // two K-half partials, added by the attention kernel on load
-    rc = va_launch_gemv3(aq, 3 * D, D, E3_STORE, true, s);
-    PROF_A(VAURA_K_QKV);
-    if (rc) return rc;
+    if (!qkv_done) {
+      PROF_B(VAURA_K_QKV);   // qkv = rinv * Wqkv.(g*h)                                  llama.py:280, 228
+      Gemv3Args aq = g3(L.wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D);
+      aq.out2 = qkv2;        // two K-half partials, added by the attention kernel on load
+      rc = va_launch_gemv3(aq, 3 * D, D, E3_STORE, true, s);
+      PROF_A(VAURA_K_QKV);
+      if (rc) return rc;
+    }
+    qkv_done = false;
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
     rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
@@ -153,10 +159,17 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     if (mlp_engine) {
       // ONE launch: w1||w3 + SwiGLU -> in-launch hand-off of the ffn planes -> w2 + residual, w2's weights requested ahead of the
       // hand-off (csrc/mlp_engine.h); booked under w13 by the per-launch profiler
+      Gemv3Args aqn;
+      const bool with_qkv = fuse_qkv && l + 1 < m.n_layer;
+      if (with_qkv) {
+        aqn = g3(d->layers_host[l + 1].wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D);
+        aqn.out2 = qkv2;
+      }
       PROF_B(VAURA_K_W13);
-      rc = va_launch_mlp_engine(a13, a2, d->ws_sync, d->state, l, s);
+      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s);
       PROF_A(VAURA_K_W13);
       if (rc) return rc;
+      qkv_done = with_qkv;
       continue;
     }
     PROF_B(VAURA_K_W13);   // ffn = silu(W1 x) * (W3 x), x = rmsnorm(h)                  llama.py:282, 177

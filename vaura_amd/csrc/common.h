@@ -185,7 +185,8 @@ int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStr
 int va_pack_weight_h(const float* src, void* dst, int64_t N, int64_t K, int planes, hipStream_t s);   // fp16 plane(s) + row scales
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 bool va_mlp_engine_eligible(const vaura_decoder* d);
-int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer, hipStream_t s);
+int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq_next, uint32_t* flags, int32_t* state, int layer,
+                         hipStream_t s);
 int va_launch_tail_engine(const Gemv3Args& awo, const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer,
                           hipStream_t s);
 int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t s);

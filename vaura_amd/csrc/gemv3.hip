@@ -209,26 +209,35 @@ bool va_mlp_engine_eligible(const vaura_decoder* d) {
   return cus[dev] >= 256;
 }
 
-template <int WT>
+template <int WT, bool QKV>
 static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
   using SH = MlpEngineShape<WT>;
   static unsigned long long big = 0;
-  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT>), SH::LDS, &big)) return VAURA_ERR_STATE;
-  VA_LAUNCH((mlp_engine_kernel<WT>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
+  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT, QKV>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  VA_LAUNCH((mlp_engine_kernel<WT, QKV>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
   return 0;
 }
 
-int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer, hipStream_t s) {
+// aq != nullptr: the next layer's qkv GEMV (K-split, two partial outputs) as a third phase of the same launch
+int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq, uint32_t* flags, int32_t* state, int layer,
+                         hipStream_t s) {
   MlpEngineArgs e;
   e.p1 = a13;
   e.p2 = a2;
+  e.p3 = aq ? *aq : a2;
+  if (aq) {
+    if (!aq->W || !aq->out || !aq->out2 || !aq->ss_in || aq->XP != a2.outp || aq->ss_in != a2.ss_out || aq->R != 1) return VAURA_ERR_ARG;
+    if (aq->wq != a2.wq || aq->N != 3 * 1536 || aq->k_total != 1536 || aq->n_ss_in != 96) return VAURA_ERR_SHAPE;
+    e.p3.wscale = weight_scales(*aq, 3 * 1536, 1536);
+  }
   if (!a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || a13.R != 1 || a2.R != 1) return VAURA_ERR_ARG;
   if (a13.wq != a2.wq || (a13.wq != 0 && a13.wq != 2) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 || a13.n_ss_in != 96) return VAURA_ERR_SHAPE;
   e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
-  return a13.wq == 2 ? launch_mlp_engine_t<2>(e, s) : launch_mlp_engine_t<0>(e, s);
+  if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true>(e, s) : launch_mlp_engine_t<0, true>(e, s);
+  return a13.wq == 2 ? launch_mlp_engine_t<2, false>(e, s) : launch_mlp_engine_t<0, false>(e, s);
 }
 
 template <int WT>

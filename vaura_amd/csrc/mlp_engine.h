@@ -20,7 +20,8 @@
 struct MlpEngineArgs {
   Gemv3Args p1;            // w1||w3: W, XP (h planes), ss_in, outp (ffn planes), N = ffn_dim, rows, R = 1, eps, k_total, wscale
   Gemv3Args p2;            // w2: W, XP (= p1.outp), res / out (h), outp (h planes), gain_out, ss_out, N = d_model, wscale
-  uint32_t* flags;         // [256] producer flags
+  Gemv3Args p3;            // QKV instances: the NEXT layer's wqkv: W, XP (= p2.outp), ss_in (= p2.ss_out), out / out2 (K-half partials), wscale
+  uint32_t* flags;         // [512]: [0, 256) phase-1 producers, [256, 448) phase-2 producers (QKV instances)
   const int32_t* state;    // device state: [0] position, [3] sequence id, [4] status bits
   int32_t* state_rw;
   int layer;
@@ -37,7 +38,7 @@ struct MlpEngineShape {
   static constexpr int G2 = 8;                         // k-group pairs per wave in phase 2 (K = 4096)
   static constexpr int PL = WT == 2 ? 4 : 8;           // pairs per wave whose weights wait in LDS (the rest in registers)
   static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB
-  static constexpr int RED = MLPE_NW * 2 * 64 * 16;    // reduction tiles (both phases)
+  static constexpr int RED = MLPE_NW * 3 * 64 * 16;    // reduction tiles (every phase; the qkv phase has three tiles per wave)
   static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 128;     // + the arrival / hand-shake words
 };
 
@@ -95,7 +96,7 @@ __device__ __forceinline__ uint32_t mlpe_ld_sc1(const uint32_t* p) {
   return v;
 }
 
-template <int WT>
+template <int WT, bool QKV>
 __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __restrict__ W13q, const uint16_t* __restrict__ XPq,
                                                                   const void* __restrict__ W2q, MlpEngineArgs e) {
   using SH = MlpEngineShape<WT>;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   unsigned char* ring = mlpe_lds;
   f32x4* red = reinterpret_cast<f32x4*>(mlpe_lds + NW * SH::WAVE_RING);            // [NW][2][64]
   unsigned* arrive = reinterpret_cast<unsigned*>(mlpe_lds + NW * SH::WAVE_RING + SH::RED);
+  unsigned* arrive2 = arrive + NW;             // phase-2 tiles written (QKV instances: their phase-2 reduction has no barrier either)
 
   VA_STAMP_DECL(stamps);
   VA_STAMP(stamps, 0);                       // wave start
@@ -370,20 +372,129 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       }
       red[(wid * 2 + nh) * 64 + lane] = o;
     }
-    __syncthreads();
-    if (wid == 0) {
-      const int m = lane & 15;
-      const bool mine = (m >> 3) == h;
-      const int src = (m & 7) + 16 * (q & 1);
-      f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
+    if constexpr (!QKV) {
+      __syncthreads();
+      if (wid == 0) {
+        const int m = lane & 15;
+        const bool mine = (m >> 3) == h;
+        const int src = (m & 7) + 16 * (q & 1);
+        f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
 #pragma unroll
-      for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
-      v *= ws2;
-      if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
+        for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
+        v *= ws2;
+        if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
+      }
+      VA_WAIT_VM(0);
+      VA_STAMP(stamps, 6);                               // done (wave 0: epilogue stores acknowledged)
+      VA_STAMP_FLUSH(stamps, 11);
+    } else {
+      // ============================================================== phase 3: the NEXT layer's qkv GEMV (gemv3_kernel<3, 8, 3, E3_STORE, true, 1, 0, WT, 2>)
+      // Same pattern once more: the weights of the next layer's wqkv depend on nothing, so every wave requests its slice (3 tiles x 3
+      // k-groups, straight into the registers phase 2 has released) as soon as its phase-2 products are issued, wave 0 once it has
+      // published; the h planes and the partial sums of squares phase 2's epilogues write are handed over inside the launch (192
+      // producers = these same workgroups); behind the hand-off: one round trip for the planes, 18 products per wave, reduction,
+      // rinv, store of the two K-half partials the attention kernel adds on load.  One launch and one kernel boundary less per layer.
+      Gemv3Args aq = e.p3;
+      constexpr int G = 3, TQ = 3, KQ = 1536, KGQ = KQ / 32;
+      const int ks = bid & 1, tile0q = (bid >> 1) * TQ, kgo = ks * G * NW;
+      const int w3 = (wid + bid) % NW;
+      const int mq = lane & 15;
+      const int lane16 = lane * 16;
+      const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(aq.W), 0, -16, 0x00020000);
+      u32x4 wq[TQ][G][WH];
+      auto load_wq = [&]() {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int t = 0; t < TQ; ++t) {
+            const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
+#pragma unroll
+            for (int hh = 0; hh < WH; ++hh)
+              wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+          }
+      };
+      if (lane == 0) __hip_atomic_store(arrive2 + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (wid != 0) load_wq();
+      if (wid < TQ) wsq = *reinterpret_cast<const f32x4*>(aq.wscale + (size_t)(tile0q + wid) * 16 + 4 * q);
+      if (wid == 0) {
+        mlpe_wait_words(arrive2, epoch);
+        const int m = lane & 15;
+        const bool mine = (m >> 3) == h;
+        const int src = (m & 7) + 16 * (q & 1);
+        f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
+        v *= ws2;
+        if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
+        // publish phase 2: h, its partial sums of squares and its planes are out (write-through), drained, then the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 256 + bid), "v"(epoch) : "memory");
+        load_wq();
+      }
+      (void)mlpe_poll_flags(e.flags + 256, 48, epoch, e, wid, lane);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aq.XP), 0, aq.R * VA_NPL * (KQ / 8) * 256, 0x00020000);
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.ss_in), 0, 96 * 16 * 4, 0x00020000);
+      u32x4 xq[G][VA_NPL];
+      {
+        const int xl16 = mq < aq.rows ? lane16 : 0x7ffffff0;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int p = 0; p < VA_NPL; ++p)
+            xq[g][p] = __builtin_amdgcn_raw_buffer_load_b128(hrs, xl16, (int)((p * (KQ / 8) * 16 + (kgo + w3 * G + g) * 64) * 16), 16 /* sc1 */);
+      }
+      constexpr int NSSQ = KQ / 64;
+      float ssq[NSSQ];
+      if (wid < TQ) {
+#pragma unroll
+        for (int j = 0; j < NSSQ; ++j)                   // written by phase 2's epilogues in THIS launch: sc1
+          ssq[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, ((q + 4 * j) * 16 + mq) * 4, 0, 16 /* sc1 */));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 accq[TQ][NACC];
+#pragma unroll
+      for (int t = 0; t < TQ; ++t)
+#pragma unroll
+        for (int p = 0; p < NACC; ++p) accq[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+          f16x8 wf[F32 ? 2 : 1];
+          wf[0] = __builtin_bit_cast(f16x8, wq[t][g][0]);
+          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wq[t][g][WH - 1]);
+          mfma_group<WT>(wf, xq[g], accq[t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) red[(wid * TQ + t) * 64 + lane] = acc_sum<WT>(accq[t]);
+      float rinvq = 1.f;
+      if (wid < TQ) {
+        float ssp = 0.f;
+#pragma unroll
+        for (int j = 0; j < NSSQ; ++j) ssp += ssq[j];
+        ssp += va_xor16(ssp);
+        ssp += va_xor32(ssp);
+        rinvq = 1.0f / sqrtf(ssp * (1.0f / (float)aq.k_total) + aq.eps);
+      }
+      __syncthreads();
+      if (wid < TQ) {
+        f32x4 sacc = red[(0 * TQ + wid) * 64 + lane];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) sacc += red[(i * TQ + wid) * 64 + lane];
+        sacc *= wsq;
+        const f32x4 v = sacc * rinvq;
+        if (ks > 0) aq.out = aq.out2;
+        gemv3_epilogue<1, E3_STORE>(aq, 0, tile0q + wid, lane, &v, nullptr);
+      }
+      VA_WAIT_VM(0);
+      VA_STAMP(stamps, 6);
+      VA_STAMP_FLUSH(stamps, 11);
     }
-    VA_WAIT_VM(0);
-    VA_STAMP(stamps, 6);                               // done (wave 0: epilogue stores acknowledged)
-    VA_STAMP_FLUSH(stamps, 11);
   }
 }
 
