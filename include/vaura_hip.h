@@ -154,8 +154,9 @@ typedef struct vaura_decoder {
   const float* first_norm;   /* layers[0].attn_norm (device), gain applied by the embed kernel */
   float*    ws_attn_part;    /* optional (rows, n_head, 8, head_dim + 8): partials of the range-split attention used when
                                 rows*n_head < 256 and max_len > 256 (vaura_attention_splits); NULL -> never split       */
-  uint32_t* ws_sync;         /* optional 512 words (zeroed once by the caller): producer flags of the one-launch layer tail (csrc/mlp_engine.h: wo ->
-                                hand-off -> w1||w3 -> hand-off -> w2, each phase's weight stream running ahead of its hand-off).  NULL -> separate launches */
+  uint32_t* ws_sync;         /* optional 768 words (zeroed once by the caller): producer flags of the launches that hand activations over INSIDE the
+                                launch (csrc/mlp_engine.h: w1||w3 -> w2 -> next layer's qkv; csrc/attention.hip: attention -> wo), each phase's weight
+                                stream running ahead of its hand-off.  NULL -> every GEMV and the attention are separate launches */
 } vaura_decoder;
 
 /* -------------------------------------------------------------------------------------------

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
   d.ws_ffn_split = dev_zero<uint16_t>((size_t)rp * 3 * F); d.ws_ss = dev_zero<float>((size_t)(rp / 16) * (D / 16) * 16);
   d.first_norm = lw[0].attn_norm;
   d.ws_attn_part = nullptr;
-  d.ws_sync = dev_zero<uint32_t>(512);
+  d.ws_sync = dev_zero<uint32_t>(768);
   vaura_sampling sp{1, 1.0f, 250, 0.0f, 6.0f, 1234ull, 0ull};
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CK(hipDeviceSynchronize());

@@ -118,6 +118,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // ... and the NEXT layer's qkv GEMV as a third phase of that launch
   const bool fuse_qkv = mlp_engine && qkv2 && !(va_debug_flags_get() & 0x2000000u);   // debug flag bit 25: qkv stays its own launch
   bool qkv_done = false;                     // layer l's qkv partials were written by layer l - 1's engine launch
+  // attention + wo as one launch too (single-round-trip attention only: cache <= 256 positions, 16 heads; debug flag bit 26: no)
+  const bool attn_wo = mlp_engine && H == 16 && d->max_len <= 256 && !(va_debug_flags_get() & 0x4000008u);
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -130,12 +132,23 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
       if (rc) return rc;
     }
     qkv_done = false;
+    const Gemv3Args awo0 = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
+    if (attn_wo) {
+      // attention + wo as ONE launch (csrc/attention.hip attn_wo_kernel): wo's weights stream under the attention, the attention's
+      // planes are handed over inside the launch; booked under the attention kind by the per-launch profiler
+      PROF_B(VAURA_K_ATTN);
+      rc = va_launch_attn_wo(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, d->ws_attn_split,
+                             rows, H, d->max_len, d->state, awo0, d->ws_sync + 512, l, s);
+      PROF_A(VAURA_K_ATTN);
+      if (rc) return rc;
+    } else {
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
     rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
+    }
     const Gemv3Args awo = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
     if (mlp_engine && (va_debug_flags_get() & 8u)) {
       // EXPERIMENT (debug flag bit 3): the whole layer TAIL as one launch — wo + residual -> hand-off -> w1||w3 + SwiGLU -> hand-off
@@ -150,10 +163,12 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
       if (rc) return rc;
       continue;
     }
-    PROF_B(VAURA_K_WO);    // h += Wo.attn ; emit split(h * ffn_norm) + ss               llama.py:259, 279
-    rc = va_launch_gemv3(awo, D, D, E3_RESID, false, s);
-    PROF_A(VAURA_K_WO);
-    if (rc) return rc;
+    if (!attn_wo) {
+      PROF_B(VAURA_K_WO);    // h += Wo.attn ; emit split(h * ffn_norm) + ss               llama.py:259, 279
+      rc = va_launch_gemv3(awo, D, D, E3_RESID, false, s);
+      PROF_A(VAURA_K_WO);
+      if (rc) return rc;
+    }
     const Gemv3Args a13 = g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F);
     const Gemv3Args a2 = g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D);
     if (mlp_engine) {

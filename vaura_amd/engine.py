@@ -244,7 +244,7 @@ class DecoderEngine:
             self.ws_ffn_split = torch.zeros(rp * 2 * c.ffn_dim, **i16)
             self.ws_ss = torch.zeros((rp // 16) * (c.d_model // 16) * 16, **f32)
             self.ws_attn_part = torch.zeros(rows * c.nhead * 8 * (c.d_model // c.nhead + 8), **f32)
-            self.ws_sync = torch.zeros(512, dtype=torch.int32, device=self.dev)
+            self.ws_sync = torch.zeros(768, dtype=torch.int32, device=self.dev)
             crp = self._rows_padded(rows * n_cond_tokens)
             self.cond_in = torch.zeros(crp * c.cond_in, **f32)
             self.cond_tmp = torch.zeros(crp * c.cond_dim, **f32)
