@@ -118,8 +118,10 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // ... and the NEXT layer's qkv GEMV as a third phase of that launch
   const bool fuse_qkv = mlp_engine && qkv2 && !(va_debug_flags_get() & 0x2000000u);   // debug flag bit 25: qkv stays its own launch
   bool qkv_done = false;                     // layer l's qkv partials were written by layer l - 1's engine launch
-  // attention + wo as one launch too (single-round-trip attention only: cache <= 256 positions, 16 heads; debug flag bit 26: no)
-  const bool attn_wo = mlp_engine && H == 16 && d->max_len <= 256 && !(va_debug_flags_get() & 0x4000008u);
+  // EXPERIMENT (debug flag bit 26): attention + wo as one launch too (csrc/attention.hip attn_wo_kernel; single-round-trip attention
+  // only: cache <= 256 positions, 16 heads).  Bit-identical and measured SLOWER than the two launches (13.7 us against 7.05 + 0.7 +
+  // 4.8: the loop +3.3 % two planes / +3.8 % one): wo's stream is 1.5 us, nothing a run-ahead could hide pays for the hand-off.
+  const bool attn_wo = mlp_engine && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x4000000u) && !(va_debug_flags_get() & 8u);
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
