@@ -56,7 +56,12 @@ __device__ __forceinline__ float va_dpp(float x) {   // x as seen through DPP co
 #define VA_DPP_HALF_MIRROR 0x141   /* lane i <-> 7 - i of its 8: pairs the two quads (== xor 4 on quad-uniform values) */
 #define VA_DPP_ROR8 0x128   /* rotate a 16-lane row by 8 == xor 8 */
 // the value of lane ^ 16 / lane ^ 32.  v_permlane{16,32}_swap exchanges the odd rows of its first register with the even rows of
-// its second.  Written as inline asm: with the builtin, hipcc 7.2 folds `select(lane bit, r[0], r[1])` of swap(x, x) to r[0] (and
+// its second.  PRECONDITION of va_xor16 / va_xor32 / wave_sum / wave_max: 1-D blocks whose size is a multiple of 64 (lane = threadIdx.x
+// & 63: every kernel of this library is launched that way — the lane bit costs nothing, an mbcnt pair per call would) and the
+// partner lane active (full waves at the call site).  tools/microbench/lane_exchange_probe.hip checks all six exchanges on device.
+// The butterfly order of wave_sum / wave_max is 1, 2, 4, 8, 16, 32 since round 3 (round 2: 32 .. 1): fp32 sums round differently from
+// round-2 records (LayerNorm in vit, the RVQ argmin distances, the sampler's softmax denominator, rinv) — bit-exactness claims against
+// round-2 outputs do not carry over; the goldens (reference-generated) are what pins them.  Written as inline asm: with the builtin, hipcc 7.2 folds `select(lane bit, r[0], r[1])` of swap(x, x) to r[0] (and
 // may give both operands one physical register) — tools/microbench/lane_exchange_probe.hip is the passing check of THIS form.  The
 // s_nop covers the VALU-write -> permlane-read wait states the compiler would otherwise insert.
 __device__ __forceinline__ float va_xor16(float x) {

@@ -109,8 +109,21 @@ class VAURAModel(nn.Module):
         — if the checkpoint lacks them, the strict load fails loudly."""
         import inspect
         import os
+        import warnings
         import yaml
-        blob = torch.load(os.fspath(checkpoint_path), map_location="cpu", weights_only=False)   # a Lightning file: pickled hparams inside
+        if callable(map_location) or isinstance(map_location, dict):
+            raise L.VauraHipError("load_from_checkpoint: map_location must be a device (or None): tensors are read on the CPU and the model "
+                                  "is moved afterwards; a callable / dict remapping is not supported")
+        # With an hparams_file only `state_dict` is needed from the checkpoint: tensors only, no pickled objects executed.  Without one
+        # the constructor arguments are the checkpoint's own pickled `hyper_parameters` (Lightning's AttributeDict / OmegaConf nodes):
+        # that needs the full unpickler — the caller is trusting the file exactly as Lightning's own loader would.
+        try:
+            blob = torch.load(os.fspath(checkpoint_path), map_location="cpu", weights_only=True)
+        except Exception:
+            if hparams_file is not None:
+                warnings.warn(f"{checkpoint_path}: not loadable with weights_only=True (pickled objects beside the tensors); falling back to "
+                              "the full unpickler — only do this with checkpoints you trust", stacklevel=2)
+            blob = torch.load(os.fspath(checkpoint_path), map_location="cpu", weights_only=False)
         if "state_dict" not in blob:
             raise L.VauraHipError(f"{checkpoint_path}: not a Lightning checkpoint (no 'state_dict')")
         sd = dict(blob["state_dict"])
@@ -124,6 +137,9 @@ class VAURAModel(nn.Module):
         hp = _plain(hp)
         hp.update(kwargs)
         accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        dropped = sorted(k for k in hp if k not in accepted)
+        if dropped:      # training-side hyper-parameters (optimizer, logging, ...) have no meaning here: say which ones were ignored
+            warnings.warn(f"load_from_checkpoint: hyper-parameters without a counterpart on the generation path ignored: {dropped}", stacklevel=2)
         hp = {k: v for k, v in hp.items() if k in accepted}
         for key in ("feature_extractor_config", "audio_encoder_config", "sampler_config", "pattern_provider_config"):
             c = hp.get(key)
@@ -138,6 +154,8 @@ class VAURAModel(nn.Module):
         if isinstance(fe, dict) and fe.get("target", "").startswith("vaura_amd.") and any(k.startswith("visual_feature_extractor.") for k in sd):
             p = fe.setdefault("params", {})
             if p.get("ckpt_path") and not os.path.exists(p["ckpt_path"]):
+                warnings.warn(f"feature extractor ckpt_path {p['ckpt_path']!r} does not exist here: using the extractor tensors the "
+                              "checkpoint itself carries (visual_feature_extractor.*)", stacklevel=2)
                 p["ckpt_path"] = None
         model = cls(**hp)
         for k in cls.UNUSED_CHECKPOINT_KEYS:

@@ -3,12 +3,13 @@
 The device quantiser lives in libvaura_hip.so (``vaura_pack_weight(..., VAURA_W_FP8)``); these few torch
 lines state the same rule so that a caller (and the parity tests) can ask "which fp32 matrix does the fp8
 model actually multiply by?".  The reference has no fp8 path (BASELINE.json configs[4] is ours), so the
-contract is: the fp8 engine generates exactly the tokens the bf16 engine generates for the checkpoint
-whose four per-layer matrices are replaced by ``fp8_effective_weight(W)``.
+contract is: the fp8 engine generates exactly the tokens the one-fp16-plane ("h1") engine generates for the
+checkpoint whose four per-layer matrices are replaced by ``fp8_effective_weight(W)``.
 
 Format: OCP e4m3 (``torch.float8_e4m3fn``), one scale per output row, the smallest power of two with
-``max|W[n, :]| <= 448 * scale[n]``.  A power-of-two scale makes ``fp8 * scale`` exact in bf16, so the
-dequantised matrix is bf16-representable and the engine's exactness argument carries over.
+``max|W[n, :]| <= 448 * scale[n]``.  e4m3 widens to fp16 exactly (3 significand bits, exponents inside fp16's
+range) and the power-of-two scale is applied to the fp32 sum, so the kernel computes exactly what the
+one-plane path computes on the dequantised matrix.
 """
 from __future__ import annotations
 
