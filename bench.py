@@ -452,6 +452,8 @@ def main():
         names = json.load(open(os.path.join(REPO, "profiles", "kernel_names.json"))) if os.path.exists(
             os.path.join(REPO, "profiles", "kernel_names.json")) else {}
         kname = names.get("c4" if long_ctx else storage, {}).get(dom, dom)
+        if dom == "mlp" and not qkv_in_mlp:
+            kname = names.get(storage, {}).get("mlp_last", kname)
         # the committed rocprofv3 --kernel-trace --stats summary of this command (tools/profile_round.sh): its average duration of the
         # same kernel, quoted next to the live one so that the two can be seen to agree
         rocprof = None

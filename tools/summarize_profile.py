@@ -20,7 +20,7 @@ import re
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
@@ -45,6 +45,8 @@ def stage_of(name):
             return "w13"
         if epi == 4:
             return "heads"
+    if name.startswith("mlp_engine_kernel"):          # w1||w3 -> w2 (-> next layer's qkv) in one launch (csrc/mlp_engine.h)
+        return "mlp" if name.rstrip(">").endswith("true") else "mlp_last"
     m = re.match(r"gemv3h_kernel<(\d+), ", name)      # row-split pair kernels: G2 = k-group pairs per wave
     if m:
         return "w2" if int(m.group(1)) == 8 else "wo"

@@ -116,12 +116,12 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // flags (dec->ws_sync); debug flag bit 2: two launches whatever the shape (the A/B, and the path every other shape takes)
   const bool mlp_engine = !(va_debug_flags_get() & 4u) && va_mlp_engine_eligible(d);
   // ... and the NEXT layer's qkv GEMV as a third phase of that launch
-  const bool fuse_qkv = mlp_engine && qkv2 && !(va_debug_flags_get() & 0x2000000u);   // debug flag bit 25: qkv stays its own launch
+  const bool fuse_qkv = mlp_engine && qkv2 && !(va_debug_flags_get() & 0x2u);   // debug flag bit 1: qkv stays its own launch
   bool qkv_done = false;                     // layer l's qkv partials were written by layer l - 1's engine launch
-  // EXPERIMENT (debug flag bit 26): attention + wo as one launch too (csrc/attention.hip attn_wo_kernel; single-round-trip attention
+  // EXPERIMENT (debug flag bit 12): attention + wo as one launch too (csrc/attention.hip attn_wo_kernel; single-round-trip attention
   // only: cache <= 256 positions, 16 heads).  Bit-identical and measured SLOWER than the two launches (13.7 us against 7.05 + 0.7 +
   // 4.8: the loop +3.3 % two planes / +3.8 % one): wo's stream is 1.5 us, nothing a run-ahead could hide pays for the hand-off.
-  const bool attn_wo = mlp_engine && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x4000000u) && !(va_debug_flags_get() & 8u);
+  const bool attn_wo = mlp_engine && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u);
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -183,7 +183,11 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
         aqn.out2 = qkv2;
       }
       PROF_B(VAURA_K_W13);
-      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s);
+      // (experiment, debug flag bit 21: the 64 workgroups that leave after phase 1 touch the next attention's K / V rows)
+      const bool touch = with_qkv && (va_debug_flags_get() & 0x200000u);
+      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l,
+                                touch ? d->kcache + (size_t)(l + 1) * kv_layer : nullptr, touch ? d->vcache + (size_t)(l + 1) * kv_layer : nullptr,
+                                rows * H, d->max_len * hd, s);
       PROF_A(VAURA_K_W13);
       if (rc) return rc;
       qkv_done = with_qkv;
