@@ -828,8 +828,8 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
     out = {}
     try:
         # the default (w1||w3 -> w2 -> next layer's qkv in one launch) | + attention and wo in one launch (experiment) | qkv separate |
-        # + K/V touch by the idle workgroups (experiment) | the three-phase tail experiment | every GEMV and the attention their own launches
-        for flags in (0, 0x1000, 0x2, 0x200000, 8, 4):
+        # the three-phase tail experiment | every GEMV and the attention their own launches
+        for flags in (0, 0x1000, 0x2, 8, 4):
             L.lib().vaura_set_debug_flags(flags)
             eng._free_graph()
             out[flags] = (eng.logits_all_positions(idx, f12).clone(),
@@ -842,7 +842,7 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
         eng._free_graph()
     torch.cuda.synchronize()
     assert torch.isfinite(out[4][0]).all()
-    for flags in (0, 0x1000, 0x2, 0x200000, 8):
+    for flags in (0, 0x1000, 0x2, 8):
         assert torch.equal(out[flags][0], out[4][0]), (flags, float((out[flags][0] - out[4][0]).abs().max()))
         for i in (1, 2, 3):
             assert torch.equal(out[flags][i], out[4][i]), (flags, i)

@@ -183,11 +183,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
         aqn.out2 = qkv2;
       }
       PROF_B(VAURA_K_W13);
-      // (experiment, debug flag bit 21: the 64 workgroups that leave after phase 1 touch the next attention's K / V rows)
-      const bool touch = with_qkv && (va_debug_flags_get() & 0x200000u);
-      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l,
-                                touch ? d->kcache + (size_t)(l + 1) * kv_layer : nullptr, touch ? d->vcache + (size_t)(l + 1) * kv_layer : nullptr,
-                                rows * H, d->max_len * hd, s);
+      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s);
       PROF_A(VAURA_K_W13);
       if (rc) return rc;
       qkv_done = with_qkv;

@@ -191,7 +191,7 @@ int va_pack_weight_h(const float* src, void* dst, int64_t N, int64_t K, int plan
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 bool va_mlp_engine_eligible(const vaura_decoder* d);
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq_next, uint32_t* flags, int32_t* state, int layer,
-                         const float* kv_k, const float* kv_v, int kv_blocks, int kv_stride, hipStream_t s);
+                         hipStream_t s);
 int va_launch_attn_wo(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out, uint16_t* outp,
                       int rows, int n_head, int max_len, const int32_t* state, const Gemv3Args& awo, uint32_t* flags, int layer, hipStream_t s);
 int va_launch_tail_engine(const Gemv3Args& awo, const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer,

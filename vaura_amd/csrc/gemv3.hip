@@ -220,9 +220,8 @@ static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
 
 // aq != nullptr: the next layer's qkv GEMV (K-split, two partial outputs) as a third phase of the same launch
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq, uint32_t* flags, int32_t* state, int layer,
-                         const float* kv_k, const float* kv_v, int kv_blocks, int kv_stride, hipStream_t s) {
+                         hipStream_t s) {
   MlpEngineArgs e;
-  e.kv_k = kv_k; e.kv_v = kv_v; e.kv_blocks = kv_blocks; e.kv_stride = kv_stride;
   e.p1 = a13;
   e.p2 = a2;
   e.p3 = aq ? *aq : a2;

@@ -27,12 +27,6 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
-  // K/V touch (optional): the 64 workgroups that leave after phase 1 first touch the cached K / V rows the NEXT attention launch will
-  // read — [rows x heads] blocks of kv_pos positions, kv_stride floats apart — one dword per 128-byte line, so that those rows sit in
-  // the memory-side cache when it starts.  kv_k == nullptr: off.
-  const float* kv_k;
-  const float* kv_v;
-  int kv_blocks, kv_stride;
 };
 
 #define MLPE_NW 8
@@ -262,20 +256,6 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     }
   }
   if (bid >= 192) {
-    if (e.kv_k) {
-      // this CU would idle for the 13 us phases 2 and 3 still take: touch the next attention's K / V rows (cache length = position + 1
-      // by then; the newest row does not exist yet).  Nothing waits for these loads; the wave ends when they have returned.
-      const int npos = e.state[0] + (QKV ? 1 : 0);                      // the NEXT layer's cache at this step holds positions [0, pos)
-      const int lines = (npos * 96 * 4 + 127) / 128;                    // 128-byte lines per (row, head) block
-      const int total = e.kv_blocks * lines;
-      float acc = 0.f;
-      for (int i = (bid - 192) * (MLPE_NW * 64) + (int)threadIdx.x; i < total; i += 64 * MLPE_NW * 64) {
-        const int blk = i / lines, ln = i - blk * lines;
-        acc += __builtin_nontemporal_load(e.kv_k + (size_t)blk * e.kv_stride + ln * 32);
-        acc += __builtin_nontemporal_load(e.kv_v + (size_t)blk * e.kv_stride + ln * 32);
-      }
-      asm volatile("" ::"v"(acc));
-    }
     VA_STAMP_FLUSH(stamps, 11);
     return;
   }
