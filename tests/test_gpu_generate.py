@@ -847,3 +847,41 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
         for i in (1, 2, 3):
             assert torch.equal(out[flags][i], out[4][i]), (flags, i)
     assert torch.equal(out[4][1], out[4][3])
+
+
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_one_launch_mlp_under_concurrent_load_and_repeats(one_launch):
+    """The in-launch hand-offs of csrc/mlp_engine.h under conditions an idle chip hides (MI355X_MICROARCH.md: "test every hand-off under
+    UNEVEN load"): (1) the decode loop replayed many times on the same inputs must give the same tokens every time (a stale plane or a
+    flag seen too early would show as a difference sooner or later); (2) with a SECOND stream keeping the chip busy with full-chip
+    codec launches — workgroups of the MLP launch then become resident late and unevenly, its consumers wait (bounded) for producers
+    that have not started — the tokens must still equal the quiet run's and no consumer may have given up (status word clean)."""
+    cfg = synth.tiny_sampler(3)
+    sd = synth.sampler_state_dict(cfg, seed=111, round_bf16=False)
+    eng = DecoderEngine(cfg, sd, DEV, one_launch_mlp=one_launch)     # False: the control (separate launches under the same load)
+    assert eng.wdtype == "h2" and eng.one_launch_mlp == one_launch
+    feats = synth.video_features(8, seed=112).to(DEV)
+    kw = dict(cfg_scale=6.0, use_sampling=True, top_k=250, seed=5)
+    ref = eng.generate_codes(feats, 60, **kw).clone()
+    eng.check_status()
+    for _ in range(12):
+        assert torch.equal(eng.generate_codes(feats, 60, **kw), ref)
+    eng.check_status()
+    ccfg = synth.FULL_CODEC
+    codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), DEV)
+    codes = torch.randint(0, 1024, (8, 9, 220), device=DEV)
+    side = torch.cuda.Stream(DEV)
+    main = torch.cuda.Stream(DEV)
+    codec.decode(codes)                     # workspaces allocated before the overlap
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                codec.decode(codes)         # ~45 ms of full-chip conv grids next to the loop
+        with torch.cuda.stream(main):
+            outs.append(eng.generate_codes(feats, 60, **kw).clone())
+        torch.cuda.synchronize()
+    eng.check_status()                       # a consumer that gave up waiting raises here
+    for o in outs:
+        assert torch.equal(o, ref)

@@ -115,6 +115,10 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   const int bid = blockIdx.x;
   // epoch of this hand-off: unique per (sequence, position, layer); the flags hold the previous hand-off's epoch until rewritten
   const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)e.state[0] + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
+  // LDS arrival words carry the epoch mixed with THIS workgroup's id: on a busy chip the 256 workgroups of a launch do not all start at
+  // once, and a late one can land on a CU another workgroup of the SAME launch has just left — whose arrival words hold this very
+  // epoch (round 4: found by the concurrent-load test; on an idle chip every workgroup has a CU of its own and it never shows)
+  const uint32_t ltag = epoch ^ ((uint32_t)(blockIdx.x + 1) * 0x9E3779B1u);
 
   EpiPre pre;
   pre.have = false;
@@ -215,10 +219,11 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
     for (int t = 0; t < T; ++t) red[(wid * T + t) * 64 + lane] = acc_sum<WT>(acc[t]);
     // arrival words instead of a workgroup barrier: waves 1..7 go on to request their w2 slice at once; wave 0 alone waits for
-    // the tiles.  A wave's word carries this launch's epoch (LDS keeps what the previous launch on this CU left: its epoch, never
-    // this one), so nothing has to be initialised and no barrier opens the kernel.  LDS operations of a wave execute in order:
+    // the tiles.  A wave's word carries this launch's epoch mixed with the workgroup id (LDS keeps what the previous workgroup on
+    // this CU left: another epoch or another workgroup's tag, never this one), so nothing has to be initialised and no barrier
+    // opens the kernel.  LDS operations of a wave execute in order:
     // the word lands behind the tiles (release: the compiler keeps that order too).
-    if (lane == 0) __hip_atomic_store(arrive + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(arrive + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     VA_STAMP(stamps, 2);                               // phase 1: products done, tiles in LDS
     if (wid == 0) {
       float ssp = 0.f;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       for (;;) {
         bool all = true;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) all &= __hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == epoch;
+        for (int i = 0; i < NW; ++i) all &= __hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == ltag;
         if (all) break;
         __builtin_amdgcn_s_sleep(1);
       }
@@ -337,6 +342,13 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
           xb[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (p * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
     }
     __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
+    // The ring was filled by LDS-DMA: the compiler does not know those instructions write LDS and would read fragments while they
+    // are still in flight (it issued the first ds_reads AHEAD of its own wait for the planes).  On a quiet chip the DMA has landed
+    // microseconds earlier; with another stream loading the chip it has not (test_one_launch_mlp_under_concurrent_load_and_repeats
+    // found tokens differing).  A wave reads only fragments it requested itself, so its own counter is the whole synchronisation: every
+    // request of this wave — DMA, register weights, planes (needed next anyway) — has landed before the first fragment is read.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     VA_WAIT_VM(0);
     VA_STAMP(stamps, 5);                               // (diagnostic build) weights and planes landed
     f32x4 acc[2][NACC];
@@ -413,12 +425,12 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
               wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
           }
       };
-      if (lane == 0) __hip_atomic_store(arrive2 + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(arrive2 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
       if (wid != 0) load_wq();
       if (wid < TQ) wsq = *reinterpret_cast<const f32x4*>(aq.wscale + (size_t)(tile0q + wid) * 16 + 4 * q);
       if (wid == 0) {
-        mlpe_wait_words(arrive2, epoch);
+        mlpe_wait_words(arrive2, ltag);
         const int m = lane & 15;
         const bool mine = (m >> 3) == h;
         const int src = (m & 7) + 16 * (q & 1);
@@ -533,6 +545,10 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.x;
   const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)e.state[0] + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
+  // LDS arrival words carry the epoch mixed with THIS workgroup's id: on a busy chip the 256 workgroups of a launch do not all start at
+  // once, and a late one can land on a CU another workgroup of the SAME launch has just left — whose arrival words hold this very
+  // epoch (round 4: found by the concurrent-load test; on an idle chip every workgroup has a CU of its own and it never shows)
+  const uint32_t ltag = epoch ^ ((uint32_t)(blockIdx.x + 1) * 0x9E3779B1u);
   uint32_t* flags0 = e.flags;            // [192] phase-0 producers
   uint32_t* flags1 = e.flags + 256;      // [256] phase-1 producers
   const bool narrow = bid < 192;         // this workgroup owns a (tile, row half) of the 1536-wide outputs (phases 0 and 2)
@@ -637,13 +653,13 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
       }
       red[(wid * 2 + nh) * 64 + lane] = o;
     }
-    if (lane == 0) __hip_atomic_store(arrive0 + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(arrive0 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     VA_STAMP(stamps, 1);                                   // phase 0: products done
     // phase 1's weight stream starts once this wave's phase-0 operands have LANDED (its products are issued): requested at kernel
     // start the 50 MB compete with phase 0's 9 MB for the same HBM pipe and phase 0 — the head of the whole chain — slows down
     if (wid != 0 && !(e.abl & 2)) load_w13();
     if (wid == 0) {
-      mlpe_wait_words(arrive0, epoch);
+      mlpe_wait_words(arrive0, ltag);
       const bool mine = (m >> 3) == h;
       const int src = (m & 7) + 16 * (q & 1);
       f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
@@ -706,7 +722,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) red[(wid * T + t) * 64 + lane] = acc_sum<WT>(acc[t]);
-    if (lane == 0) __hip_atomic_store(arrive1 + wid, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(arrive1 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     VA_STAMP(stamps, 4);                                   // phase 1: products done
     if (wid == 0) {
       float ssp = 0.f;
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
       ssp += va_xor16(ssp);
       ssp += va_xor32(ssp);
       const float rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
-      mlpe_wait_words(arrive1, epoch);
+      mlpe_wait_words(arrive1, ltag);
       f32x4 v[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -780,6 +796,8 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
         for (int p = 0; p < VA_NPL; ++p)
           xb[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (p * (K / 8) * 16 + (wn * G2 + j) * 128) * 16, 16 /* sc1 */);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA'd ring fragments of this wave have landed (see mlp_engine_kernel)
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[2][NACC];
 #pragma unroll
