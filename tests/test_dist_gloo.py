@@ -32,9 +32,12 @@ def _worker(rank, world, port, total, out):
     wav = torch.arange(first, first + n, dtype=torch.float32)[:, None, None].expand(n, 1, 7).contiguous()
     fullw = vdist.gather_clips(wav, counts)
     t = vdist.max_over_ranks(float(rank + 1), "cpu")
+    seen = vdist.ranks_seen("cpu")                      # who took part (the bench record's `ranks_seen` / `ranks`)
+    per_rank = vdist.gather_floats(10.0 * (rank + 1), "cpu")
     vdist.barrier()
     ok = (full.shape == (total, 9, 5) and bool((full[:, 0, 0] == torch.arange(total, dtype=torch.int32)).all())
-          and bool((fullw[:, 0, 0] == torch.arange(total, dtype=torch.float32)).all()) and t == float(world))
+          and bool((fullw[:, 0, 0] == torch.arange(total, dtype=torch.float32)).all()) and t == float(world)
+          and [d["rank"] for d in seen] == list(range(world)) and per_rank == [10.0 * (i + 1) for i in range(world)])
     out[rank] = ok
     dist.destroy_process_group()
 
@@ -46,3 +49,12 @@ def test_final_gather_two_ranks(total):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
     assert all(out[r] for r in range(world))
+
+
+def test_gpu_count_without_hip_never_touches_torch_cuda():
+    """bench.py's launcher parent counts GPUs from sysfs (it must not initialise HIP before it spawns the ranks): an int or None,
+    and no CUDA context afterwards."""
+    n = vdist.count_gpus_without_hip()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    assert not torch.cuda.is_initialized()
+    assert vdist.ranks_seen("cpu")[0]["rank"] == 0 and vdist.gather_floats(1.5, "cpu") == [1.5]     # single process: no group needed
