@@ -10,6 +10,8 @@
 #   graph-steps                         decode steps per graph launch (debug flag bits 24..27): 1 / 4 / 12, alternating
 #   chains                              the batch as 2 / 4 independent decode chains on separate streams against one chain of all rows
 #   plain-stores                        write-through output stores (product) against ordinary ones (build --plain-stores), alternating
+#   codec-abl [tags ..]                 codec decode (mfma_driver codec 8, precisions 1 and 4) on experiment builds `python -m vaura_amd.csrc.build --tag T -DVA_CONV_ABL=n`
+#                                       (timing ablations of conv_pair_kernel, csrc/dac.hip) next to the product library
 #   codec-layers                        per-dispatch durations of one codec decode (kernel trace of mfma_driver codec 8)
 #   avclip-stats                        per-kernel averages of one extractor forward (mfma_driver avclip 8 under rocprofv3 --stats)
 #   prefill-ab                          one later chunk of the sliding-window caller: LDS-DMA prefill GEMM (0) against the register-staged one (131072)
@@ -67,6 +69,11 @@ plain-stores)
   for w in h2 h1; do for rep in 1 2; do for lib in libvaura_hip.so libvaura_hip_plain.so; do
     timeout 300 /tmp/pmc_driver vaura_amd/csrc/$lib --time 5 --weights $w > $OUT/t.log 2>&1; echo "$w $lib: $(grep 'loop of 228' $OUT/t.log | cut -c1-110)"
   done; done; done | tee $OUT/plain_stores.log ;;
+codec-abl)
+  mfma_driver
+  for rep in 1 2; do for t in "" ${@:-_cabl1 _cabl2 _cabl4 _cabl3}; do for pr in 1 4; do
+    echo "lib$t precision $pr: $(timeout 120 /tmp/mfma_driver vaura_amd/csrc/libvaura_hip$t.so codec 8 $pr 5 2>&1 | grep -o 'last decode [0-9.]* ms')" | tee -a $OUT/codec_abl.log
+  done; done; done ;;
 codec-layers)
   mfma_driver; cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o c -- /tmp/mfma_driver $LIB codec 8 > $OUT/run.log 2>&1

@@ -201,8 +201,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
                                                   const float* __restrict__ rope,
                                                   float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ out,
                                                   uint16_t* __restrict__ outp, int n_head, int pos, f32x4* sqkv,
-                                                  f32x4 (*wacc)[HD / 4], float* wm, float* wl, HOOK after_requests = HOOK(),
-                                                  bool drain_at_barrier = false) {
+                                                  f32x4 (*wacc)[HD / 4], float* wm, float* wl, HOOK after_requests = HOOK()) {
   constexpr int QUADS = HD / 4;   // 24
   constexpr int QPL = QUADS / 8;  // 3
   constexpr int NW = ATT1_THREADS / 64;
@@ -264,16 +263,12 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   if (tid >= QUADS && tid < 3 * QUADS)
     va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD) + cq, y);
   // Only the LDS writes have to be visible behind this barrier.  __syncthreads() would also drain the vector-memory counter, i.e. wait
-  // for EVERY cached K and V row before the first score (round 3's "one round trip by design"); with a raw barrier the rows stay in
-  // flight and the compiler's own counted waits let pass u's scores start when pass u's rows have landed (debug flag bit 21: the
-  // draining barrier, for the A/B).
-  if (drain_at_barrier) {
-    __syncthreads();
-  } else {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
+  // for EVERY cached K and V row before the first score; with a raw barrier the rows stay in flight and the compiler's own counted
+  // waits let pass u's scores start when pass u's rows have landed.  (Measured neutral on the 228-step loop, like the unconditional
+  // qkv2 load above: the launch is bound by the K / V stream itself — profiles/r04_ab_mlp_engine.txt, attention section.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
 #ifdef VAURA_STAMPS
   VA_STAMP(stamps, 3);                       // rotated q / k / v parked in LDS (first barrier)
   VA_WAIT_VM(0);
@@ -370,7 +365,7 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
     // argument order = what the dependent chain needs first (the leading 14 dwords are preloaded into SGPRs)
     const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
     const float* __restrict__ qkv2, const float* __restrict__ rope, int n_head, int max_len, int pos_host,
-    float* __restrict__ out, uint16_t* __restrict__ outp, int drain) {
+    float* __restrict__ out, uint16_t* __restrict__ outp) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];   // rotated q | rotated k | v of the new position | scratch
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -379,11 +374,11 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
   float* kc = kcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
   float* vc = vcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
   switch ((pos + 63) >> 6) {
-    case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, NoHook(), drain != 0); break;
-    case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, NoHook(), drain != 0); break;
-    case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, NoHook(), drain != 0); break;
-    case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, NoHook(), drain != 0); break;
-    default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, NoHook(), drain != 0); break;
+    case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
   }
 }
 
@@ -934,7 +929,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
     VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
-              n_head, max_len, pos_host, out, outp, (int)((va_debug_flags_get() >> 21) & 1u));
+              n_head, max_len, pos_host, out, outp);
     return 0;
   }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);

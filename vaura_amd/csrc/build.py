@@ -41,7 +41,14 @@ def _stale(target: str, deps) -> bool:
 
 
 def _compile(src: str, force: bool, stamps=False) -> str:
-    # stamps: False = product, True = -DVAURA_STAMPS, "wt" = -DVAURA_PLAIN_STORES
+    # stamps: False = product, True = -DVAURA_STAMPS, "wt" = -DVAURA_PLAIN_STORES, ("tag", "-DX=1", ..) = an experiment build
+    if isinstance(stamps, tuple):
+        obj = os.path.join(HERE, src.replace(".hip", f".{stamps[0]}.o"))
+        cmd = [_hipcc(), *FLAGS, *stamps[1:], "-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
     obj = os.path.join(HERE, src.replace(".hip", ".wt.o" if stamps == "wt" else (".stamps.o" if stamps else ".o")))
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
     if force or _stale(obj, deps):
@@ -57,6 +64,9 @@ def _compile(src: str, force: bool, stamps=False) -> str:
 def build(force: bool = False, verbose: bool = False, stamps=False) -> str:
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     LIB = LIB_WT if stamps == "wt" else (LIB_STAMPS if stamps else globals()["LIB"])
+    if isinstance(stamps, tuple):
+        LIB = os.path.join(HERE, f"libvaura_hip_{stamps[0]}.so")
+        force = True
     with cf.ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, stamps), srcs))
     if force or _stale(LIB, objs):
@@ -70,4 +80,7 @@ def build(force: bool = False, verbose: bool = False, stamps=False) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True, stamps="wt" if "--plain-stores" in sys.argv else ("--stamps" in sys.argv))
+    if "--tag" in sys.argv:      # experiment build: --tag NAME -DX=1 ... -> libvaura_hip_NAME.so (tools/experiment.sh; never loaded by the package)
+        build(verbose=True, stamps=(sys.argv[sys.argv.index("--tag") + 1], *[a for a in sys.argv if a.startswith("-D")]))
+    else:
+        build(force="--force" in sys.argv, verbose=True, stamps="wt" if "--plain-stores" in sys.argv else ("--stamps" in sys.argv))

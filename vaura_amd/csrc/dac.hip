@@ -295,6 +295,11 @@ __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float*
 // faster).  With MJ = 8 one staged weight tile serves twice the rows: 756 KB per 256 x 96 outputs against 1 314.  The activation
 // block (256 + halo rows) then has ONE LDS buffer — it is restaged between two barriers once per chunk, every NT steps — so two
 // workgroups still share a CU (70 KB each); the output tile goes out in two 128-row passes.
+// VA_CONV_ABL: timing ablations for tools/experiment.sh codec-abl (WRONG RESULTS; product build = 0): 1 no weight-tile loads / stores
+// after the first, 2 no matrix instructions, 4 no per-step barrier, 8 fragments read from LDS once (no LDS reads in the loop)
+#ifndef VA_CONV_ABL
+#define VA_CONV_ABL 0
+#endif
 template <int NI, bool WS, bool XS = false, int MJ = 4>
 __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
   constexpr int BN_ = 32 * NI;
@@ -385,11 +390,11 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
     const int xb = NXB == 2 ? (c & 1) : 0;
     for (int t = 0; t < NT; ++t, ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < nk) load_w(kt + 1);
+      if (kt + 1 < nk && !(VA_CONV_ABL & 1)) load_w(kt + 1);
       // (256 rows: the next chunk's block is requested at the LAST tap — its registers are free of the step's fragments only there —
       // and stored between two barriers below)
       if (t == (NXB == 2 ? 0 : NT - 1) && c + 1 < kc) load_x(c + 1);
-      const int shift = a.off_base + t * a.off_step - lo_off;
+      const int shift = (VA_CONV_ABL & 8) ? 0 : a.off_base + t * a.off_step - lo_off;
       f16x8 wh[NI], wl[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -409,17 +414,23 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
         for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < JG; ++j) {
+            if constexpr (VA_CONV_ABL & 2) {
+              acc[i][jh + j][0] += (float)wh[i][0] * (float)xh[j][0];
+              if constexpr (!XS) acc[i][jh + j][1] += (float)xl[j][0];
+              if constexpr (!WS && !XS) acc[i][jh + j][2] += (float)wl[i][0];
+              continue;
+            }
             if constexpr (!WS && !XS) acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][jh + j], 0, 0, 0);
             if constexpr (!XS) acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][jh + j], 0, 0, 0);
             acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][jh + j], 0, 0, 0);
           }
       }
-      if (kt + 1 < nk) store_w(buf ^ 1);
+      if (kt + 1 < nk && !(VA_CONV_ABL & 1)) store_w(buf ^ 1);
       if (t == NT - 1 && c + 1 < kc) {
         if constexpr (NXB == 1) __syncthreads();        // every wave is done with the block before it is overwritten
         store_x(NXB == 2 ? (xb ^ 1) : 0);
       }
-      __syncthreads();
+      if constexpr (!(VA_CONV_ABL & 4)) __syncthreads();
     }
   }
 
