@@ -320,6 +320,11 @@ size_t vaura_dac_workspace_elems(const vaura_codec* c, int B, int T);
  * Lout = Lin * stride.  `scratch` (>= B*Lin*Cin floats) receives the input in the precision's activation format.   */
 int vaura_dac_conv(const vaura_conv* cv, int precision, const float* in, float* out, float* scratch, int B, int Lin,
                    vaura_stream_t s);
+/* Op-level access for parity tests: the codec's activation, Snake1d of descript-audio-codec 1.0.0 (dac/nn/layers.py: x + (alpha + 1e-9)^-1 *
+ * sin(alpha x)^2), exactly as every conv epilogue of the decoder / encoder applies it.  x, y (rows, C) fp32 channels-last, alpha (C).
+ * The sine is an own restatement (period-pi reduction of sin^2 + a degree-9 odd polynomial, csrc/dac.hip::snake_sin2): max abs error
+ * 2.5e-7 for |alpha x| < 1e6 — the library sinf was the largest single cost of the decode.                                             */
+int vaura_snake(const float* x, const float* alpha, float* y, int64_t rows, int C, vaura_stream_t s);
 
 /* -------------------------------------------------------------------------------------------
  * f4 DacModelWrapper.encode (models/modules/dac/model.py:30-39): DAC encoder + residual VQ (descript-audio-codec

@@ -495,6 +495,38 @@ _CONV_SHAPES = [  # (Cin, Cout, k, dilation, stride)  — the decoder's layer ge
     (192, 192, 7, 1, 1), (192, 192, 1, 1, 1), (192, 96, 4, 1, 2), (96, 96, 7, 9, 1), (96, 96, 1, 1, 1)]
 
 
+def test_snake_sine():
+    """The codec's activation (vaura_snake = the snake_f of every conv epilogue; Snake1d of descript-audio-codec 1.0.0, restated in
+    oracle/dac_oracle.py::snake) with its own sin^2 (csrc/dac.hip::snake_sin2) against fp64 and against the oracle's fp32 form:
+    ordinary activations, the whole fp16-plane range (|x| up to 6e4, alpha up to 8), tiny alpha, exact zeros and multiples of pi/2.
+    The bar is absolute on sin^2 in [0, 1]: 4e-7 (the fp32 torch.sin squared is itself 1.3e-7 from fp64), i.e. error / alpha-inverse."""
+    from oracle import dac_oracle
+    from vaura_amd.engine import snake
+    g = torch.Generator().manual_seed(5)
+    C = 96
+    alpha = torch.cat([torch.rand(C - 6, generator=g) * 3 + 0.05, torch.tensor([1e-3, 8.0, 1.0, 0.5, 2.0, 1e-6])])
+    rows = [torch.randn(4000, C, generator=g) * 3, torch.randn(2000, C, generator=g) * 300,
+            (torch.rand(2000, C, generator=g) * 2 - 1) * 6.0e4,
+            torch.zeros(1, C), (torch.arange(1, 65, dtype=torch.float64)[:, None] * (torch.pi / 2) / alpha.double()[None]).float()]
+    x = torch.cat(rows)
+    got = snake(x, alpha, DEV).cpu().double()
+    ref = x.double() + (alpha.double() + 1e-9).reciprocal() * torch.sin(alpha.double() * x.double()) ** 2
+    # the product alpha * x is rounded to fp32 before the sine by the reference too (torch fp32): compare on that argument
+    arg = (alpha * x).double()
+    ref32arg = x.double() + (alpha.double() + 1e-9).reciprocal() * torch.sin(arg) ** 2
+    s2_err = ((got - ref32arg) * (alpha.double() + 1e-9)).abs()          # error of sin^2 itself
+    s2_err = s2_err - (x.double().abs() * 2.0 ** -23 * (alpha.double() + 1e-9))   # minus the final add's own rounding (|y| ~ |x|)
+    ora = dac_oracle.snake(x, alpha).double()
+    ora_err = ((ora - ref32arg) * (alpha.double() + 1e-9)).abs() - (x.double().abs() * 2.0 ** -23 * (alpha.double() + 1e-9))
+    print(f"snake: sin^2 max abs error {float(s2_err.max()):.2e} (the oracle's fp32 form: {float(ora_err.max()):.2e}); "
+          f"max |got - oracle| / max(1, |x|) = {float(((got - ora).abs() / x.double().abs().clamp(min=1)).max()):.2e}")
+    assert torch.isfinite(got).all()
+    assert float(s2_err.max()) <= 4e-7, float(s2_err.max())
+    assert float(((got - ref).abs() / (1 + ref.abs())).max()) <= 2e-2      # vs exact fp64 incl. the fp32 product alpha * x (ulp(6e4 * 8) = 0.03 rad)
+    small = x.abs().amax(dim=1) < 50
+    assert float((got[small] - ora[small]).abs().max()) <= 2e-6
+
+
 @pytest.mark.parametrize("shape", _CONV_SHAPES, ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("precision", ["f32", "f16pair", "f16", "f16pair_w8", "mx8"])
 def test_codec_convolution_per_precision(shape, precision):

@@ -12,6 +12,7 @@
 #   plain-stores                        write-through output stores (product) against ordinary ones (build --plain-stores), alternating
 #   codec-abl [tags ..]                 codec decode (mfma_driver codec 8, precisions 1 and 4) on experiment builds `python -m vaura_amd.csrc.build --tag T -DVA_CONV_ABL=n`
 #                                       (timing ablations of conv_pair_kernel, csrc/dac.hip) next to the product library
+#   codec-pmc                           SQ wait / issue / LDS counters of the codec kernels (mfma_driver codec 8 under rocprofv3 --pmc, four passes), per kernel
 #   codec-layers                        per-dispatch durations of one codec decode (kernel trace of mfma_driver codec 8)
 #   avclip-stats                        per-kernel averages of one extractor forward (mfma_driver avclip 8 under rocprofv3 --stats)
 #   prefill-ab                          one later chunk of the sliding-window caller: LDS-DMA prefill GEMM (0) against the register-staged one (131072)
@@ -74,6 +75,34 @@ codec-abl)
   for rep in 1 2; do for t in "" ${@:-_cabl1 _cabl2 _cabl4 _cabl3}; do for pr in 1 4; do
     echo "lib$t precision $pr: $(timeout 120 /tmp/mfma_driver vaura_amd/csrc/libvaura_hip$t.so codec 8 $pr 5 2>&1 | grep -o 'last decode [0-9.]* ms')" | tee -a $OUT/codec_abl.log
   done; done; done ;;
+codec-pmc)
+  mfma_driver; cd /tmp && export TMPDIR=/tmp
+  i=0
+  for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT" \
+           "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_IFETCH SQ_IFETCH_LEVEL SQ_LEVEL_WAVES SQ_VMEM_TA_ADDR_FIFO_FULL" \
+           "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    i=$((i+1))
+    rocprofv3 --kernel-trace --pmc $G --output-format csv -d $OUT/pmc$i -- /tmp/mfma_driver $LIB codec 8 ${1:-1} > $OUT/pmc$i.log 2>&1
+  done
+  python3 - <<PY
+import csv, glob, collections
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for i in range(1, 6):
+    for f in glob.glob("$OUT/pmc%d/**/*counter_collection.csv" % i, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_INST_LEVEL_LDS", "GRBM_GUI_ACTIVE"): n[(k, r["Counter_Name"])] += 1
+with open("$OUT/codec_pmc.txt", "w") as out:
+    for k, c in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:6]:
+        out.write(k + "\n")
+        for name, v in sorted(c.items()):
+            out.write("   %-28s %.4g\n" % (name, v))
+print(open("$OUT/codec_pmc.txt").read())
+PY
+  find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*counter_collection.csv" -delete ;;
 codec-layers)
   mfma_driver; cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o c -- /tmp/mfma_driver $LIB codec 8 > $OUT/run.log 2>&1

@@ -151,6 +151,7 @@ SIGNATURES = {
     "vaura_dac_decode": (C.c_int, [C.POINTER(Codec), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vaura_dac_workspace_elems": (C.c_size_t, [C.POINTER(Codec), C.c_int, C.c_int]),
     "vaura_dac_conv": (C.c_int, [C.POINTER(Conv), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vaura_snake": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

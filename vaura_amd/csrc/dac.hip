@@ -35,10 +35,34 @@ struct ConvArgs {
 // mx8 activation buffers keep their scale words behind the e4m3 bytes of the whole (B, L, C) tensor
 __host__ __device__ __forceinline__ size_t mx8_scale_offset(size_t elems) { return (elems + 15) & ~(size_t)15; }
 
-__device__ __forceinline__ float snake_f(float v, float al) {
-  const float sn = sinf(al * v);
-  return v + (1.0f / (al + 1e-9f)) * (sn * sn);
+#ifndef VA_CONV_ABL
+#define VA_CONV_ABL 0      // timing ablations, see conv_pair_kernel
+#endif
+// sin^2(x) for Snake.  The library sinf (Payne-Hanek path, sign / quadrant selects; inlined at every call site) was 2.3 ms of the 11.2 ms
+// decode of 8 clips (profiles/r04_codec_ablations.txt: the activation, not the matrix pipe, was the codec's largest single cost).  Only
+// the SQUARE is needed, and sin^2 has period pi and no sign: n = rint(x / pi), r = x - n pi in two fused steps (pi = PI_A + PI_B; the
+// fma keeps n PI_A exact), sin r on [-pi/2, pi/2] as r + r t p(t), t = r^2 (degree-4 fit of sin(r)/r - 1: 7e-9 before rounding).
+// Measured against fp64 over |x| <= 3e4: max abs error 2.5e-7, rms 3.7e-8 — the fp32 sinf squared gives 1.2e-7 / 2.9e-8; both are
+// rounding noise of the final multiply.  The error stays at that level while n is exact (|x| < ~1e6; the fp16-plane activation
+// format itself ends at 65504) and grows smoothly beyond.  tests/test_gpu_ops.py::test_snake_sine.
+__device__ __forceinline__ float snake_sin2(float x) {
+  const float n = __builtin_rintf(x * 0.318309886183790672f);
+  float r = fmaf(-n, 3.14159274101257324f, x);
+  r = fmaf(-n, -8.74227765734758577e-8f, r);
+  const float t = r * r;
+  float p = fmaf(t, 2.6051661734527443e-06f, -0.00019809046352747828f);
+  p = fmaf(t, p, 0.008333050645887852f);
+  p = fmaf(t, p, -0.16666658222675323f);
+  const float sn = fmaf(r, t * p, r);
+  return sn * sn;
 }
+// inv = 1.0f / (al + 1e-9f): one IEEE division per CHANNEL where a thread keeps its channels (the tile store, the fused unit), not per element
+__device__ __forceinline__ float snake_fi(float v, float al, float inv) {
+  if constexpr ((VA_CONV_ABL & 64) != 0) { const float sn = sinf(al * v); return v + inv * (sn * sn); }      // round 3's sine, for the A/B
+  const float s2 = (VA_CONV_ABL & 16) ? al * v : snake_sin2(al * v);
+  return v + inv * s2;
+}
+__device__ __forceinline__ float snake_f(float v, float al) { return snake_fi(v, al, 1.0f / (al + 1e-9f)); }
 
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   __shared__ f32x4 Ws[2][BK / 4][BN + 1];
@@ -164,6 +188,11 @@ struct ConvPArgs {
   uint8_t* out_scale;    // (B, Lout, ceil(Cout/128)) words of four E8M0 bytes: one power-of-two scale per 32 channels of a row
   const uint32_t* in_scale;   // the same for an mx8 input
   const float* wscale;   // (Cout) power-of-two scale of each output channel's e4m3 weights
+  // --- residual unit in one launch (conv_pair_kernel<.., FUSE = true>): this conv (7 taps) -> Snake(alpha_mid) -> 1 x 1 conv (w2, bias2)
+  //     -> + res -> out_raw / Snake(alpha) -> out_act.  bias / alpha_mid belong to the first conv, res / out_* / alpha to the second.
+  const uint16_t* w2;    // pair layout [Cout][Cout]
+  const float* bias2;
+  const float* alpha_mid;
 };
 
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -233,18 +262,29 @@ __device__ __forceinline__ float snake_fast(float v, float al) {
   return v + __builtin_amdgcn_rcpf(al + 1e-9f) * (sn * sn);
 }
 
-template <int BN_, int SP, bool FAST = false>
+template <int BN_, int SP, bool FAST = false, int ROWS = BM>
 __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float* stage, int b, int ph, int j0, int n0, int tid) {
   constexpr int OCT = BN_ / 8;              // octets per tile row
   static_assert(OCT % 4 == 0, "a 32-channel scale block = 4 consecutive threads of one row");
+  // a thread keeps ONE octet column and walks the rows (256 / OCT rows per sweep: 21 for 96 columns — threads 252..255 sit out, a whole
+  // 4-thread scale group — 32 for 64): its eight Snake alphas and their inverses are loaded / divided once, not per element
+  constexpr int RSTEP = 256 / OCT;
+  if (tid >= RSTEP * OCT) return;
+  const int oc = tid % OCT, row0 = tid / OCT;
+  const int co = n0 + oc * 8;
   const size_t obase = (size_t)b * a.Lout;
-  for (int u = tid; u < BM * OCT; u += 256) {
-    const int row = u / OCT, oc = u - row * OCT;
+  f32x4 al0 = f32x4{0.f, 0.f, 0.f, 0.f}, al1 = al0, iv0 = al0, iv1 = al0;
+  if (a.out_act && a.act == 0) {
+    al0 = *reinterpret_cast<const f32x4*>(a.alpha + co);
+    al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { iv0[r] = 1.0f / (al0[r] + 1e-9f); iv1[r] = 1.0f / (al1[r] + 1e-9f); }
+  }
+  for (int row = row0; row < ROWS; row += RSTEP) {
     const int jr = j0 + row;
     if (jr >= a.jcount) continue;
     const int orow = jr * a.ostride + a.oshift0 + ph;
     if (orow < 0 || orow >= a.Lout) continue;
-    const int co = n0 + oc * 8;
     const size_t o = (obase + (size_t)orow) * a.Cout + co;
     f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8);
     f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * SP + oc * 8 + 4);
@@ -257,8 +297,6 @@ __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float*
       *reinterpret_cast<f32x4*>(a.out_raw + o + 4) = v1;
     }
     if (a.out_act) {
-      f32x4 al0 = f32x4{0.f, 0.f, 0.f, 0.f}, al1 = al0;
-      if (a.act == 0) { al0 = *reinterpret_cast<const f32x4*>(a.alpha + co); al1 = *reinterpret_cast<const f32x4*>(a.alpha + co + 4); }
       float sv[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -266,8 +304,8 @@ __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float*
           sv[r] = snake_fast(v0[r], al0[r]);
           sv[r + 4] = snake_fast(v1[r], al1[r]);
         } else {
-          sv[r] = a.act == 0 ? snake_f(v0[r], al0[r]) : (a.act == 1 ? gelu_erf_f(v0[r]) : v0[r]);
-          sv[r + 4] = a.act == 0 ? snake_f(v1[r], al1[r]) : (a.act == 1 ? gelu_erf_f(v1[r]) : v1[r]);
+          sv[r] = a.act == 0 ? snake_fi(v0[r], al0[r], iv0[r]) : (a.act == 1 ? gelu_erf_f(v0[r]) : v0[r]);
+          sv[r + 4] = a.act == 0 ? snake_fi(v1[r], al1[r], iv1[r]) : (a.act == 1 ? gelu_erf_f(v1[r]) : v1[r]);
         }
       }
       store_act_octet(a.out_act, a.out_scale, a.act_fmt, obase + (size_t)orow, co, a.Cout, sv);
@@ -296,11 +334,11 @@ __device__ __forceinline__ void conv_tile_store(const ConvPArgs& a, const float*
 // block (256 + halo rows) then has ONE LDS buffer — it is restaged between two barriers once per chunk, every NT steps — so two
 // workgroups still share a CU (70 KB each); the output tile goes out in two 128-row passes.
 // VA_CONV_ABL: timing ablations for tools/experiment.sh codec-abl (WRONG RESULTS; product build = 0): 1 no weight-tile loads / stores
-// after the first, 2 no matrix instructions, 4 no per-step barrier, 8 fragments read from LDS once (no LDS reads in the loop)
+// after the first, 2 no matrix instructions, 4 no per-step barrier, 16 Snake without its sine, 64 Snake on the library sinf (round 3)
 #ifndef VA_CONV_ABL
 #define VA_CONV_ABL 0
 #endif
-template <int NI, bool WS, bool XS = false, int MJ = 4>
+template <int NI, bool WS, bool XS = false, int MJ = 4, bool FUSE = false>
 __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
   constexpr int BN_ = 32 * NI;
   constexpr int BMT = 32 * MJ;              // rows per workgroup (two waves along the rows)
@@ -320,7 +358,14 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
   constexpr int WS_ELEMS = 2 * (BK / 4) * WSTR, XS_ELEMS = NXB * (BK / 4) * XSTR;
   constexpr int SP = BN_ + 4;               // padded row stride (floats) of the staged output tile
   static_assert((WS_ELEMS + XS_ELEMS) * 16 >= BM * SP * 4, "the output tile must fit in the main loop's LDS");
-  __shared__ u32x4 smem[WS_ELEMS + XS_ELEMS];
+  // FUSE: the epilogue holds the 1 x 1 conv's whole weight matrix (3 chunks) and the activated tile of 64 rows as fragment images
+  static_assert(!FUSE || (NI == 3 && MJ == 8), "the fused residual unit: all 96 channels in one 256-row workgroup");
+  constexpr int W1STR = 112, YSTR = 80;     // plane strides (rows) of those images: multiples of 16, see above
+  constexpr int W1_ELEMS = FUSE ? 3 * (BK / 4) * W1STR : 0, Y_ELEMS = FUSE ? 3 * (BK / 4) * YSTR : 0;
+  static_assert(!FUSE || Y_ELEMS * 16 >= 64 * SP * 4, "the 64-row output tile is staged over the activated tile");
+  constexpr int SMEM_ELEMS = (WS_ELEMS + XS_ELEMS) > (W1_ELEMS + Y_ELEMS) ? (WS_ELEMS + XS_ELEMS) : (W1_ELEMS + Y_ELEMS);
+  constexpr int TAB_ELEMS = FUSE ? 2 * BN_ / 4 : 0;      // FUSE: alpha_mid and 1 / (alpha_mid + 1e-9) per channel, behind everything else
+  __shared__ u32x4 smem[SMEM_ELEMS + TAB_ELEMS];
   auto coff = [](int kq) { return (kq & 1) + ((kq >> 2) << 1); };     // {0,1,0,1,2,3,2,3}
   auto Ws = [&](int buf, int kq, int row) -> u32x4& { return smem[(buf * (BK / 4) + kq) * WSTR + row + coff(kq)]; };
   auto Xs = [&](int buf, int kq, int row) -> u32x4& { return smem[WS_ELEMS + (buf * (BK / 4) + kq) * XSTR + row + coff(kq)]; };
@@ -383,6 +428,14 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
   load_x(0);
   store_w(0);
   store_x(0);
+  if constexpr (FUSE) {
+    if (tid < BN_) {
+      float* tab = reinterpret_cast<float*>(smem + SMEM_ELEMS);
+      const float al = a.alpha_mid[tid];
+      tab[tid] = al;
+      tab[BN_ + tid] = 1.0f / (al + 1e-9f);
+    }
+  }
   __syncthreads();
   const int g = lane >> 4, r16 = lane & 15;
   int kt = 0;
@@ -438,6 +491,99 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
   // row: half cache lines for the fp32 stream, 8-byte pieces for the pair stream); staging the tile lets every thread
   // own a whole octet of a row, so residual reads and both output streams move 32 contiguous bytes per thread and
   // whole 128-byte lines per 4 threads.  (The main loop ended with a barrier: its LDS is free.)
+  if constexpr (FUSE) {
+    // ---- the residual unit's second half without leaving the CU.  Per 64-row pass: the two waves that own those rows turn their
+    // accumulators into the 1 x 1 conv's input — + bias, Snake(alpha_mid), (hi, lo) split: exactly what conv_tile_store writes to
+    // memory in the two-launch form — as a fragment image [chunk][kq][row] in LDS; all four waves multiply it by the 1 x 1 weights
+    // (three chunks, same three matrix instructions per product in the same order as the stand-alone launch: bit-identical sums);
+    // the 64 x 96 result is staged as fp32 over the image and leaves through the shared tile store (+ residual, raw, Snake, pairs).
+    u32x4* W1 = smem;
+    u32x4* Yi = smem + W1_ELEMS;
+    auto W1s = [&](int c2, int kq, int row) -> u32x4& { return W1[(c2 * (BK / 4) + kq) * W1STR + row + coff(kq)]; };
+    auto Ys = [&](int c2, int kq, int row) -> u32x4& { return Yi[(c2 * (BK / 4) + kq) * YSTR + row + coff(kq)]; };
+    // the 1 x 1 conv's weights (96 x 96 pairs = 2 304 quads, 9 per thread; L2 hits): requested here, parked in LDS behind the first
+    // pass's Snake arithmetic
+    u32x4 w1reg[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w1reg[i] = reinterpret_cast<const u32x4*>(a.w2)[tid + 256 * i];
+    float* stage = reinterpret_cast<float*>(Yi);
+    const float* tab = reinterpret_cast<const float*>(smem + SMEM_ELEMS);
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    auto pass = [&](auto pc) {                  // (a lambda per compile-time pass: the accumulator indices must be static)
+      constexpr int p = decltype(pc)::value;
+      if (p > 0) __syncthreads();               // the previous pass's tile store is done with `stage`
+      if (wm == (p >> 1)) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int col = wn * (NI * 16) + i * 16 + 4 * g;
+            const f32x4 v = acc[i][4 * (p & 1) + jj] + *reinterpret_cast<const f32x4*>(a.bias + col);
+            const f32x4 al = *reinterpret_cast<const f32x4*>(tab + col), iv = *reinterpret_cast<const f32x4*>(tab + BN_ + col);
+            f16x4 h4, l4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float sv = snake_fi(v[e], al[e], iv[e]);
+              h4[e] = (_Float16)sv;
+              l4[e] = (_Float16)(sv - (float)h4[e]);
+            }
+            const int c2 = col >> 5, o = (col & 31) >> 3, half = (col & 7) >> 2, row = jj * 16 + r16;
+            reinterpret_cast<f16x4*>(&Ys(c2, 2 * o, row))[half] = h4;
+            reinterpret_cast<f16x4*>(&Ys(c2, 2 * o + 1, row))[half] = l4;
+          }
+      }
+      if (p == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const int qd = tid + 256 * i, n = qd / 24, q = qd - n * 24;
+          W1s(q >> 3, q & 7, n) = w1reg[i];
+        }
+      }
+      __syncthreads();
+      f32x4 acc2[NI][2];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c2 = 0; c2 < 3; ++c2) {
+        f16x8 wh[NI], wl[NI], xh[2], xl[2];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          wh[i] = __builtin_bit_cast(f16x8, W1s(c2, 2 * g, wn * (NI * 16) + i * 16 + r16));
+          if constexpr (!WS && !XS) wl[i] = __builtin_bit_cast(f16x8, W1s(c2, 2 * g + 1, wn * (NI * 16) + i * 16 + r16));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          xh[j] = __builtin_bit_cast(f16x8, Ys(c2, 2 * g, (wm * 2 + j) * 16 + r16));
+          if constexpr (!XS) xl[j] = __builtin_bit_cast(f16x8, Ys(c2, 2 * g + 1, (wm * 2 + j) * 16 + r16));
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (!WS && !XS) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc2[i][j], 0, 0, 0);
+            if constexpr (!XS) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc2[i][j], 0, 0, 0);
+            acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc2[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();                          // every wave has read the image: the fp32 tile may overwrite it
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = (wm * 2 + j) * 16 + r16, col = wn * (NI * 16) + i * 16 + 4 * g;
+          *reinterpret_cast<f32x4*>(stage + row * SP + col) = acc2[i][j] + *reinterpret_cast<const f32x4*>(a.bias2 + col);
+        }
+      __syncthreads();
+      conv_tile_store<BN_, SP, false, 64>(a, stage, b, ph, j0 + p * 64, n0, tid);
+    };
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+    pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{});
+    return;
+  }
   float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int h = 0; h < MJ / 4; ++h) {          // 128 rows per pass: row block wm * MJ + j of the workgroup, eight per pass
@@ -807,6 +953,7 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
     p.alpha = alpha; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
     p.Lin = Lin; p.Cin = cv.cin; p.Cout = cv.cout; p.act = 0;
     p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
+    p.w2 = nullptr; p.bias2 = nullptr; p.alpha_mid = nullptr;
     int ph = 1;
     if (cv.stride > 1) {
       if (cv.stride % 2) return VAURA_ERR_SHAPE;
@@ -877,6 +1024,37 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
   }
   dim3 grid((a.jcount + BM - 1) / BM, cv.cout / BN, B * phases);
   VA_LAUNCH(conv_mfma_kernel, grid, dim3(256), 0, s, a);
+  return 0;
+}
+
+
+// A whole residual unit (7-tap dilated conv -> Snake -> 1 x 1 conv -> + residual) as ONE launch where one workgroup holds every channel
+// (C = 96: the codec's last block, a third of its activation bytes).  The codec is bound by its activation streams, not by the matrix
+// pipe (profiles/r04_codec_ablations.txt): fused, the intermediate activation (4 B per element written and read back) never leaves the
+// CU.  Same sums in the same order as the two launches: bit-identical (tests/test_gpu_generate.py).  Returns 1 when the unit is not
+// of that shape (the caller then launches the two convs), 0 when launched.  out_act must not alias `in` (neighbours read halo rows).
+static long long va_conv_units_fused = 0;
+static int launch_conv_unit(const vaura_conv& c7, const vaura_conv& c1, const float* in, const float* res, const float* alpha_mid,
+                            const float* alpha_next, float* out_raw, float* out_act, int B, int L, int pairs, hipStream_t s) {
+  if (pairs != 1 && pairs != 2 && pairs != 4) return 1;
+  if (va_debug_flags_get() & (0x200000u | 0x100000u)) return 1;       // debug flag bit 21: the two-launch form (bit 20: no 256-row instances at all)
+  if (c7.cin != BN || c7.cout != BN || c1.cin != BN || c1.cout != BN || c7.stride != 1 || c1.stride != 1 || c1.taps != 1 || c7.taps < 1 ||
+      (c7.taps - 1) * c7.dilation > XHALO || !c7.w || !c7.bias || !c1.w || !c1.bias || !alpha_mid || !alpha_next || !res || !out_act || (const float*)out_act == in)
+    return 1;
+  const int g256 = (L + 2 * BM - 1) / (2 * BM);
+  if ((int64_t)g256 * B < 384) return 1;
+  ConvPArgs p;
+  p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(c7.w); p.bias = c7.bias; p.res = res;
+  p.alpha = alpha_next; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
+  p.Lin = L; p.Lout = L; p.Cin = BN; p.Cout = BN; p.act = 0;
+  p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
+  p.NT = c7.taps; p.off_base = -((c7.taps - 1) / 2) * c7.dilation; p.off_step = c7.dilation;
+  p.ostride = 1; p.oshift0 = 0; p.jcount = L;
+  p.w2 = reinterpret_cast<const uint16_t*>(c1.w); p.bias2 = c1.bias; p.alpha_mid = alpha_mid;
+  ++va_conv_units_fused;
+  if (pairs == 4) VA_LAUNCH((conv_pair_kernel<3, true, true, 8, true>), dim3(g256, 1, B), dim3(256), 0, s, p);
+  else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true, false, 8, true>), dim3(g256, 1, B), dim3(256), 0, s, p);
+  else VA_LAUNCH((conv_pair_kernel<3, false, false, 8, true>), dim3(g256, 1, B), dim3(256), 0, s, p);
   return 0;
 }
 
@@ -1020,6 +1198,7 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
   p.Lin = Lin; p.Lout = Lout; p.Cin = Cin; p.Cout = Cout; p.NT = 1; p.off_base = 0; p.off_step = 1; p.ostride = 1;
   p.oshift0 = oshift; p.jcount = Lin; p.act = act;
   p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
+  p.w2 = nullptr; p.bias2 = nullptr; p.alpha_mid = nullptr;
   if (Cout % LBN == 0 && act != 0 && !(va_debug_flags_get() & 64)) {     // debug flag bit 6: the 128 x 96 conv tile instead
     const int ntiles = Cout / LBN;
     // debug flag bit 8: 256 x 192 tiles (512 threads, one workgroup per CU) — 30 % fewer operand bytes per flop, and measured
@@ -1150,9 +1329,21 @@ __global__ __launch_bounds__(256) void rvq_stage_kernel(float* __restrict__ resi
   if (tid == 0) codes[((size_t)(row / T) * K + k) * T + (row % T)] = fi;
 }
 
+// the codec's activation on its own (op-level entry vaura_snake): the same snake_f every conv epilogue applies
+__global__ __launch_bounds__(256) void snake_kernel(const float* __restrict__ x, const float* __restrict__ alpha, float* __restrict__ y,
+                                                    int64_t n, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = snake_f(x[i], alpha[i % C]);
+}
+
 extern "C" {
 
 long long vaura_debug_counter(int which) {
+  if (which == 1) {       // residual units launched as one kernel (launch_conv_unit)
+    const long long v = va_conv_units_fused;
+    va_conv_units_fused = 0;
+    return v;
+  }
   if (which != 0) return -1;
   const long long v = va_conv256_launches;
   va_conv256_launches = 0;
@@ -1196,11 +1387,15 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
     L *= c->rates[b];
     { float* t = R; R = Y; Y = t; t = A; A = Z; Z = t; }
     for (int u = 0; u < 3; ++u) {
+      const float* next_alpha = (u < 2) ? c->alpha_res[b][u + 1][0] : (b + 1 < c->n_blocks ? c->alpha_up[b + 1] : c->alpha_out);
+      // the whole unit in one launch where one workgroup holds every channel (the activated result goes to Y: neighbours still read A's halo rows)
+      rc = launch_conv_unit(c->res[b][u][0], c->res[b][u][1], A, R, c->alpha_res[b][u][1], next_alpha, (u < 2) ? R : nullptr, Y, B, L, pr, s);
+      if (rc < 0) return rc;
+      if (rc == 0) { float* t = A; A = Y; Y = t; continue; }
       // y = Snake2(conv7(Snake1(x)))  (Snake1 applied by the producer)
       rc = launch_conv(c->res[b][u][0], A, nullptr, c->alpha_res[b][u][1], nullptr, Y, B, L, pr, s);
       if (rc) return rc;
       // x = x + conv1(y); emit Snake_next(x)
-      const float* next_alpha = (u < 2) ? c->alpha_res[b][u + 1][0] : (b + 1 < c->n_blocks ? c->alpha_up[b + 1] : c->alpha_out);
       rc = launch_conv(c->res[b][u][1], Y, R, next_alpha, (u < 2) ? R : nullptr, A, B, L, pr, s);
       if (rc) return rc;
     }
@@ -1215,6 +1410,13 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
   } else {
     VA_LAUNCH(conv_out_kernel, dim3((L + 31) / 32, B), dim3(256), 0, s, A, c->conv_out.w, c->conv_out.bias, wav, L, C, pr);
   }
+  return 0;
+}
+
+int vaura_snake(const float* x, const float* alpha, float* y, int64_t rows, int C, vaura_stream_t s_) {
+  if (!x || !alpha || !y || rows <= 0 || C <= 0) return VAURA_ERR_ARG;
+  const int64_t n = rows * C;
+  VA_LAUNCH(snake_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(s_), x, alpha, y, n, C);
   return 0;
 }
 

@@ -626,6 +626,21 @@ class CodecConvOp:
         return out
 
 
+def snake(x: torch.Tensor, alpha: torch.Tensor, device="cuda:0") -> torch.Tensor:
+    """The codec's activation through ``vaura_snake`` (op-level parity tests): x (..., C) fp32 channels-last, alpha (C)."""
+    _require_cuda(device)
+    dev = torch.device(device)
+    with off_null_stream(dev) as caller:
+        xi = x.to(dev, torch.float32).contiguous()
+        al = alpha.to(dev, torch.float32).contiguous()
+        y = torch.empty_like(xi)
+        L.check(L.lib().vaura_snake(L.ptr(xi), L.ptr(al), L.ptr(y), xi.numel() // xi.shape[-1], xi.shape[-1], L.current_stream(dev)),
+                "vaura_snake")
+    if caller is not None:
+        y.record_stream(caller)
+    return y
+
+
 class CodecEncoderEngine:
     """DAC encode (waveform -> codes) on the HIP path; weights from a DAC-1.0.0-keyed state dict
     (``encoder.block.*``, ``quantizer.quantizers.N.{in_proj,codebook,out_proj}``).  Convolutions run on (hi, lo) fp16
