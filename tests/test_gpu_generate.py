@@ -691,8 +691,8 @@ def test_full_length_codec_decode_and_encode_match_the_oracle_on_the_256_row_ins
     got = dec.decode(codes.to(DEV))
     torch.cuda.synchronize()
     n256, nfused = int(L.lib().vaura_debug_counter(0)), int(L.lib().vaura_debug_counter(1))
-    # 4 x (up + 3 x 2) = 28 of the 30 convs; a residual unit launched as ONE 256-row kernel (C = 96: the last block's three) covers two of them
-    assert n256 + 2 * nfused >= 28 and nfused == 3, f"only {n256} conv launches + {nfused} fused units took the 256-row instances"
+    # 4 x (up + 3 x 2) = 28 of the 30 convs; a residual unit launched as ONE kernel (C = 96 and C = 192: the last two blocks' six) covers two of them
+    assert n256 + 2 * nfused >= 28 and nfused == 6, f"only {n256} conv launches + {nfused} fused units took the 256-row instances"
     # ... and the one-launch units are bit-identical to the two-launch form (debug flag bit 21), which is what the oracle is compared with below too
     L.lib().vaura_set_debug_flags(1 << 21)
     try:

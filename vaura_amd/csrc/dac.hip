@@ -604,6 +604,236 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// A whole residual unit — 7-tap dilated conv -> Snake -> 1 x 1 conv -> + residual -> raw / Snake / pairs — in one launch, for the
+// widths where ONE workgroup can hold every channel (C = 96: 256 rows per workgroup, C = 192: 128 rows).  The codec is bound by its
+// activation streams (profiles/r04_codec_ablations.txt); here the intermediate activation never exists in memory, not even in LDS:
+//  * the four waves split the ROWS (wave w owns 16 RB rows x all C columns: accumulators acc[C / 16][RB], 96 registers as before), so a
+//    wave ends the first conv holding every channel of its rows;
+//  * the first conv's weight tile is stored into LDS with its output channels permuted inside each group of 32 (row 16 i + 4 q + e of
+//    the tile image <- channel 32 (i / 2) + 8 q + 4 (i % 2) + e): a permutation of the M rows of the matrix instruction changes no
+//    sum, but now accumulator tiles 2 c and 2 c + 1 of lane group q hold channels 32 c + 8 q .. + 7 — which IS the B-operand fragment
+//    (row r16, k-octet q of chunk c) the second conv needs.  + bias, Snake(alpha_mid), (hi, lo) split happen in registers and the
+//    1 x 1 conv multiplies straight out of them;
+//  * the 1 x 1 conv is the main loop again with one tap and a register-resident activation: its weight tiles (96 output channels x 32,
+//    like every tile of this file) pass through the same two LDS buffers, C / 96 column tiles one after the other;
+//  * same matrix instructions on the same fragments in the same order as the two stand-alone launches: bit-identical results.
+template <int N, typename F>
+__device__ __forceinline__ void va_static_for(F&& f) {
+  if constexpr (N > 0) {
+    va_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int NCT, int RB, bool WS, bool XS>
+__global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
+  constexpr int C_ = 16 * NCT;               // channels = columns of the workgroup
+  constexpr int BMT = 64 * RB;               // rows of the workgroup
+  constexpr int KC = C_ / BK;                // 32-channel chunks (of both convs)
+  constexpr int XROWS_T = BMT + XHALO;
+  constexpr int WSTR = (C_ + 3 + 15) / 16 * 16, XSTR = (XROWS_T + 3 + 15) / 16 * 16, W2STR = (BN + 3 + 15) / 16 * 16;
+  constexpr int WS_ELEMS = 2 * (BK / 4) * WSTR, XS_ELEMS = (BK / 4) * XSTR;
+  constexpr int SP = BN + 4;                 // fp32 output tile: 64 rows x 96 columns
+  constexpr int W2_ELEMS = 2 * (BK / 4) * W2STR, ST_ELEMS = 64 * SP / 4;
+  constexpr int MAIN_ELEMS = WS_ELEMS + XS_ELEMS > W2_ELEMS + ST_ELEMS ? WS_ELEMS + XS_ELEMS : W2_ELEMS + ST_ELEMS;
+  constexpr int TAB_ELEMS = 2 * C_ / 4;      // alpha_mid and 1 / (alpha_mid + 1e-9) per channel
+  static_assert(NCT % 6 == 0 && (RB == 2 || RB == 4) && NCT * RB == 24, "96 channels x 256 rows or 192 x 128: 96 accumulator registers");
+  __shared__ u32x4 smem[MAIN_ELEMS + TAB_ELEMS];
+  auto coff = [](int kq) { return (kq & 1) + ((kq >> 2) << 1); };
+  auto Ws = [&](int buf, int kq, int row) -> u32x4& { return smem[(buf * (BK / 4) + kq) * WSTR + row + coff(kq)]; };
+  auto Xs = [&](int kq, int row) -> u32x4& { return smem[WS_ELEMS + kq * XSTR + row + coff(kq)]; };
+  auto W2s = [&](int buf, int kq, int row) -> u32x4& { return smem[(buf * (BK / 4) + kq) * W2STR + row + coff(kq)]; };
+  float* tab = reinterpret_cast<float*>(smem + MAIN_ELEMS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int j0 = blockIdx.x * BMT, b = blockIdx.z;
+  constexpr int cq = C_ / 4;                 // 16-B quads per row
+  const u32x4* in = reinterpret_cast<const u32x4*>(a.in) + (size_t)b * a.Lin * cq;
+  const u32x4* wbase = reinterpret_cast<const u32x4*>(a.w);
+  const int NT = a.NT, nk = NT * KC;
+  const int span = (NT - 1) * (a.off_step < 0 ? -a.off_step : a.off_step);
+  const int lo_off = a.off_base + (a.off_step < 0 ? (NT - 1) * a.off_step : 0);
+  const int xrows = BMT + span;
+  constexpr int WL = C_ * (BK / 4) / 256;                        // weight quads per thread per step (3 or 6)
+  constexpr int XL = (XROWS_T * (BK / 4) + 255) / 256;           // activation quads per thread per chunk
+
+  u32x4 wreg[WL], xreg[XL];
+  auto load_w = [&](int kt) {
+    const int c = kt / NT, t = kt - c * NT;
+    const u32x4* wt = wbase + (size_t)t * C_ * cq + c * (BK / 4);
+#pragma unroll
+    for (int i = 0; i < WL; ++i) { const int qd = tid + 256 * i; wreg[i] = wt[(size_t)(qd >> 3) * cq + (qd & 7)]; }
+  };
+  auto store_w = [&](int buf) {          // output channel ch -> tile-image row 32 (ch / 32) + 16 ((ch / 4) % 2) + 4 ((ch % 32) / 8) + ch % 4
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int qd = tid + 256 * i, ch = qd >> 3, w5 = ch & 31;
+      Ws(buf, qd & 7, (ch & ~31) + (((w5 >> 2) & 1) << 4) + ((w5 >> 3) << 2) + (w5 & 3)) = wreg[i];
+    }
+  };
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int qd = tid + 256 * i, row = qd >> 3, kq = qd & 7;
+      const int jr = j0 + lo_off + row;
+      xreg[i] = (row < xrows && jr >= 0 && jr < a.Lin) ? in[(size_t)jr * cq + c * (BK / 4) + kq] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) { const int qd = tid + 256 * i; if ((qd >> 3) < XROWS_T) Xs(qd & 7, qd >> 3) = xreg[i]; }
+  };
+
+  f32x4 acc[NCT][RB];
+#pragma unroll
+  for (int i = 0; i < NCT; ++i)
+#pragma unroll
+    for (int j = 0; j < RB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_w(0);
+  load_x(0);
+  store_w(0);
+  store_x();
+  for (int ch = tid; ch < C_; ch += 256) {
+    const float al = a.alpha_mid[ch];
+    tab[ch] = al;
+    tab[C_ + ch] = 1.0f / (al + 1e-9f);
+  }
+  __syncthreads();
+  int kt = 0;
+  for (int c = 0; c < KC; ++c) {
+    for (int t = 0; t < NT; ++t, ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_w(kt + 1);
+      if (t == NT - 1 && c + 1 < KC) load_x(c + 1);
+      const int shift = a.off_base + t * a.off_step - lo_off;
+      f16x8 xh[RB], xl[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        xh[j] = __builtin_bit_cast(f16x8, Xs(2 * g, shift + (wv * RB + j) * 16 + r16));
+        if constexpr (!XS) xl[j] = __builtin_bit_cast(f16x8, Xs(2 * g + 1, shift + (wv * RB + j) * 16 + r16));
+      }
+#pragma unroll
+      for (int ig = 0; ig < NCT; ig += 3) {
+        f16x8 wh[3], wl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          wh[i] = __builtin_bit_cast(f16x8, Ws(buf, 2 * g, (ig + i) * 16 + r16));
+          if constexpr (!WS && !XS) wl[i] = __builtin_bit_cast(f16x8, Ws(buf, 2 * g + 1, (ig + i) * 16 + r16));
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            if constexpr (!WS && !XS) acc[ig + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[ig + i][j], 0, 0, 0);
+            if constexpr (!XS) acc[ig + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[ig + i][j], 0, 0, 0);
+            acc[ig + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[ig + i][j], 0, 0, 0);
+          }
+      }
+      if (kt + 1 < nk) store_w(buf ^ 1);
+      if (t == NT - 1 && c + 1 < KC) {
+        __syncthreads();        // every wave is done with the block before it is overwritten
+        store_x();
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- the 1 x 1 conv's weight tiles: 96 output channels (column tile nt) x chunk c2, through the first two LDS buffers
+  const u32x4* w2q = reinterpret_cast<const u32x4*>(a.w2);
+  u32x4 w2reg[3];
+  auto load_w2 = [&](int nt, int c2) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; w2reg[i] = w2q[(size_t)(nt * BN + (qd >> 3)) * cq + c2 * (BK / 4) + (qd & 7)]; }
+  };
+  auto store_w2 = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; W2s(buf, qd & 7, qd >> 3) = w2reg[i]; }
+  };
+  load_w2(0, 0);      // (in flight under the Snake arithmetic below; the main loop ended with a barrier: its LDS is free)
+
+  // ---- first conv's epilogue in registers: + bias, Snake(alpha_mid), (hi, lo) split -> the second conv's B fragments
+  f16x8 yh[KC][RB], yl[KC][RB];
+  va_static_for<KC>([&](auto cc) {
+    constexpr int c2 = decltype(cc)::value;
+    const int ch = 32 * c2 + 8 * g;           // this lane's eight channels of the chunk: ch .. ch + 3 in tile 2 c2, ch + 4 .. ch + 7 in tile 2 c2 + 1
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + ch), b1 = *reinterpret_cast<const f32x4*>(a.bias + ch + 4);
+    const f32x4 al0 = *reinterpret_cast<const f32x4*>(tab + ch), al1 = *reinterpret_cast<const f32x4*>(tab + ch + 4);
+    const f32x4 iv0 = *reinterpret_cast<const f32x4*>(tab + C_ + ch), iv1 = *reinterpret_cast<const f32x4*>(tab + C_ + ch + 4);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const f32x4 v0 = acc[2 * c2][j] + b0, v1 = acc[2 * c2 + 1][j] + b1;
+      f16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s0 = snake_fi(v0[e], al0[e], iv0[e]), s1 = snake_fi(v1[e], al1[e], iv1[e]);
+        h[e] = (_Float16)s0; l[e] = (_Float16)(s0 - (float)h[e]);
+        h[e + 4] = (_Float16)s1; l[e + 4] = (_Float16)(s1 - (float)h[e + 4]);
+      }
+      yh[c2][j] = h;
+      yl[c2][j] = l;
+    }
+  });
+
+  // ---- second conv: column tiles of 96 output channels, k = the C channels held in registers
+  float* stage = reinterpret_cast<float*>(smem + W2_ELEMS);
+  constexpr int WPP = 4 / RB;                 // waves that own a 64-row pass (1 or 2)
+#pragma unroll 1
+  for (int nt = 0; nt < C_ / BN; ++nt) {
+    f32x4 acc2[BN / 16][RB];
+#pragma unroll
+    for (int i = 0; i < BN / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < RB; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nt > 0) load_w2(nt, 0);
+    store_w2(0);
+    __syncthreads();
+    va_static_for<KC>([&](auto cc) {
+      constexpr int c2 = decltype(cc)::value;
+      constexpr int buf = c2 & 1;
+      if (c2 + 1 < KC) load_w2(nt, c2 + 1);
+#pragma unroll
+      for (int ig = 0; ig < BN / 16; ig += 3) {
+        f16x8 wh[3], wl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          wh[i] = __builtin_bit_cast(f16x8, W2s(buf, 2 * g, (ig + i) * 16 + r16));
+          if constexpr (!WS && !XS) wl[i] = __builtin_bit_cast(f16x8, W2s(buf, 2 * g + 1, (ig + i) * 16 + r16));
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            if constexpr (!WS && !XS) acc2[ig + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], yh[c2][j], acc2[ig + i][j], 0, 0, 0);
+            if constexpr (!XS) acc2[ig + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], yl[c2][j], acc2[ig + i][j], 0, 0, 0);
+            acc2[ig + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], yh[c2][j], acc2[ig + i][j], 0, 0, 0);
+          }
+      }
+      if (c2 + 1 < KC) store_w2(buf ^ 1);
+      __syncthreads();
+    });
+    // 64 rows at a time through the fp32 tile (owned by wave p with 256 rows, by waves 2 p and 2 p + 1 with 128)
+#pragma unroll
+    for (int p = 0; p < BMT / 64; ++p) {
+      if (p > 0) __syncthreads();               // the previous pass's store is done with the tile
+      if (wv / WPP == p) {
+#pragma unroll
+        for (int i = 0; i < BN / 16; ++i)
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            const int row = ((wv % WPP) * RB + j) * 16 + r16, col = i * 16 + 4 * g;
+            *reinterpret_cast<f32x4*>(stage + row * SP + col) = acc2[i][j] + *reinterpret_cast<const f32x4*>(a.bias2 + nt * BN + col);
+          }
+      }
+      __syncthreads();
+      conv_tile_store<BN, SP, false, 64>(a, stage, b, 0, j0 + p * 64, nt * BN, tid);
+    }
+    if (nt + 1 < C_ / BN) __syncthreads();      // ... before the next column tile's passes reuse it
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Block-scaled fp8 variant (codec precision 3; BASELINE configs[4] "fp8 MFMA ... codec conv"): activations are e4m3 bytes
 // with one power-of-two (E8M0) scale per 32 channels of a row — written by the producer's epilogue above — weights are
 // e4m3 with one power-of-two scale per output channel, and a product is ONE v_mfma_scale_f32_16x16x128_f8f6f4 per 128 k
@@ -1038,23 +1268,32 @@ static int launch_conv_unit(const vaura_conv& c7, const vaura_conv& c1, const fl
                             const float* alpha_next, float* out_raw, float* out_act, int B, int L, int pairs, hipStream_t s) {
   if (pairs != 1 && pairs != 2 && pairs != 4) return 1;
   if (va_debug_flags_get() & (0x200000u | 0x100000u)) return 1;       // debug flag bit 21: the two-launch form (bit 20: no 256-row instances at all)
-  if (c7.cin != BN || c7.cout != BN || c1.cin != BN || c1.cout != BN || c7.stride != 1 || c1.stride != 1 || c1.taps != 1 || c7.taps < 1 ||
+  const int C = c7.cin;
+  if ((C != BN && C != 2 * BN) || c7.cout != C || c1.cin != C || c1.cout != C || c7.stride != 1 || c1.stride != 1 || c1.taps != 1 || c7.taps < 1 ||
       (c7.taps - 1) * c7.dilation > XHALO || !c7.w || !c7.bias || !c1.w || !c1.bias || !alpha_mid || !alpha_next || !res || !out_act || (const float*)out_act == in)
     return 1;
-  const int g256 = (L + 2 * BM - 1) / (2 * BM);
-  if ((int64_t)g256 * B < 384) return 1;
+  const int rows = C == BN ? 256 : 128;
+  const int gx = (L + rows - 1) / rows;
+  if ((int64_t)gx * B < 384) return 1;
   ConvPArgs p;
   p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(c7.w); p.bias = c7.bias; p.res = res;
   p.alpha = alpha_next; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
-  p.Lin = L; p.Lout = L; p.Cin = BN; p.Cout = BN; p.act = 0;
+  p.Lin = L; p.Lout = L; p.Cin = C; p.Cout = C; p.act = 0;
   p.act_fmt = 0; p.out_scale = nullptr; p.in_scale = nullptr; p.wscale = nullptr;
   p.NT = c7.taps; p.off_base = -((c7.taps - 1) / 2) * c7.dilation; p.off_step = c7.dilation;
   p.ostride = 1; p.oshift0 = 0; p.jcount = L;
   p.w2 = reinterpret_cast<const uint16_t*>(c1.w); p.bias2 = c1.bias; p.alpha_mid = alpha_mid;
   ++va_conv_units_fused;
-  if (pairs == 4) VA_LAUNCH((conv_pair_kernel<3, true, true, 8, true>), dim3(g256, 1, B), dim3(256), 0, s, p);
-  else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true, false, 8, true>), dim3(g256, 1, B), dim3(256), 0, s, p);
-  else VA_LAUNCH((conv_pair_kernel<3, false, false, 8, true>), dim3(g256, 1, B), dim3(256), 0, s, p);
+  const dim3 grid(gx, 1, B);
+  if (C == BN) {      // 96 channels: conv_pair_kernel's own fused epilogue (the row-split kernel's 256-row instance does not fit the register budget)
+    if (pairs == 4) VA_LAUNCH((conv_pair_kernel<3, true, true, 8, true>), grid, dim3(256), 0, s, p);
+    else if (pairs == 2) VA_LAUNCH((conv_pair_kernel<3, true, false, 8, true>), grid, dim3(256), 0, s, p);
+    else VA_LAUNCH((conv_pair_kernel<3, false, false, 8, true>), grid, dim3(256), 0, s, p);
+  } else {
+    if (pairs == 4) VA_LAUNCH((conv_unit_kernel<12, 2, true, true>), grid, dim3(256), 0, s, p);
+    else if (pairs == 2) VA_LAUNCH((conv_unit_kernel<12, 2, true, false>), grid, dim3(256), 0, s, p);
+    else VA_LAUNCH((conv_unit_kernel<12, 2, false, false>), grid, dim3(256), 0, s, p);
+  }
   return 0;
 }
 

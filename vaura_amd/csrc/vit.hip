@@ -590,33 +590,40 @@ __global__ __launch_bounds__(512) void vit_space_attn_mfma_kernel(const float* _
 }
 
 // The same dataflow on fp16 pairs (x = hi + lo, 22 significand bits; three v_mfma_f32_16x16x32_f16 per product like every linear
-// layer of this file): 5x fewer matrix cycles than the exact-fp32 instruction.  K as hi / lo planes in the k-major image of the
-// GEMM kernels ([kq = d / 8][key] quads of 8 halves: the fragment read of a 16-lane group is 16 consecutive quads and the four
-// groups of a ds_read_b128 service set fall on different banks because 208 % 16 == 0); V TRANSPOSED ([d][key], row stride 432 B
-// = 27 x 16: conflict-free 8-byte reads) because O^T = V^T . P^T sums over keys: a lane's 8 k slots are keys 4g .. 4g+3 of two
-// adjacent key tiles — the registers it already holds — and the matching V^T fragment is two 8-byte reads.
+// layer of this file): 5x fewer matrix cycles than the exact-fp32 instruction.
+// LDS images (round 4): K AND V as hi / lo planes in ONE row-major form, [key][64 channels] halves with 160-byte rows.
+//  * S = K . Q^T reads a K fragment (key r16 of a tile, k-octet 4 st + g) with one ds_read_b128: rows 160 B = 40 banks apart, so the 16
+//    rows of a service group (8 of octet g, the other 8 of octet g + 1: MI355X_MICROARCH.md, LDS) start on the 16 different multiples
+//    of 4 banks — conflict-free.
+//  * O^T = V^T . P^T sums over keys: a lane's 8 k slots are keys 4 g .. 4 g + 3 of two adjacent key tiles — the registers it already
+//    holds — and the matching V^T fragment comes from the row-major image with ds_read_b64_tr_b16 (the transposing read of gfx950:
+//    per 16-lane group a block of 4 keys x 16 channels, delivered channel-major); the two blocks of a 32-lane half are 8 consecutive
+//    keys of the same channels = 8 rows x 32 B on bank bases 0, 40, 16, 56, 32, 8, 48, 24: conflict-free.
+//  * staging is the same for both: one octet of one key per item, (hi, lo) as two ds_write_b128 to consecutive 16-byte slots.
+// Round 3 kept K k-major ([k-octet][key]: the 8 lanes that stage one key hit one bank, 8-way) and V transposed ([channel][key]: 56
+// two-byte stores per thread, most of them conflicting): SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.60 (profiles/r03_avclip_mfma.json).
 #define VP_KEYS (VS_NKT * 16)                      // 208
-#define VP_VSTRIDE 216                             // halves per V^T row (432 B)
+#define VP_ROWH 80                                 // halves per key row (160 B)
+#define VP_VROWS (((VS_NKT + 1) / 2) * 32)         // 224: the P.V instruction walks 32 keys at a time; rows past the last tile are zeros
 __global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ out_pair, int nf, int np,
                                                                   int D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   typedef _Float16 h8 __attribute__((ext_vector_type(8)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  h8* Kh = reinterpret_cast<h8*>(smraw);                                   // [8][208]
-  h8* Kl = Kh + 8 * VP_KEYS;
-  _Float16* Vh = reinterpret_cast<_Float16*>(Kl + 8 * VP_KEYS);            // [64][216] (+ 16 halves of slack)
-  _Float16* Vl = Vh + VHD * VP_VSTRIDE + 16;
+  typedef __fp16 fp4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  _Float16* Kh = reinterpret_cast<_Float16*>(smraw);                       // [208][80]
+  _Float16* Kl = Kh + VP_KEYS * VP_ROWH;
+  _Float16* Vh = Kl + VP_KEYS * VP_ROWH;                                   // [224][80]
+  _Float16* Vl = Vh + VP_VROWS * VP_ROWH;
   const int nk = np + 1;
   const int h = blockIdx.x, f = blockIdx.y, seg = blockIdx.z, tid = threadIdx.x;
   const int L = 1 + nf * np;
   const size_t row0 = (size_t)seg * L;
-  // Staging: EVERY global load of this thread is requested before the first is converted (4 x 2 quads of K, 7 quads of V: 60
-  // registers).  Round 2's loops loaded, converted and stored one item per iteration — 11 dependent global round trips per
-  // workgroup, ~17 of its ~26 us, for 3.5 us of matrix work (MFMA busy 0.14 in profiles/r03_avclip_mfma.json).
-  constexpr int KIT = (VP_KEYS * 8 + 511) / 512, VIT = (VP_VSTRIDE * (VHD / 4) + 511) / 512;
-  f32x4 kreg[KIT][2], vreg[VIT];
+  // Staging: EVERY global load of this thread is requested before the first is converted (4 x 2 quads of K and of V: 64 registers).
+  constexpr int KIT = (VP_KEYS * 8 + 511) / 512;
+  f32x4 kreg[KIT][2], vreg[KIT][2];
 #pragma unroll
-  for (int it = 0; it < KIT; ++it) {       // K: one octet of one key per item
+  for (int it = 0; it < KIT; ++it) {       // one octet of one key per item
     const int u = tid + it * 512, j = min(u >> 3, nk - 1), kq = u & 7;
     const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
     const f32x4* kp = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + D + h * VHD + 8 * kq);
@@ -624,17 +631,15 @@ __global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* _
     kreg[it][1] = kp[1];
   }
 #pragma unroll
-  for (int it = 0; it < VIT; ++it) {       // V^T: 4 channels of one key per item
-    const int u = tid + it * 512, j = min(u / (VHD / 4), nk - 1), c = u % (VHD / 4);
-    const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
-    vreg[it] = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + 2 * D + h * VHD)[c];
-  }
-#pragma unroll
   for (int it = 0; it < KIT; ++it) {
-    const int u = tid + it * 512, j = u >> 3, kq = u & 7;
-    if (u >= VP_KEYS * 8) break;
+    const int u = tid + it * 512, j = min(u >> 3, nk - 1), kq = u & 7;
+    const size_t kr = j == 0 ? row0 : row0 + 1 + (size_t)f * np + (j - 1);
+    const f32x4* vp = reinterpret_cast<const f32x4*>(qkv + kr * 3 * D + 2 * D + h * VHD + 8 * kq);
+    vreg[it][0] = vp[0];
+    vreg[it][1] = vp[1];
+  }
+  auto park = [&](_Float16* hp, _Float16* lp, const f32x4 a, const f32x4 b, int j, int kq) {
     h8 hi, lo;
-    const f32x4 a = kreg[it][0], b = kreg[it][1];
     const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -642,22 +647,26 @@ __global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* _
       hi[i] = (_Float16)x;
       lo[i] = (_Float16)(x - (float)hi[i]);
     }
-    Kh[kq * VP_KEYS + j] = hi;
-    Kl[kq * VP_KEYS + j] = lo;
+    *reinterpret_cast<h8*>(hp + j * VP_ROWH + 8 * kq) = hi;
+    *reinterpret_cast<h8*>(lp + j * VP_ROWH + 8 * kq) = lo;
+  };
+#pragma unroll
+  for (int it = 0; it < KIT; ++it) {
+    const int u = tid + it * 512;
+    if (u >= VP_KEYS * 8) break;
+    park(Kh, Kl, kreg[it][0], kreg[it][1], u >> 3, u & 7);
   }
 #pragma unroll
-  for (int it = 0; it < VIT; ++it) {
-    const int u = tid + it * 512, j = u / (VHD / 4), c = u % (VHD / 4);
-    if (u >= VP_VSTRIDE * (VHD / 4)) break;
-    const f32x4 v = j < nk ? vreg[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const _Float16 hi = (_Float16)v[i];
-      Vh[(4 * c + i) * VP_VSTRIDE + j] = hi;
-      Vl[(4 * c + i) * VP_VSTRIDE + j] = (_Float16)(v[i] - (float)hi);
-    }
+  for (int it = 0; it < KIT; ++it) {
+    const int u = tid + it * 512;
+    if (u >= VP_KEYS * 8) break;
+    park(Vh, Vl, vreg[it][0], vreg[it][1], u >> 3, u & 7);
   }
-  if (tid < 32) { Vh[VHD * VP_VSTRIDE + (tid & 15)] = (_Float16)0.f; Vl[VHD * VP_VSTRIDE + (tid & 15)] = (_Float16)0.f; }
+  if (tid < (VP_VROWS - VP_KEYS) * 8) {             // V rows 208 .. 223: multiplied by P = 0, so they must be finite
+    const h8 z = h8{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    *reinterpret_cast<h8*>(Vh + (VP_KEYS + (tid >> 3)) * VP_ROWH + 8 * (tid & 7)) = z;
+    *reinterpret_cast<h8*>(Vl + (VP_KEYS + (tid >> 3)) * VP_ROWH + 8 * (tid & 7)) = z;
+  }
   __syncthreads();
   const int lane = tid & 63, wv = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int nqt = (np + 15) / 16;
@@ -684,7 +693,8 @@ __global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* _
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const h8 kh = Kh[(4 * st + g) * VP_KEYS + kt * 16 + r16], kl = Kl[(4 * st + g) * VP_KEYS + kt * 16 + r16];
+        const h8 kh = *reinterpret_cast<const h8*>(Kh + (kt * 16 + r16) * VP_ROWH + 8 * (4 * st + g));
+        const h8 kl = *reinterpret_cast<const h8*>(Kl + (kt * 16 + r16) * VP_ROWH + 8 * (4 * st + g));
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[st], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[st], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[st], acc, 0, 0, 0);
@@ -725,9 +735,14 @@ __global__ __launch_bounds__(512) void vit_space_attn_pair_kernel(const float* _
       }
 #pragma unroll
       for (int dt = 0; dt < VHD / 16; ++dt) {
-        const int off = (dt * 16 + r16) * VP_VSTRIDE + 32 * mp + 4 * g;
-        const h4 a0 = *reinterpret_cast<const h4*>(Vh + off), a1 = *reinterpret_cast<const h4*>(Vh + off + 16);
-        const h4 b0 = *reinterpret_cast<const h4*>(Vl + off), b1 = *reinterpret_cast<const h4*>(Vl + off + 16);
+        // transposing reads: lane 4 q + p of a 16-lane group addresses key 32 mp + 4 g + q, channels 16 dt + 4 p .. + 3, and receives
+        // channel 16 dt + r16 of the group's four keys (EXEC is all ones here: the loop over q tiles is wave-uniform)
+        const int off = (32 * mp + 4 * g + (r16 >> 2)) * VP_ROWH + dt * 16 + 4 * (r16 & 3);
+        typedef __attribute__((address_space(3))) fp4* lds_fp4;
+        const h4 a0 = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp4)(Vh + off)));
+        const h4 a1 = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp4)(Vh + off + 16 * VP_ROWH)));
+        const h4 b0 = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp4)(Vl + off)));
+        const h4 b1 = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp4)(Vl + off + 16 * VP_ROWH)));
         const h8 vh = h8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         const h8 vl = h8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oacc[dt], 0, 0, 0);
@@ -785,7 +800,7 @@ static int divided_attention(const vaura_vit* v, const vaura_vit_attn& at, const
                 v->n_patches, D);
   } else {
     if (v->n_patches + 1 <= VS_NKT * 16 && !(va_debug_flags_get() & (128 | 2048))) {   // the fp16-pair MFMA kernel
-      const size_t sm = 2 * 8 * VP_KEYS * 16 + 2 * (VHD * VP_VSTRIDE + 16) * 2;      // 108 KB of the CU's 160 KB
+      const size_t sm = (size_t)2 * (VP_KEYS + VP_VROWS) * VP_ROWH * 2;               // 135 KB of the CU's 160 KB
       static unsigned long long big_lds_p = 0;
       if (va_big_lds_once(reinterpret_cast<const void*>(vit_space_attn_pair_kernel), sm, &big_lds_p)) return VAURA_ERR_STATE;
       VA_LAUNCH(vit_space_attn_pair_kernel, dim3(v->heads, v->n_frames, n_seg), dim3(512), sm, s, (const float*)v->ws_qkv, v->ws_a, v->n_frames,
