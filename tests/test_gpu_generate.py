@@ -769,6 +769,33 @@ def test_range_guard_raises_instead_of_decoding_garbage():
     assert int(tok.min()) >= 0 and int(tok.max()) < 1024
 
 
+@pytest.mark.parametrize("precision", ["f16pair", "f16", "f16pair_w8"])
+def test_one_launch_residual_units_are_bit_identical_to_two_launches(precision):
+    """csrc/dac.hip: a residual unit (7-tap dilated conv -> Snake -> 1 x 1 conv -> + residual) of the last two decoder blocks (C = 192:
+    conv_unit_kernel, C = 96: conv_pair_kernel<..., FUSE>) runs as ONE launch wherever >= 384 workgroups remain; debug flag bit 21 keeps
+    the two launches.  Same matrix instructions on the same fragments in the same order: the waveform must be BIT-identical, in every
+    pair-arithmetic precision (each has its own kernel instance), at a batch / length other than the bench's (B = 3, T = 130: six
+    one-launch units, asserted through the library's counter), both sequence ends and the clip boundaries included."""
+    from vaura_amd import _lib as L
+    ccfg = synth.FULL_CODEC
+    sd = synth.codec_state_dict(ccfg, seed=4)
+    codes = torch.randint(0, 1024, (3, 9, 130), generator=torch.Generator().manual_seed(8)).to(DEV)
+    dec = CodecEngine(ccfg, sd, DEV, precision=precision)
+    try:
+        L.lib().vaura_debug_counter(1)
+        one = dec.decode(codes).clone()
+        torch.cuda.synchronize()
+        assert int(L.lib().vaura_debug_counter(1)) == 6
+        L.lib().vaura_set_debug_flags(1 << 21)
+        two = dec.decode(codes).clone()
+        torch.cuda.synchronize()
+        assert int(L.lib().vaura_debug_counter(1)) == 0
+    finally:
+        L.lib().vaura_set_debug_flags(0)
+    assert torch.isfinite(one).all() and float(one.abs().max()) > 0.01
+    assert torch.equal(one, two), float((one - two).abs().max())
+
+
 @pytest.mark.parametrize("wdtype", ["h2", "h1"])
 def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
     """The fp16-plane storage keeps ONE power-of-two scale per output row.  Rows that stress it: a 100-sigma outlier (ordinary
