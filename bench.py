@@ -460,7 +460,7 @@ def main():
         for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_bench_kernel_stats.csv")), reverse=True):
             try:
                 import csv
-                for row in csv.DictReader(open(os.path.join(REPO, "profiles", cand))):
+                for row in csv.DictReader(l for l in open(os.path.join(REPO, "profiles", cand)) if not l.startswith("#")):   # (the summary starts with a comment line)
                     if row.get("Name", "").replace("void ", "").split("(")[0].strip() == kname:
                         avg_us = float(row["AverageNs"]) * 1e-3
                         rocprof = {"source": f"profiles/{cand}", "avg_us_per_launch": round(avg_us, 3), "calls": int(row["Calls"]),
