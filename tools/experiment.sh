@@ -7,6 +7,8 @@
 #                                       whole 228-step graph-replayed loops of the PRODUCT library, both storages, + per-stage eager averages
 #   stamps [flags ..]                   in-kernel s_memrealtime timeline of the one-launch MLP / layer-tail kernels (diagnostic build;
 #                                       ALLWAVES=1: every wave records — perturbs heavily)
+#   lib-ab [tags ..]                    whole 228-step loops on experiment builds (`python -m vaura_amd.csrc.build --tag T -DX=..` -> libvaura_hip_T.so) next to the
+#                                       product library, two rounds, both storages
 #   graph-steps                         decode steps per graph launch (debug flag bits 24..27): 1 / 4 / 12, alternating
 #   chains                              the batch as 2 / 4 independent decode chains on separate streams against one chain of all rows
 #   plain-stores                        write-through output stores (product) against ordinary ones (build --plain-stores), alternating
@@ -53,6 +55,11 @@ stamps)
     python3 tools/engine_stamps.py $OUT/st_${w}_$f.bin | tee $OUT/stamps_${w}_f$f.txt
     rm -f $OUT/st_${w}_$f.bin
   done; done ;;
+lib-ab)
+  pmc_driver
+  for w in h2 h1; do for rep in 1 2; do for t in "" "$@"; do
+    echo "$w lib${t:+_}$t: $(timeout 300 /tmp/pmc_driver vaura_amd/csrc/libvaura_hip${t:+_}$t.so --time 5 --flags 0 --weights $w 2>&1 | grep 'loop of 228' | cut -c1-120)"
+  done; done; done | tee $OUT/lib_ab.log ;;
 graph-steps)
   pmc_driver
   for w in h2 h1; do for k in 1 4 12 1 4 12; do

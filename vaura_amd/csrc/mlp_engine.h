@@ -17,6 +17,27 @@
 #pragma once
 #include "gemv3_kernel.h"
 
+// Run-ahead throttle (round 4, second half).  A CU serves its vector-memory requests in order: the seven waves' run-ahead requests,
+// issued the moment their products are done, sit in front of wave 0's epilogue stores, and a hand-off passes only when the SLOWEST
+// producer has published (stamps: publish 5.3 us behind the products where the 64 workgroups without a run-ahead need 2.9).  Holding
+// the whole run-ahead until the stores are issued lost (the weights then land late); holding PART of it wins: waves 1..7 request
+// Q2 quarters of their w2 slice (phase 2) / PRE3 of their three qkv k-groups (phase 3) at once and the rest when wave 0 has issued its
+// stores (an LDS word).  Measured on whole loops (tools/experiment.sh lib-ab, profiles/r04_ab_mlp_engine.txt): two planes best at
+// (2, 1): 211.3 -> 202.0 ms; one plane at (1, 2): 167.0 -> 161.6 ms; neighbours are 1-4 % worse, no hold at all is ablation bit 3.
+// -DMLPE_Q2 / -DMLPE_PRE3 override both storages (experiment builds).
+template <int WT>
+struct MlpeThrottle {
+#ifdef MLPE_Q2
+  static constexpr int Q2 = MLPE_Q2;
+#else
+  static constexpr int Q2 = WT == 2 ? 2 : 1;
+#endif
+#ifdef MLPE_PRE3
+  static constexpr int PRE3 = MLPE_PRE3;
+#else
+  static constexpr int PRE3 = WT == 2 ? 1 : 2;
+#endif
+};
 struct MlpEngineArgs {
   Gemv3Args p1;            // w1||w3: W, XP (h planes), ss_in, outp (ffn planes), N = ffn_dim, rows, R = 1, eps, k_total, wscale
   Gemv3Args p2;            // w2: W, XP (= p1.outp), res / out (h), outp (h planes), gain_out, ss_out, N = d_model, wscale
@@ -249,6 +270,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         v[t] = sacc * rinv;
       }
       gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
+      if (lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the held part of the other waves' run-ahead (phase 2)
       // (Measured and rejected, round 4: holding the other waves' run-ahead requests back until these stores are in the CU's memory
       // pipeline.  A CU serves its vector-memory requests in order, so the publish waits behind the seven waves' 224 KB of requests
       // — 2.6 us median in the stamps — and with the hold it comes 2.8 us earlier; but the run-ahead then starts 2.3 us later, wave
@@ -287,25 +309,51 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     //      behind its own weight requests (a wave's vector-memory counter retires in order), which is about when the slowest
     //      producer has published anyway, and nothing of the weight stream is left for after the hand-off.
     u32x4 wreg[G2 - PL > 0 ? G2 - PL : 1][2][WH];
-    auto prefetch_w2 = [&]() {
-      const unsigned char* src = static_cast<const unsigned char*>(a.W) + ((size_t)tile * KG + 2 * (size_t)(w * G2)) * BS + lane * 16;
+    // the slice in four quarters: 0, 1 = the LDS-DMA half (k-group pairs [0, PL)), 2, 3 = the register half
+    auto prefetch_q = [&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      if constexpr (Q < 2) {
+        const unsigned char* src = static_cast<const unsigned char*>(a.W) + ((size_t)tile * KG + 2 * (size_t)(w * G2)) * BS + lane * 16;
 #pragma unroll
-      for (int c = 0; c < 2 * PL; ++c)
-#pragma unroll
-        for (int hh = 0; hh < WH; ++hh)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(c * WH + hh) * 1024),
-                                           (__attribute__((address_space(3))) void*)(myring + (c * WH + hh) * 1024), 16, 0, 2 /* nt */);
-#pragma unroll
-      for (int j = PL; j < G2; ++j) {
-        const int soff = (tile * KG + 2 * (w * G2 + j)) * BS;
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
+        for (int c = Q * PL; c < (Q + 1) * PL; ++c)
 #pragma unroll
           for (int hh = 0; hh < WH; ++hh)
-            wreg[j - PL][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(c * WH + hh) * 1024),
+                                             (__attribute__((address_space(3))) void*)(myring + (c * WH + hh) * 1024), 16, 0, 2 /* nt */);
+      } else {
+        constexpr int HALF = (G2 - PL) / 2;
+#pragma unroll
+        for (int j = PL + (Q - 2) * HALF; j < (Q == 2 ? PL + HALF : G2); ++j) {
+          const int soff = (tile * KG + 2 * (w * G2 + j)) * BS;
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int hh = 0; hh < WH; ++hh)
+              wreg[j - PL][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
+        }
       }
     };
-    if (!(e.abl & 4)) prefetch_w2();
+    auto prefetch_w2 = [&]() {
+      prefetch_q(std::integral_constant<int, 0>{}); prefetch_q(std::integral_constant<int, 1>{});
+      prefetch_q(std::integral_constant<int, 2>{}); prefetch_q(std::integral_constant<int, 3>{});
+    };
+    if (!(e.abl & 8) && !(e.abl & 4)) {
+      // partial hold: waves 1..7 request MLPE_Q2 quarters of their slice at once and the rest only when wave 0's epilogue stores are in
+      // the CU's memory pipeline (ablation bit 3: no hold, round 4's first form); wave 0 comes here behind its publish and holds nothing
+      constexpr int Q2 = MlpeThrottle<WT>::Q2;
+      const bool hold = wid != 0;
+      if (!hold || Q2 > 0) prefetch_q(std::integral_constant<int, 0>{});
+      if (!hold || Q2 > 1) prefetch_q(std::integral_constant<int, 1>{});
+      if (!hold || Q2 > 2) prefetch_q(std::integral_constant<int, 2>{});
+      if (!hold || Q2 > 3) prefetch_q(std::integral_constant<int, 3>{});
+      if (hold && Q2 < 4) {
+        while (__hip_atomic_load(arrive + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag) __builtin_amdgcn_s_sleep(1);
+        if (Q2 < 1) prefetch_q(std::integral_constant<int, 0>{});
+        if (Q2 < 2) prefetch_q(std::integral_constant<int, 1>{});
+        if (Q2 < 3) prefetch_q(std::integral_constant<int, 2>{});
+        if (Q2 < 4) prefetch_q(std::integral_constant<int, 3>{});
+      }
+    } else if (!(e.abl & 4)) prefetch_w2();
     if (wid != 0) VA_STAMP(stamps, 3);                 // waves 1..7: w2 slice requested
 
     // ---- hand-off: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest
@@ -414,20 +462,38 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       const int lane16 = lane * 16;
       const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(aq.W), 0, -16, 0x00020000);
       u32x4 wq[TQ][G][WH];
+      auto load_wq_g = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) {
+          const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
+#pragma unroll
+          for (int hh = 0; hh < WH; ++hh)
+            wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+        }
+      };
       auto load_wq = [&]() {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-          for (int t = 0; t < TQ; ++t) {
-            const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
-#pragma unroll
-            for (int hh = 0; hh < WH; ++hh)
-              wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
-          }
+        load_wq_g(std::integral_constant<int, 0>{});
+        load_wq_g(std::integral_constant<int, 1>{});
+        load_wq_g(std::integral_constant<int, 2>{});
       };
       if (lane == 0) __hip_atomic_store(arrive2 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
-      if (wid != 0) load_wq();
+      if (wid != 0) {
+        if (!(e.abl & 8)) {   // PRE3 of the three k-groups at once, the rest once wave 0's phase-2 stores are in the memory pipeline
+          constexpr int MLPE_PRE3_ = MlpeThrottle<WT>::PRE3;
+          if (MLPE_PRE3_ > 0) load_wq_g(std::integral_constant<int, 0>{});
+          if (MLPE_PRE3_ > 1) load_wq_g(std::integral_constant<int, 1>{});
+          if (MLPE_PRE3_ > 2) load_wq_g(std::integral_constant<int, 2>{});
+          if (MLPE_PRE3_ < 3)
+            while (__hip_atomic_load(arrive + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag) __builtin_amdgcn_s_sleep(1);
+          if (MLPE_PRE3_ < 1) load_wq_g(std::integral_constant<int, 0>{});
+          if (MLPE_PRE3_ < 2) load_wq_g(std::integral_constant<int, 1>{});
+          if (MLPE_PRE3_ < 3) load_wq_g(std::integral_constant<int, 2>{});
+        } else {
+          load_wq();
+        }
+      }
       if (wid < TQ) wsq = *reinterpret_cast<const f32x4*>(aq.wscale + (size_t)(tile0q + wid) * 16 + 4 * q);
       if (wid == 0) {
         mlpe_wait_words(arrive2, ltag);
@@ -439,6 +505,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
         v *= ws2;
         if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
+        if (lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         // publish phase 2: h, its partial sums of squares and its planes are out (write-through), drained, then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 256 + bid), "v"(epoch) : "memory");
