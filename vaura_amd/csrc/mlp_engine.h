@@ -25,6 +25,9 @@
 // stores (an LDS word).  Measured on whole loops (tools/experiment.sh lib-ab, profiles/r04_ab_mlp_engine.txt): two planes best at
 // (2, 1): 211.3 -> 202.0 ms; one plane at (1, 2): 167.0 -> 161.6 ms; neighbours are 1-4 % worse, no hold at all is ablation bit 3.
 // -DMLPE_Q2 / -DMLPE_PRE3 override both storages (experiment builds).
+#ifndef MLPE_REL
+#define MLPE_REL 0        // 1: the held part is released behind the publish (drained stores + flag) instead of behind the stores' issue
+#endif
 template <int WT>
 struct MlpeThrottle {
 #ifdef MLPE_Q2
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         v[t] = sacc * rinv;
       }
       gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
-      if (lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the held part of the other waves' run-ahead (phase 2)
+      if (!MLPE_REL && lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the held part of the other waves' run-ahead (phase 2)
       // (Measured and rejected, round 4: holding the other waves' run-ahead requests back until these stores are in the CU's memory
       // pipeline.  A CU serves its vector-memory requests in order, so the publish waits behind the seven waves' 224 KB of requests
       // — 2.6 us median in the stamps — and with the hold it comes 2.8 us earlier; but the run-ahead then starts 2.3 us later, wave
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       // publish: this wave stored the workgroup's whole ffn tile (write-through); drained, then the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + bid), "v"(epoch) : "memory");
+      if (MLPE_REL && lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       VA_STAMP(stamps, 3);                             // wave 0: published
     }
   }
@@ -505,10 +509,11 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
         v *= ws2;
         if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
-        if (lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         // publish phase 2: h, its partial sums of squares and its planes are out (write-through), drained, then the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 256 + bid), "v"(epoch) : "memory");
+        if (MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         load_wq();
       }
       (void)mlpe_poll_flags(e.flags + 256, 48, epoch, e, wid, lane);
