@@ -263,6 +263,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         if (all) break;
         __builtin_amdgcn_s_sleep(1);
       }
+#ifdef MLPE_DIAG       // diagnostic stamps build with -DMLPE_DIAG: slot 1 <- wave 0 has seen all eight waves' phase-1 tiles, slot 5 <- its stores are issued
+      VA_STAMP(stamps, 1);
+#endif
       f32x4 v[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -273,6 +276,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         v[t] = sacc * rinv;
       }
       gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
+#ifdef MLPE_DIAG
+      VA_STAMP(stamps, 5);
+#endif
       if (!MLPE_REL && lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the held part of the other waves' run-ahead (phase 2)
       // (Measured and rejected, round 4: holding the other waves' run-ahead requests back until these stores are in the CU's memory
       // pipeline.  A CU serves its vector-memory requests in order, so the publish waits behind the seven waves' 224 KB of requests
@@ -402,7 +408,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     VA_WAIT_VM(0);
+#ifndef MLPE_DIAG
     VA_STAMP(stamps, 5);                               // (diagnostic build) weights and planes landed
+#endif
     f32x4 acc[2][NACC];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
