@@ -848,21 +848,23 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
     assert err < 3e-5 * max(1.0, float(lg_ref.abs().max())), err
 
 
+@pytest.mark.parametrize("clips", [6, 3])
 @pytest.mark.parametrize("wdtype", ["h2", "h1"])
-def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype):
+def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     """csrc/mlp_engine.h, the default where eligible: the MLP of a layer (w1||w3 + SwiGLU -> w2 + residual) as ONE launch with an
     in-launch hand-off, w2's weights requested ahead of it (debug flag bit 2: every GEMV its own launch; bit 3: the experimental
     three-phase launch that takes wo in as well).  Same products in the same order as the separate launches: teacher-forced
     logits must be BIT-identical, tokens (greedy + CFG, and Philox-sampled) identical, through the eager path and through the
-    captured step graph, and no consumer may have given up waiting (status word clean).  12 decoder rows = both row halves live
-    (the eligible shape)."""
+    captured step graph, and no consumer may have given up waiting (status word clean).  6 clips x cfg = 12 decoder rows (both row
+    halves live) and 3 clips = 6 rows (configs[3]'s regime: one live half; the separate launches then use one workgroup per tile, the
+    one-launch form keeps its (tile, row half) workgroups and the second half multiplies zeros)."""
     from vaura_amd import _lib as L
     cfg = synth.tiny_sampler(3)
     sd = synth.sampler_state_dict(cfg, seed=101, round_bf16=(wdtype == "h1"))
     eng = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
-    feats = synth.video_features(6, seed=102).to(DEV)
-    idx = torch.randint(0, 1024, (12, 9, 20), generator=torch.Generator().manual_seed(103)).to(DEV)
-    f12 = synth.video_features(12, seed=104).to(DEV)
+    feats = synth.video_features(clips, seed=102).to(DEV)
+    idx = torch.randint(0, 1024, (2 * clips, 9, 20), generator=torch.Generator().manual_seed(103)).to(DEV)
+    f12 = synth.video_features(2 * clips, seed=104).to(DEV)
     out = {}
     try:
         # the default (w1||w3 -> w2 -> next layer's qkv in one launch) | + attention and wo in one launch (experiment) | qkv separate |

@@ -938,7 +938,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
   return 0;
 }
 
-// attention (single-round-trip kernel) + wo of one layer as one launch; the caller checked va_mlp_engine_eligible, rows in 9..16,
+// attention (single-round-trip kernel) + wo of one layer as one launch; the caller checked va_mlp_engine_eligible, rows in 1..16,
 // n_head == 16, max_len <= 256.  flags: 256 words.  awo.wscale is filled in here (the scales follow the packed tiles).
 int va_launch_attn_wo(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out, uint16_t* outp,
                       int rows, int n_head, int max_len, const int32_t* state, const Gemv3Args& awo, uint32_t* flags, int layer, hipStream_t s) {

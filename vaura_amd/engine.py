@@ -128,7 +128,7 @@ class DecoderEngine:
                  one_launch_mlp: bool = True):
         """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "f32" (``resolve_weight_dtype``).
         one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
-        is eligible (9..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
+        is eligible (1..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
         decode loop).  Its consumers wait for producers of the SAME launch, so every workgroup must become resident: pass False
         when several processes share this GPU (two such launches from two processes can starve each other until their bounded
         waits give up — reported by ``check_status``, never silent)."""
