@@ -343,6 +343,19 @@ def test_long_context_single_pass_against_live_oracle():
     got = eng.generate_codes(feats.to(DEV), 300).cpu()
     assert eng.max_len >= 1024
     assert torch.equal(got, ref), float((got == ref).float().mean())
+    # the range-split attention merges its partials inside the launch (the last split of a (row, head) to arrive); debug flag bit 19 keeps
+    # the merge as its own launch: same sums in the same order, so the very same tokens, eager and through the captured graph
+    from vaura_amd import _lib as L
+    try:
+        L.lib().vaura_set_debug_flags(1 << 19)
+        eng._free_graph()
+        two = eng.generate_codes(feats.to(DEV), 300).cpu()
+        two_eager = eng.generate_codes(feats.to(DEV), 300, use_graph=False).cpu()
+    finally:
+        L.lib().vaura_set_debug_flags(0)
+        eng._free_graph()
+    assert torch.equal(two, got) and torch.equal(two_eager, got)
+    assert torch.equal(eng.generate_codes(feats.to(DEV), 300, use_graph=False).cpu(), got)
 
 
 @pytest.mark.parametrize("B,cfg_scale,pass_positions", [(2, 1.0, 32), (3, 6.0, 32), (10, 6.0, 32), (3, 6.0, 192), (2, 1.0, 8)])

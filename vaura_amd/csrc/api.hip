@@ -147,7 +147,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
     rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
-                             d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s);
+                             d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s,
+                             d->ws_sync ? d->ws_sync + 448 : nullptr);      // words 448.. : arrival counts of the range-split attention
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     }

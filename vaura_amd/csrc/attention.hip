@@ -690,20 +690,66 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
       denom += f * wl[w];
       o += wacc[w][tid] * f;
     }
-    reinterpret_cast<f32x4*>(pp)[tid] = o;
-    if (tid == 0) { pp[HD] = M; pp[HD + 1] = denom; }
+    va_st16(reinterpret_cast<f32x4*>(pp) + tid, o);      // write-through: the last split to arrive may merge them inside this launch
+    if (tid == 0) { va_st4(pp + HD, M); va_st4(pp + HD + 1, denom); }
   }
+}
+
+// merge of the n_split (<= 8) partials of one (row, head) by thread tid < HD / 4.  FRESH: the partials were written by other workgroups
+// of the SAME launch (write-through): read them past the caches (sc1) — all of them requested before the one wait.
+template <int HD, bool FRESH>
+__device__ __forceinline__ void attention_combine(const float* __restrict__ pp, float* __restrict__ out, uint16_t* __restrict__ outp,
+                                                  int n_head, int n_split, int h, int row, int tid) {
+  float Mz[8], dz[8];
+  f32x4 oz[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z) {
+    const float* pz = pp + min(z, n_split - 1) * ATT_PART_STRIDE(HD);      // slots past the last split re-read it and are not used
+    if constexpr (FRESH) {
+      asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(Mz[z]) : "v"(pz + HD) : "memory");
+      asm volatile("global_load_dword %0, %1, off sc1" : "=&v"(dz[z]) : "v"(pz + HD + 1) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(oz[z]) : "v"(pz + 4 * tid) : "memory");
+    } else {
+      Mz[z] = pz[HD];
+      dz[z] = pz[HD + 1];
+      oz[z] = *reinterpret_cast<const f32x4*>(pz + 4 * tid);
+    }
+  }
+  if constexpr (FRESH) {
+    // (the outputs above are early-clobber asm results the compiler cannot track in flight: one explicit wait, tied to every register)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int z = 0; z < 8; ++z) asm volatile("" : "+v"(Mz[z]), "+v"(dz[z]), "+v"(oz[z]));
+  }
+  float M = -INFINITY;
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (z < n_split) M = fmaxf(M, Mz[z]);                                  // finite: the last split holds the new position
+  float denom = 0.f;
+  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    if (z < n_split) {
+      const float f = expf(Mz[z] - M);
+      denom += f * dz[z];
+      o += oz[z] * f;
+    }
+  o *= 1.0f / denom;
+  const int D = n_head * HD;
+  va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(row, (h * HD) / 4 + tid, D), o);
+  if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
 }
 
 template <int HD>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
     const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
     const float* __restrict__ qkv2, const float* __restrict__ rope, int n_head, int max_len, int pos_host,
-    float* __restrict__ part) {
+    float* __restrict__ part, uint32_t* __restrict__ arrivals, float* __restrict__ out, uint16_t* __restrict__ outp) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
   __shared__ float wm[ATT1_THREADS / 64], wl[ATT1_THREADS / 64];
+  __shared__ int s_last;
   const int h = blockIdx.x, row = blockIdx.y, z = blockIdx.z, n_split = gridDim.z;
   const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos)
   const bool last = z == n_split - 1;                // owner of the new position
@@ -719,6 +765,24 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
     case 3: attention_split_body<HD, 3>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
     default: attention_split_body<HD, 4>(qkv, qkv2, rope, kc, vc, pp, n_head, pos, lo, hi, last, sqkv, wacc, wm, wl); break;
   }
+  // The merge inside this launch (arrivals != nullptr: one zero-initialised word per (row, head), left at zero): the partial of this
+  // split is out write-through and drained, the (row, head)'s arrival count moves (device-scope atomic), and the LAST of its n_split
+  // workgroups to arrive reads all partials past the caches and does what attention_combine_kernel does — same sums, same order.
+  // One launch and one kernel boundary less per layer wherever the range is split (long caches with few rows: configs[3]).
+  if (arrivals) {
+    if (threadIdx.x < 64) {      // wave 0 holds the threads that stored the partial
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) {
+        uint32_t* cnt = arrivals + (size_t)row * n_head + h;
+        const uint32_t n = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = n == (uint32_t)n_split - 1u;
+        if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < QUADS)
+      attention_combine<HD, true>(part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD), out, outp, n_head, n_split, h, row, threadIdx.x);
+  }
 }
 
 template <int HD>
@@ -727,21 +791,7 @@ __global__ __launch_bounds__(64) void attention_combine_kernel(const float* __re
   constexpr int QUADS = HD / 4;
   const int h = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
   if (tid >= QUADS) return;
-  const float* pp = part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD);
-  float M = -INFINITY;
-  for (int z = 0; z < n_split; ++z) M = fmaxf(M, pp[z * ATT_PART_STRIDE(HD) + HD]);   // finite: the last split holds the new position
-  float denom = 0.f;
-  f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < n_split; ++z) {
-    const float* pz = pp + z * ATT_PART_STRIDE(HD);
-    const float f = expf(pz[HD] - M);
-    denom += f * pz[HD + 1];
-    o += reinterpret_cast<const f32x4*>(pz)[tid] * f;
-  }
-  o *= 1.0f / denom;
-  const int D = n_head * HD;
-  va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(row, (h * HD) / 4 + tid, D), o);
-  if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
+  attention_combine<HD, false>(part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD), out, outp, n_head, n_split, h, row, tid);
 }
 
 // rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
@@ -917,14 +967,16 @@ int va_attention_splits(int rows, int n_head, int max_len) {
 
 int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
-                        float* part, int n_split, hipStream_t s) {
+                        float* part, int n_split, hipStream_t s, uint32_t* arrivals) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
     if (n_split > 8) return VAURA_ERR_ARG;
+    // arrivals (rows * n_head zeroed words, e.g. the decoder's ws_sync + 448): the last split to arrive merges; debug flag bit 19: own launch
+    if (va_debug_flags_get() & 0x80000u) arrivals = nullptr;
     VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2,
-              rope, n_head, max_len, pos_host, part);
-    VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split);
+              rope, n_head, max_len, pos_host, part, arrivals, out, outp);
+    if (!arrivals) VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split);
     return 0;
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
