@@ -156,7 +156,7 @@ typedef struct vaura_decoder {
                                 rows*n_head < 256 and max_len > 256 (vaura_attention_splits); NULL -> never split       */
   uint32_t* ws_sync;         /* optional 768 words (zeroed once by the caller): producer flags of the launches that hand activations over INSIDE the
                                 launch (csrc/mlp_engine.h: w1||w3 -> w2 -> next layer's qkv; csrc/attention.hip: attention -> wo), each phase's weight
-                                stream running ahead of its hand-off; words 448.. : arrival counts of the range-split attention (the last split
+                                stream running ahead of its hand-off; words 512 .. 767: arrival counts of the range-split attention (the last split
                                 of a (row, head) merges the partials inside the launch; left at zero).  NULL -> every GEMV, the attention and its
                                 merge are separate launches */
 } vaura_decoder;

@@ -148,7 +148,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s,
-                             d->ws_sync ? d->ws_sync + 448 : nullptr);      // words 448.. : arrival counts of the range-split attention
+                             d->ws_sync ? d->ws_sync + 512 : nullptr);      // words 512 .. 767: arrival counts of the range-split attention (the MLP / tail engines use 0 .. 511; the attention + wo experiment uses 512 .. only with caches <= 256, where nothing is split)
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     }

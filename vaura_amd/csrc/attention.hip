@@ -972,7 +972,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
     if (n_split > 8) return VAURA_ERR_ARG;
-    // arrivals (rows * n_head zeroed words, e.g. the decoder's ws_sync + 448): the last split to arrive merges; debug flag bit 19: own launch
+    // arrivals (rows * n_head zeroed words, e.g. the decoder's ws_sync + 512): the last split to arrive merges; debug flag bit 19: own launch
     if (va_debug_flags_get() & 0x80000u) arrivals = nullptr;
     VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2,
               rope, n_head, max_len, pos_host, part, arrivals, out, outp);
