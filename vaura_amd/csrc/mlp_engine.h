@@ -28,6 +28,12 @@
 #ifndef MLPE_REL
 #define MLPE_REL 0        // 1: the held part is released behind the publish (drained stores + flag) instead of behind the stores' issue
 #endif
+template <typename F>
+__device__ __forceinline__ void va_static_for9(F&& f) {
+  f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});
+  f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});
+  f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{}); f(std::integral_constant<int, 8>{});
+}
 template <int WT>
 struct MlpeThrottle {
 #ifdef MLPE_Q2
@@ -39,6 +45,11 @@ struct MlpeThrottle {
   static constexpr int PRE3 = MLPE_PRE3;
 #else
   static constexpr int PRE3 = WT == 2 ? 1 : 2;
+#endif
+#ifdef MLPE_PRE3U
+  static constexpr int PRE3U = MLPE_PRE3U;      // the same in ninths (finer experiment builds)
+#else
+  static constexpr int PRE3U = 3 * PRE3;
 #endif
 };
 struct MlpEngineArgs {
@@ -493,15 +504,19 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
       if (wid != 0) {
         if (!(e.abl & 8)) {   // PRE3 of the three k-groups at once, the rest once wave 0's phase-2 stores are in the memory pipeline
-          constexpr int MLPE_PRE3_ = MlpeThrottle<WT>::PRE3;
-          if (MLPE_PRE3_ > 0) load_wq_g(std::integral_constant<int, 0>{});
-          if (MLPE_PRE3_ > 1) load_wq_g(std::integral_constant<int, 1>{});
-          if (MLPE_PRE3_ > 2) load_wq_g(std::integral_constant<int, 2>{});
-          if (MLPE_PRE3_ < 3)
+          // in ninths (k-group g, tile t; unit = 3 g + t): PRE3U of them at once, the rest behind the hold
+          constexpr int PRE3U = MlpeThrottle<WT>::PRE3U;
+          auto unit = [&](auto uc) {
+            constexpr int u = decltype(uc)::value, g = u / 3, t = u % 3;
+            const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
+#pragma unroll
+            for (int hh = 0; hh < WH; ++hh)
+              wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+          };
+          va_static_for9([&](auto uc) { if constexpr (decltype(uc)::value < PRE3U) unit(uc); });
+          if (PRE3U < 9)
             while (__hip_atomic_load(arrive + 17, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag) __builtin_amdgcn_s_sleep(1);
-          if (MLPE_PRE3_ < 1) load_wq_g(std::integral_constant<int, 0>{});
-          if (MLPE_PRE3_ < 2) load_wq_g(std::integral_constant<int, 1>{});
-          if (MLPE_PRE3_ < 3) load_wq_g(std::integral_constant<int, 2>{});
+          va_static_for9([&](auto uc) { if constexpr (decltype(uc)::value >= PRE3U) unit(uc); });
         } else {
           load_wq();
         }
