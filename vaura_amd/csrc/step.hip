@@ -238,29 +238,85 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     if (a.top_p > 0.0f) {
       // utils/utils.py:181-196 — sort descending (ties: lower id first), sequential cumsum, cut, renormalise,
       // draw in sorted space with the noise indexed by RANK, map back.
+      // Bitonic network over the 1024 (probability, id) pairs, element 4 tid + j in thread tid's registers.  A stage of stride st compares
+      // element i with i ^ st: strides 1, 2 stay inside a thread, 4 .. 128 are lane exchanges inside a wave (xor of the lane by st / 4),
+      // only 256 and 512 (three of the 55 stages) cross waves and go through LDS with barriers.  Same comparisons as the LDS network
+      // of rounds 1-3 (ties: lower id first): the same order, bit for bit (round 4: the top-p launch 52 -> 36.5 us; the network is ~20 us of
+      // it, the sequential sum below ~10: tools/time_sampler.py).
+      float sp_r[4];
+      int id_r[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { sp[4 * tid + j] = p[j]; sidx[4 * tid + j] = 4 * tid + j; }
-      __syncthreads();
+      for (int j = 0; j < 4; ++j) { sp_r[j] = p[j]; id_r[j] = 4 * tid + j; }
+      auto cmpx = [&](int j, float py, int idy, int st, int sz) {
+        const int i = 4 * tid + j;
+        const bool lower = (i & st) == 0;
+        const bool desc = ((i & ~st) & sz) == 0;            // direction of the pair = that of its lower index
+        const bool x_first = (sp_r[j] > py) || (sp_r[j] == py && id_r[j] < idy);
+        const bool keep_x = (lower == desc) ? x_first : !x_first;
+        if (!keep_x) { sp_r[j] = py; id_r[j] = idy; }
+      };
       for (int sz = 2; sz <= 1024; sz <<= 1) {
         for (int st = sz >> 1; st > 0; st >>= 1) {
-          for (int t = tid; t < 512; t += SMP_THREADS) {
-            const int i = ((t / st) * (st << 1)) + (t % st);
-            const int j = i + st;
-            const bool desc = ((i & sz) == 0);
-            const float pi = sp[i], pj = sp[j];
-            const int ii = sidx[i], ij = sidx[j];
-            const bool i_first = (pi > pj) || (pi == pj && ii < ij);  // i should precede j in descending order
-            if (desc ? !i_first : i_first) { sp[i] = pj; sp[j] = pi; sidx[i] = ij; sidx[j] = ii; }
+          if (st == 1) {           // (static register indices: a run-time `j ^ st` would send the arrays to scratch)
+            const float py[4] = {sp_r[1], sp_r[0], sp_r[3], sp_r[2]};
+            const int iy[4] = {id_r[1], id_r[0], id_r[3], id_r[2]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cmpx(j, py[j], iy[j], 1, sz);
+          } else if (st == 2) {
+            const float py[4] = {sp_r[2], sp_r[3], sp_r[0], sp_r[1]};
+            const int iy[4] = {id_r[2], id_r[3], id_r[0], id_r[1]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cmpx(j, py[j], iy[j], 2, sz);
+          } else if (st < 256) {
+            float py[4]; int iy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { py[j] = __shfl_xor(sp_r[j], st >> 2, 64); iy[j] = __shfl_xor(id_r[j], st >> 2, 64); }
+            // stride >= 4: whether this thread's four elements are the lower ones of their pairs, and the pairs' direction, do not depend on j
+            const bool want_first = (((4 * tid) & st) == 0) == ((((4 * tid) & ~st) & sz) == 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool x_first = (sp_r[j] > py[j]) || (sp_r[j] == py[j] && id_r[j] < iy[j]);
+              if (x_first != want_first) { sp_r[j] = py[j]; id_r[j] = iy[j]; }
+            }
+          } else {
+            __syncthreads();                                 // (the previous exchange's reads are done)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sp[4 * tid + j] = sp_r[j]; sidx[4 * tid + j] = id_r[j]; }
+            __syncthreads();
+            float py[4]; int iy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { py[j] = sp[(4 * tid + j) ^ st]; iy[j] = sidx[(4 * tid + j) ^ st]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cmpx(j, py[j], iy[j], st, sz);
           }
-          __syncthreads();
         }
       }
-      if (tid == 0) {
-        float cs = 0.f;
-        for (int i = 0; i < 1024; ++i) {
-          cs += sp[i];
-          skeep[i] = (cs - sp[i] > a.top_p) ? 0.f : 1.f;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { sp[4 * tid + j] = sp_r[j]; sidx[4 * tid + j] = id_r[j]; }
+      __syncthreads();
+      // torch.cumsum's order: one sequential chain of 1024 fp32 additions — kept in REGISTERS of wave 0 (lane l holds elements 16 l ..
+      // 16 l + 15, the carry moves from lane to lane through an SGPR), not 1024 dependent LDS round trips of one thread
+      if (tid < 64) {
+        float v[16], keep[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 x = *reinterpret_cast<const f32x4*>(sp + 16 * tid + 4 * j);
+          v[4 * j] = x[0]; v[4 * j + 1] = x[1]; v[4 * j + 2] = x[2]; v[4 * j + 3] = x[3];
         }
+        float carry = 0.f;
+        for (int l = 0; l < 64; ++l) {
+          float cs = carry;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            cs += v[j];
+            if (tid == l) keep[j] = (cs - v[j] > a.top_p) ? 0.f : 1.f;
+          }
+          carry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cs), l));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(skeep + 16 * tid + 4 * j) = f32x4{keep[4 * j], keep[4 * j + 1], keep[4 * j + 2], keep[4 * j + 3]};
       }
       __syncthreads();
       float ps[4];
