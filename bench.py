@@ -305,14 +305,20 @@ def main():
         torch.cuda.synchronize(dev)
         elapsed_local[0] = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
         vdist.barrier()
-        return vdist.max_over_ranks(time.perf_counter() - t0, dev), res
+        el = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+        # outside the timed region: the sticky device status word (a hand-off of the one-launch MLP that gave up makes every later
+        # hand-off return at once — wrong tokens AND an optimistic time; non-finite logits = garbage tokens): the run FAILS on either
+        eng.check_status()
+        return el, res
 
     elapsed_local = [0.0]
 
     if world > 1:
         args.no_extras = True            # N > 1: the timed region, its split and who took part — nothing else
-    elapsed, (codes, wav) = timed(step)
     seen = vdist.ranks_seen(dev)
+    if not share:
+        vdist.assert_distinct_devices(seen)          # --gpus N means N GPUs: two ranks on one device uuid is a launcher error, not a result
+    elapsed, (codes, wav) = timed(step)
     per_rank_ms = vdist.gather_floats(1e3 * elapsed_local[0] / args.steps, dev)
     main_marks = marks[-args.steps:]
     t_loop = sum(a.elapsed_time(b) for a, b, _ in main_marks) / args.steps
@@ -328,7 +334,11 @@ def main():
         "metric": f"audio codec tokens/sec (whole node), {'10.24' if long_ctx else '2.56'} s clips",
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",   # dtype = the arithmetic type: fp32 accumulate of exact products of (hi, lo) fp16 operand pairs (22 significand bits), whatever the storage
+        "scaling": "weak", "vs_baseline": None,
+        # the arithmetic type the path computes in: exact products of (hi, lo) fp16 operand PAIRS (22 significand bits per operand, the
+        # wlo*xlo term dropped) accumulated in fp32; `--weights f32` is bit-for-bit fp32 products on the fp32 MFMA (value_f32_exact below)
+        "dtype": {"h2": "f16x2-split(22b)/f32-acc", "h1": "f16x2-split(22b act, 11b w)/f32-acc", "fp8": "fp8-w,f16x2-act/f32-acc",
+                  "f32": "f32"}[storage], "data": "synthetic",
         "config": {"workload": (f"configs[{3 if long_ctx else (4 if storage == 'fp8' and args.codec == 'mx8' else 1)}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
@@ -384,6 +394,23 @@ def main():
         torch.cuda.empty_cache()
         eng = eng_main
 
+    # ---- the price of EXACT fp32: the same job, same checkpoint, on the exact-fp32-MFMA engine
+    #      (`--weights f32`: fp32 tiles, v_mfma_f32_16x16x4_f32, fp32 activations between kernels) — one more timed region, driver-run
+    if not args.no_extras and args.weights == "auto" and args.checkpoint == "raw" and not args.no_second and not long_ctx:
+        eng_main = eng
+        eng = DecoderEngine(cfg, sd, dev, wdtype="f32", one_launch_mlp=one_launch)
+        elx, (codesx, wavx) = timed(step)
+        t_loopx = sum(a.elapsed_time(b) for a, b, _ in marks[-args.steps:]) / args.steps
+        assert int(codesx.min()) >= 0 and int(codesx.max()) < 1024 and bool(torch.isfinite(wavx).all())
+        out["value_f32_exact"] = round(tokens / elx, 1)
+        out["f32_exact"] = {"what": "same job and checkpoint with weight_dtype='f32': fp32 weight tiles and fp32 activations on the exact "
+                                    "fp32 matrix instruction (bit-for-bit fp32 products; the cross-check engine of the parity tests)",
+                            "ms_per_step": round(1e3 * elx / args.steps, 3), "decode_loop_ms": round(t_loopx, 3),
+                            "value_over_value_f32_exact": round(out["value"] / (tokens / elx), 3)}
+        del eng, codesx, wavx
+        torch.cuda.empty_cache()
+        eng = eng_main
+
     if rank == 0 and not args.no_extras:
         # ---- split of the timed steps (HIP events recorded inside them, on the streams the work ran on) + per-kernel roofline
         torch.cuda.synchronize(dev)
@@ -421,6 +448,7 @@ def main():
         eng.start_sequence(None)
         L.check(L.lib().vaura_profile_loop(C.byref(eng.dec), C.byref(sp), n_steps, 0xFF, tot, cnt,
                                            int(torch.cuda.current_stream().cuda_stream)), "vaura_profile_loop")
+        eng.check_status()                       # vaura_profile_loop synchronised: a broken hand-off would make these intervals meaningless
         outl = (C.c_int64 * 8)()
         L.lib().vaura_profile_outliers(outl)     # intervals > 10x the kind's median (a stalled queue) are counted at the median
         n_out = int(sum(outl))
@@ -463,7 +491,8 @@ def main():
                 for row in csv.DictReader(l for l in open(os.path.join(REPO, "profiles", cand)) if not l.startswith("#")):   # (the summary starts with a comment line)
                     if row.get("Name", "").replace("void ", "").split("(")[0].strip() == kname:
                         avg_us = float(row["AverageNs"]) * 1e-3
-                        rocprof = {"source": f"profiles/{cand}", "avg_us_per_launch": round(avg_us, 3), "calls": int(row["Calls"]),
+                        rocprof = {"source": f"profiles/{cand}", "measured_by": "builder: committed rocprofv3 summary, NOT measured by this run",
+                                   "avg_us_per_launch": round(avg_us, 3), "calls": int(row["Calls"]),
                                    "frac": round(ab / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                         break
             except Exception:
@@ -483,7 +512,8 @@ def main():
             except Exception:
                 continue
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_source": (f"{tsrc} (builder: committed PMC record, NOT measured by this run)" if tsrc else None),
                            "kernel": f"{kname} = {dom}", "dominant_by": "total time over the decode loop",
                            "stalled_intervals_counted_at_median": n_out, "rocprofv3_kernel_trace": rocprof,
                            "share_of_loop_kernel_time": round(total_us[dom] / sum(total_us.values()), 4),
@@ -557,6 +587,7 @@ def main():
             ev[2].record()
             torch.cuda.synchronize(dev)
             t_e2e = (time.perf_counter() - t0) / reps
+            eng.check_status()
             out["end_to_end_with_extractor"] = {"what": "raw frames -> Segment-AVCLIP (divided space-time ViT-B/16, 4 segments per clip) -> decode loop "
                                                         "-> DAC decode; engine level, same storage as `value`",
                                                 "ms_per_step": round(1e3 * t_e2e, 3), "extractor_ms_last_step": round(ev[0].elapsed_time(ev[1]), 3),

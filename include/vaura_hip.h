@@ -134,7 +134,12 @@ typedef struct vaura_decoder {
                                 [4]=STATUS bits, sticky until the caller clears them (VAURA_STATUS_*): the sampler raises
                                 VAURA_STATUS_NONFINITE_LOGITS when a logit it is about to sample from is inf / NaN — which is
                                 where every overflow of the fp16-plane activation format ends up (|activation| > 65504 -> inf
-                                in the hi plane -> NaN in the residual stream).  [5..7] spare */
+                                in the hi plane -> NaN in the residual stream).  [5]=launch-epoch counter of the in-launch hand-offs,
+                                OWNED BY THE LIBRARY: whatever ends a decode step (sampler, teacher-forced advance) bumps it and
+                                nothing rewinds it, so every launch that shares the hand-off flag words (ws_sync) gets a fresh
+                                epoch even when the caller rewinds [0] or restarts a sequence with [3] unchanged.  Contract:
+                                zero it only together with ws_sync (a fresh allocation of both is fine), never write it
+                                otherwise.  [6..7] spare */
   const float* noise;        /* optional (n_steps, B*K, vocab) Exp(1) draws; NULL -> Philox */
 
   float* ws_h;               /* packed rows (rows x d_model) residual stream        */

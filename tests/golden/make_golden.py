@@ -6,6 +6,9 @@
     python tests/golden/make_golden.py full_greedy_raw   # full_greedy on the UN-rounded checkpoint (~4 min)
     python tests/golden/make_golden.py full_sample_raw   # UN-rounded checkpoint, B=2, cfg 6, top-k 250 sampled (~8 min)
     python tests/golden/make_golden.py full_greedy_cfg6_raw   # UN-rounded checkpoint, B=2, cfg 6, greedy      (~8 min)
+    python tests/golden/make_golden.py full_vgg_raw      # UN-rounded checkpoint, configs/generate_vgg.yaml:23-27 defaults (top-k 128, cfg 6) (~8 min)
+    python tests/golden/make_golden.py full_chunk_raw    # a LATER chunk of the sliding-window caller (scripts/generate.py:344-357): Tp=166, T=221,
+                                                         # cfg 6, top-k 128 sampled + greedy, UN-rounded checkpoint (~8 min)
     python tests/golden/make_golden.py avclip        # Segment-AVCLIP extractor (row f2), reference classes, 1 + 4 segments (~1 min)
     python tests/golden/make_golden.py full_c4       # configs[3]: block_size 1024, Tv=128, B=1, T=880 (~30 min)
     python tests/golden/make_golden.py codec         # DAC decode, transformers' DacModel   (seconds)
@@ -257,22 +260,22 @@ def gold_full_sample():
     print(f"reference generate(): {dt:.1f}s")
 
 
-def _cfg_run(name, B, cfg_scale, use_sampling, top_k, noise_seed):
+def _cfg_run(name, B, cfg_scale, use_sampling, top_k, noise_seed, T=220, prompt=None, feat_seed=0, keep=(1, 9, 10, 100, 228), model=None):
     """CFG generate() of the reference on the UN-rounded checkpoint (what a real fp32 V-AURA checkpoint looks like to the
     storage decision: 'auto' -> two fp16 planes) with every step's [cond; null] last-position logits captured.  Recorded per
     step, clip and codebook: the CFG-mixed top-1 / top-2 logit margin (greedy) or, for top-k sampling, the relative margin of
     argmax(p / Exp(1)) over the kept set and the relative gap at the top-k threshold — the only places where a storage
     format's logit error can change a token."""
-    model = _full_model(round_bf16=False)
-    feats = synth.video_features(B, seed=0)
+    model = model or _full_model(round_bf16=False)
+    feats = synth.video_features(B, seed=feat_seed)
     store = []
     h = _capture_logits(model, store)
     if use_sampling:
         torch.manual_seed(noise_seed)
     t = time.time()
-    r = model.generate(frames=feats.reshape(B, 4, 8, 768), audio=None, max_new_tokens=220,
+    r = model.generate(frames=feats.reshape(B, 4, 8, 768), audio=prompt, max_new_tokens=T,
                        return_sampled_indices=True, use_sampling=use_sampling, temp=1.0, top_k=top_k, top_p=0.0,
-                       prompt_is_encoded=True, cfg_scale=cfg_scale)
+                       prompt_is_encoded=True, cfg_scale=cfg_scale, remove_prompts=False)
     dt = time.time() - t
     h.remove()
     tok = r["sampled_indices"].numpy()
@@ -297,13 +300,17 @@ def _cfg_run(name, B, cfg_scale, use_sampling, top_k, noise_seed):
     extra = {}
     if use_sampling:
         extra = dict(noise_seed=np.int64(noise_seed), threshold_rel_gap=np.stack(thr_gap).astype(np.float32))
-    keep = [1, 9, 10, 100, 228]
+    if prompt is not None:
+        extra["prompt"] = prompt.numpy().astype(np.int16)
+    keep = list(keep)
     logits = {L: lg for (L, lg) in store}
+    assert [L for (L, _) in store] == list(range(1 if prompt is None else prompt.shape[-1] + 1, T + 9)), "one pass per sequence step"
     save(name, tokens=tok.astype(np.int16), sha1=np.array(sha1(tok.astype(np.int16))),
          margins=np.stack(margins).astype(np.float32), logits_steps=np.array(keep),
          logits=np.stack([logits[L].numpy() for L in keep]), cfg_scale=np.float64(cfg_scale), top_k=np.int64(top_k),
-         ref_seconds=np.float64(dt), weight_seed=np.int64(0), feat_seed=np.int64(0), round_bf16=np.int64(0), **extra)
+         ref_seconds=np.float64(dt), weight_seed=np.int64(0), feat_seed=np.int64(feat_seed), round_bf16=np.int64(0), **extra)
     print(f"reference generate(): {dt:.1f}s  min margin {np.stack(margins).min():.3e}")
+    return model
 
 
 def gold_full_sample_raw():
@@ -314,6 +321,27 @@ def gold_full_sample_raw():
 
 def gold_full_greedy_cfg6_raw():
     _cfg_run("full_greedy_cfg6_raw_B2_T220.npz", 2, 6.0, False, 0, 0)
+
+
+def gold_full_vgg_raw():
+    """The reference's shipped sampling defaults (configs/generate_vgg.yaml:23-27: use_sampling, temperature 1.0, top_k 128,
+    top_p 0.0, cfg_scale 6.0) at full depth on the un-rounded checkpoint, B=2, the reference's own noise stream."""
+    _cfg_run("full_topk128_cfg6_raw_B2_T220.npz", 2, 6.0, True, 128, 2027)
+
+
+def gold_full_chunk_raw():
+    """A LATER chunk of the sliding-window caller at full depth (scripts/generate.py:327-369): max_gen_len = ceil(2.56 * 44100 / 512)
+    = 221, the prompt = the previous chunk's tokens from stride 55 on = 166 tokens (`prompt_tokens = gen_tokens[:, :, stride_tokens:]`,
+    :365), remove_prompts=False, prompt_is_encoded=True -> start_offset_sequence 167, 63 cache-less passes of 167..229 positions.
+    The prompt is the tail of the headline golden's own sampled tokens (frames 54..219 of full_topk250_cfg6_raw_B2_T220: 166 frames
+    the same model produced), the features of the chunk are a fresh seed.  Two runs on ONE model build: generate_vgg.yaml's
+    defaults (cfg 6, top-k 128 sampled, the reference's noise stream) and greedy under cfg 6."""
+    prev = np.load(os.path.join(HERE, "full_topk250_cfg6_raw_B2_T220.npz"))["tokens"].astype(np.int64)
+    prompt = torch.from_numpy(prev[:, :, 54:220]).contiguous()
+    assert prompt.shape == (2, 9, 166)
+    keep = (167, 168, 200, 229)
+    m = _cfg_run("full_chunk_topk128_cfg6_raw_B2_Tp166_T221.npz", 2, 6.0, True, 128, 2026, T=221, prompt=prompt, feat_seed=1, keep=keep)
+    _cfg_run("full_chunk_greedy_cfg6_raw_B2_Tp166_T221.npz", 2, 6.0, False, 0, 0, T=221, prompt=prompt, feat_seed=1, keep=keep, model=m)
 
 
 # ------------------------------------------------------------------------------------- codec
@@ -491,6 +519,10 @@ if __name__ == "__main__":
         gold_full_sample_raw()
     elif what == "full_greedy_cfg6_raw":
         gold_full_greedy_cfg6_raw()
+    elif what == "full_vgg_raw":
+        gold_full_vgg_raw()
+    elif what == "full_chunk_raw":
+        gold_full_chunk_raw()
     elif what == "codec":
         gold_codec()
     elif what == "codec_full":

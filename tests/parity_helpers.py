@@ -1,28 +1,103 @@
-"""Helpers shared by the -m gpu parity tests (tests/ is on sys.path under pytest's rootdir conftest)."""
+"""Helpers shared by the -m gpu parity tests (tests/ is on sys.path under pytest's rootdir conftest).
+
+Token parity against a reference golden is STRICT (`assert_tokens_equal`): `torch.equal`, no exception.  The one golden that holds
+a step whose reference margin is inside fp32 summation-order noise (configs[3], step 578, margin 5.5e-6) goes through
+`assert_tokens_or_recorded_near_tie`, and what happened there is written down per storage.  Every comparison is recorded in the
+session's `ParityReport` (conftest.py `parity_report`), which the session writes ONCE to gpurun_out/r05_parity.json."""
+import json
+import os
+
 import torch
 
 
-def assert_cfg_tokens_or_recorded_near_tie(tok, ref, margins, tol, what, threshold_gap=None):
-    """Tokens must equal the reference's.  The one admissible exception: the FIRST differing token of a clip sits on a step whose
-    recorded reference margin — CFG-mixed top-1 / top-2 logit gap (greedy) or the relative gap of argmax(p / Exp(1)) over the kept
-    set (sampled; optionally the relative gap at the top-k threshold) — is below `tol`: there the 22-bit operand format's logit
-    error (<= 1.2e-5, times up to 2 * cfg_scale - 1 = 11 through the CFG mix) can legitimately decide the draw, and every later
-    token of that clip then differs.  Clips are independent, so each is judged on its own.  Returns clips that are identical."""
-    K, T = tok.shape[1], tok.shape[2]
-    steps = torch.arange(T)[None, :] + 1 + torch.arange(K)[:, None]                     # step that produced (k, t)
-    same = 0
-    for b in range(tok.shape[0]):
+def _steps(K, T):
+    """Sequence step that produced frame t of codebook k under the delay pattern (codebook_patterns.py:390-406): s = t + 1 + k."""
+    return torch.arange(T)[None, :] + 1 + torch.arange(K)[:, None]
+
+
+def token_diff_summary(tok, ref, margins=None, threshold_gap=None, first_step=1):
+    """tok / ref (B, K, T).  `margins` (passes, B, K): the reference's own recorded decision margin per pass; pass i fills sequence
+    step first_step + i (first_step = Tp + 1 with a prompt of Tp frames).  Returns a JSON-able dict."""
+    B, K, T = ref.shape
+    steps = _steps(K, T)
+    out = {"tokens_equal": bool(torch.equal(tok, ref)), "clips": B, "clips_identical": 0, "frames": T,
+           "token_agreement": float((tok == ref).float().mean()), "first_diff_step": None, "reference_margin_there": None,
+           "threshold_gap_there": None, "identical_frames_before_first_diff": T}
+    if margins is not None:
+        out["reference_min_margin"] = float(margins.min())
+    firsts = []
+    for b in range(B):
         if torch.equal(tok[b], ref[b]):
-            same += 1
+            out["clips_identical"] += 1
             continue
         bad = tok[b] != ref[b]
         s = int(steps[bad].min())
-        for k in range(K):
-            if bool((bad & (steps == s))[k].any()):
-                m = float(margins[s - 1, b, k])
-                g = float(threshold_gap[s - 1, b, k]) if threshold_gap is not None else float("inf")
-                assert m < tol or g < tol, (f"{what}: clip {b} first differs at step {s}, codebook {k}: recorded reference margin {m:.3e}"
-                                            f" (threshold gap {g:.3e}) >= {tol}")
-        assert torch.equal(tok[b][steps < s], ref[b][steps < s])
-        print(f"{what}: clip {b} identical up to step {s} (recorded near-tie there)")
-    return same
+        ks = [k for k in range(K) if bool((bad & (steps == s))[k].any())]
+        m = min(float(margins[s - first_step, b, k]) for k in ks) if margins is not None else None
+        g = min(float(threshold_gap[s - first_step, b, k]) for k in ks) if threshold_gap is not None else None
+        firsts.append((s, b, ks, m, g))
+    if firsts:
+        s, b, ks, m, g = min(firsts)
+        out.update(first_diff_step=s, first_diff_clip=b, first_diff_codebooks=ks, reference_margin_there=m, threshold_gap_there=g,
+                   identical_frames_before_first_diff=max(0, s - K))
+    return out
+
+
+class ParityReport:
+    """One entry per (golden, storage, launch shape) comparison of a session."""
+
+    def __init__(self):
+        self.entries = []
+
+    def add(self, golden, storage, what, tok, ref, margins=None, threshold_gap=None, first_step=1, max_logit_err=None, **extra):
+        e = {"golden": golden, "storage": storage, "what": what}
+        e.update(token_diff_summary(tok, ref, margins, threshold_gap, first_step))
+        if max_logit_err is not None:
+            e["max_abs_logit_err"] = float(max_logit_err)
+        e.update(extra)
+        self.entries.append(e)
+        return e
+
+    def note_logit_err(self, golden, storage, err, **extra):
+        for e in reversed(self.entries):
+            if e["golden"] == golden and e["storage"] == storage:
+                e["max_abs_logit_err"] = float(err)
+                e.update(extra)
+                return
+        self.entries.append({"golden": golden, "storage": storage, "max_abs_logit_err": float(err), **extra})
+
+    def summary_lines(self):
+        for e in self.entries:
+            yield (f"{e['golden']} [{e['storage']}] {e.get('what', '')}: tokens_equal={e.get('tokens_equal')} first_diff_step={e.get('first_diff_step')}"
+                   f" margin_there={e.get('reference_margin_there')} max_abs_logit_err={e.get('max_abs_logit_err')}")
+
+    def write(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"what": "token / logit parity of the HIP decode loop against goldens produced by the reference itself "
+                               "(tests/golden/make_golden.py), one entry per comparison of this pytest session",
+                       "entries": self.entries}, f, indent=1)
+
+
+def assert_tokens_equal(report, golden, storage, what, tok, ref, margins=None, threshold_gap=None, first_step=1, **extra):
+    """STRICT: every token equals the reference's.  Recorded in the session report either way."""
+    e = report.add(golden, storage, what, tok, ref, margins, threshold_gap, first_step, **extra)
+    assert e["tokens_equal"], (f"{golden} [{storage}] {what}: first differs at step {e['first_diff_step']} (clip {e.get('first_diff_clip')}, "
+                               f"codebooks {e.get('first_diff_codebooks')}); reference margin there {e['reference_margin_there']}, "
+                               f"agreement {e['token_agreement']:.4f}")
+    return e
+
+
+def assert_tokens_or_recorded_near_tie(report, golden, storage, what, tok, ref, margins, tol, first_step=1, **extra):
+    """For the ONE golden with a step inside summation-order noise (configs[3]: step 578, reference top-1 / top-2 margin 5.5e-6; the
+    next smallest of its 888 steps is 6.2e-5): tokens must equal the reference's up to a first difference that sits on a step whose
+    recorded reference margin is below `tol`.  Returns the report entry (identical_frames_before_first_diff = T when all equal)."""
+    e = report.add(golden, storage, what, tok, ref, margins, None, first_step, near_tie_tolerance=tol, **extra)
+    if not e["tokens_equal"]:
+        m = e["reference_margin_there"]
+        assert m is not None and m < tol, (f"{golden} [{storage}] {what}: first differs at step {e['first_diff_step']} where the reference's "
+                                           f"margin is {m} >= {tol}")
+        K, T = ref.shape[1], ref.shape[2]
+        before = (_steps(K, T) < e["first_diff_step"])[None].expand_as(ref)
+        assert torch.equal(tok[before], ref[before])
+    return e

@@ -244,13 +244,13 @@ def test_reference_host_call_pattern_is_served_from_a_cache(tiny_sampler_sd, gol
     assert eng.cached_forward_steps == 11 and float((other[:, :, :5] - full[:, :, :5]).abs().max()) > 1e-4
 
 
-def test_full_depth_generate_through_the_plugin_surface_matches_reference(golden, full_sampler_sd_raw):
+def test_full_depth_generate_through_the_plugin_surface_matches_reference(golden, full_sampler_sd_raw, parity_report):
     """ONE full-depth VAURAModel.generate() through the plugin classes (the call scripts/generate.py:311-324 makes) on the
     un-rounded checkpoint, cfg 6, top-k 250, seeded like the reference run (noise_mode='torch_cpu' consumes torch's global CPU
     generator exactly as utils.multinomial does): sampled_indices == the reference's own generate() output
     (make_golden.py full_sample_raw), waveform of the right shape and finite.  weight_dtype stays the plugin default ("auto" -> h2)."""
     from vaura_amd.model import VAURAModel
-    from parity_helpers import assert_cfg_tokens_or_recorded_near_tie
+    from parity_helpers import assert_tokens_equal
     g = golden("full_topk250_cfg6_raw_B2_T220.npz")
     cfg = synth.FULL_SAMPLER
     with warnings.catch_warnings():
@@ -271,6 +271,6 @@ def test_full_depth_generate_through_the_plugin_surface_matches_reference(golden
                    top_k=int(g["top_k"]), top_p=0.0, prompt_is_encoded=True, cfg_scale=float(g["cfg_scale"]))
     assert m.sampler.resolved_weight_dtype == "h2"
     tok = r["sampled_indices"].cpu()
-    assert_cfg_tokens_or_recorded_near_tie(tok, _ref(g, "tokens"), g["margins"], 5e-4, "plugin surface, full depth",
-                                           g["threshold_rel_gap"])
+    assert_tokens_equal(parity_report, "full_topk250_cfg6_raw_B2_T220", "h2", "VAURAModel.generate() through the plugin surface, B=2 (4 rows)", tok,
+                        _ref(g, "tokens"), g["margins"], g["threshold_rel_gap"])
     assert r["generated_audio"].shape == (2, 1, 220 * 512) and bool(torch.isfinite(r["generated_audio"]).all())

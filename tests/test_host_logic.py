@@ -154,6 +154,19 @@ def test_shard_covers_every_clip_once():
             assert seen == list(range(total))
 
 
+def test_two_ranks_on_one_device_uuid_are_refused():
+    """bench.py --gpus N asserts N DISTINCT devices (vaura_amd.dist.assert_distinct_devices over the all-gathered rank records)."""
+    ok = [{"rank": r, "device": f"cuda:{r}", "uuid": f"GPU-{r:04x}"} for r in range(8)]
+    vdist.assert_distinct_devices(ok)
+    vdist.assert_distinct_devices(ok[:1])
+    bad = [dict(ok[0]), dict(ok[1], uuid=ok[0]["uuid"]), dict(ok[2])]
+    with pytest.raises(RuntimeError, match="3 ranks but only 2 distinct"):
+        vdist.assert_distinct_devices(bad)
+    # no uuid reported (older runtime): the device string decides
+    with pytest.raises(RuntimeError, match="shared by several ranks"):
+        vdist.assert_distinct_devices([{"rank": 0, "device": "cuda:0"}, {"rank": 1, "device": "cuda:0"}])
+
+
 def test_synthetic_inputs_are_keyed_by_clip_index():
     a = synth.video_features(8, seed=0)
     b = synth.video_features(4, seed=0, first_clip=4)

@@ -50,6 +50,7 @@ with torch.cuda.stream(s):
         codes, wav = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+eng.check_status()            # a broken hand-off / non-finite logits would make this time meaningless: fail instead
 n_tok = codes.shape[-1]
 print(json.dumps({"workload": f"{duration} s clips via the sliding-window caller (2.56 s window, 0.64 s stride), batch {B}, cfg 6.0, top-k 250",
                   "chunks": len(sched), "tokens_per_clip_and_codebook": n_tok, "seconds_per_batch": round(dt, 4),

@@ -34,6 +34,7 @@ for pp in PASSES:
         out = eng.generate_codes(feats, 221, **kw)
     torch.cuda.synchronize()
     res[pp] = (time.perf_counter() - t0) / 3
+    eng.check_status()        # a broken hand-off / non-finite logits would make this time meaningless: fail instead
     print(f"prefill_positions={pp}: {res[pp] * 1e3:.1f} ms per chunk (166 prompt + 63 generated positions)")
     if pp == PASSES[0]:
         ref = out.clone()

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(ATT1_THREADS) void attn_wo_kernel(
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-  const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)pos + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
+  const uint32_t epoch = va_handoff_epoch(e.state, e.layer);
   const bool narrow = bid < 192;
   const int h = (bid >> 3) & 1, tile = (bid & 7) + 8 * (bid >> 4);
   const int la = lane & 7, sb = (lane >> 3) & 1, q = lane >> 4, m = lane & 15;

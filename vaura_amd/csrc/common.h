@@ -205,3 +205,13 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
                           uint16_t* out_act, int act, int B, int Lin, int Lout, int oshift, int Cin, int Cout, hipStream_t s);
 int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);
 int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);
+
+// Epoch of an in-launch hand-off (mlp_engine.h, the attention + wo experiment): the flag words are never reset, a hand-off passes when
+// every producer's word holds THIS launch's epoch, so no two launches that share flag words may share an epoch while a stale word can
+// still be seen.  state[5] is a launch-epoch counter OWNED BY THE LIBRARY: bumped by whatever ends a decode step (the sampler's last
+// workgroup, advance_kernel), never rewound — so a caller that rewinds the position (state[0]) or restarts a sequence without changing
+// state[3] still gets fresh epochs (round 4's epoch was (state[3], state[0] + 1, layer): re-running a (sequence, position) step on the
+// same flags matched stale words).  27 bits of counter x 32 layers; + 1 keeps zeroed flag words below every epoch.
+__device__ __forceinline__ uint32_t va_handoff_epoch(const int32_t* state, int layer) {
+  return ((((uint32_t)state[5] & 0x7ffffffu) << 5) | ((uint32_t)layer & 31u)) + 1u;
+}

@@ -1283,20 +1283,23 @@ static int launch_conv(const vaura_conv& cv, const float* in, const float* res, 
 // A whole residual unit (7-tap dilated conv -> Snake -> 1 x 1 conv -> + residual) as ONE launch where one workgroup holds every channel
 // (C = 96: the codec's last block, a third of its activation bytes).  The codec is bound by its activation streams, not by the matrix
 // pipe (profiles/r04_codec_ablations.txt): fused, the intermediate activation (4 B per element written and read back) never leaves the
-// CU.  Same sums in the same order as the two launches: bit-identical (tests/test_gpu_generate.py).  Returns 1 when the unit is not
-// of that shape (the caller then launches the two convs), 0 when launched.  out_act must not alias `in` (neighbours read halo rows).
+// CU.  Same sums in the same order as the two launches: bit-identical (tests/test_gpu_generate.py).  Returns VA_UNIT_NOT_ELIGIBLE when
+// the unit is not of that shape (the caller then launches the two convs), 0 when launched, anything else = an ERROR to propagate (a
+// negative VAURA_ERR_* or the positive hipError_t of a failed launch — VA_LAUNCH returns those, and hipErrorInvalidValue IS 1: "not
+// eligible" must not share a value with them).  out_act must not alias `in` (neighbours read halo rows).
+#define VA_UNIT_NOT_ELIGIBLE (-0x7fffff00)
 static long long va_conv_units_fused = 0;
 static int launch_conv_unit(const vaura_conv& c7, const vaura_conv& c1, const float* in, const float* res, const float* alpha_mid,
                             const float* alpha_next, float* out_raw, float* out_act, int B, int L, int pairs, hipStream_t s) {
-  if (pairs != 1 && pairs != 2 && pairs != 4) return 1;
-  if (va_debug_flags_get() & (0x200000u | 0x100000u)) return 1;       // debug flag bit 21: the two-launch form (bit 20: no 256-row instances at all)
+  if (pairs != 1 && pairs != 2 && pairs != 4) return VA_UNIT_NOT_ELIGIBLE;
+  if (va_debug_flags_get() & (0x200000u | 0x100000u)) return VA_UNIT_NOT_ELIGIBLE;       // debug flag bit 21: the two-launch form (bit 20: no 256-row instances at all)
   const int C = c7.cin;
   if ((C != BN && C != 2 * BN) || c7.cout != C || c1.cin != C || c1.cout != C || c7.stride != 1 || c1.stride != 1 || c1.taps != 1 || c7.taps < 1 ||
       (c7.taps - 1) * c7.dilation > XHALO || !c7.w || !c7.bias || !c1.w || !c1.bias || !alpha_mid || !alpha_next || !res || !out_act || (const float*)out_act == in)
-    return 1;
+    return VA_UNIT_NOT_ELIGIBLE;
   const int rows = C == BN ? 256 : 128;
   const int gx = (L + rows - 1) / rows;
-  if ((int64_t)gx * B < 384) return 1;
+  if ((int64_t)gx * B < 384) return VA_UNIT_NOT_ELIGIBLE;
   ConvPArgs p;
   p.in = reinterpret_cast<const uint16_t*>(in); p.w = reinterpret_cast<const uint16_t*>(c7.w); p.bias = c7.bias; p.res = res;
   p.alpha = alpha_next; p.out_raw = out_raw; p.out_act = reinterpret_cast<uint16_t*>(out_act);
@@ -1651,8 +1654,8 @@ int vaura_dac_decode(const vaura_codec* c, const int32_t* codes, int B, int T, f
       const float* next_alpha = (u < 2) ? c->alpha_res[b][u + 1][0] : (b + 1 < c->n_blocks ? c->alpha_up[b + 1] : c->alpha_out);
       // the whole unit in one launch where one workgroup holds every channel (the activated result goes to Y: neighbours still read A's halo rows)
       rc = launch_conv_unit(c->res[b][u][0], c->res[b][u][1], A, R, c->alpha_res[b][u][1], next_alpha, (u < 2) ? R : nullptr, Y, B, L, pr, s);
-      if (rc < 0) return rc;
       if (rc == 0) { float* t = A; A = Y; Y = t; continue; }
+      if (rc != VA_UNIT_NOT_ELIGIBLE) return rc;          // a real failure of the one-launch unit (argument error or hipError_t): not a fallback
       // y = Snake2(conv7(Snake1(x)))  (Snake1 applied by the producer)
       rc = launch_conv(c->res[b][u][0], A, nullptr, c->alpha_res[b][u][1], nullptr, Y, B, L, pr, s);
       if (rc) return rc;

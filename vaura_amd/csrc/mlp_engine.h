@@ -149,7 +149,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.x;
   // epoch of this hand-off: unique per (sequence, position, layer); the flags hold the previous hand-off's epoch until rewritten
-  const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)e.state[0] + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
+  const uint32_t epoch = va_handoff_epoch(e.state, e.layer);
   // LDS arrival words carry the epoch mixed with THIS workgroup's id: on a busy chip the 256 workgroups of a launch do not all start at
   // once, and a late one can land on a CU another workgroup of the SAME launch has just left — whose arrival words hold this very
   // epoch (round 4: found by the concurrent-load test; on an idle chip every workgroup has a CU of its own and it never shows)
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void tail_engine_kernel(const void* _
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = blockIdx.x;
-  const uint32_t epoch = (((uint32_t)e.state[3] & 0x7ffu) << 16 | (((uint32_t)e.state[0] + 1u) & 0x7ffu) << 5 | ((uint32_t)e.layer & 31u)) + 1u;
+  const uint32_t epoch = va_handoff_epoch(e.state, e.layer);
   // LDS arrival words carry the epoch mixed with THIS workgroup's id: on a busy chip the 256 workgroups of a launch do not all start at
   // once, and a late one can land on a CU another workgroup of the SAME launch has just left — whose arrival words hold this very
   // epoch (round 4: found by the concurrent-load test; on an idle chip every workgroup has a CU of its own and it never shows)

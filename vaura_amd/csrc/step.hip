@@ -411,6 +411,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
         __hip_atomic_store(&a.state_rw[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.state_rw[0] = pos + 1;
         a.state_rw[2] = (int)step + 1;
+        a.state_rw[5] = a.state_rw[5] + 1;     // launch-epoch counter of the in-launch hand-offs (common.h va_handoff_epoch): never rewound
       }
     }
   }
@@ -432,7 +433,10 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
 }
 
 __global__ void advance_kernel(int32_t* state, int set_to) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) state[0] = set_to >= 0 ? set_to : state[0] + 1;
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    state[0] = set_to >= 0 ? set_to : state[0] + 1;
+    state[5] = state[5] + 1;                   // launch-epoch counter (common.h va_handoff_epoch)
+  }
 }
 int va_launch_advance(int32_t* state, int set_to, hipStream_t s) {
   VA_LAUNCH(advance_kernel, dim3(1), dim3(64), 0, s, state, set_to);

@@ -70,6 +70,17 @@ def ranks_seen(device) -> List[dict]:
     return out
 
 
+def assert_distinct_devices(seen: List[dict]) -> None:
+    """Every rank of a clip-parallel job must sit on its OWN GPU: two ranks with the same device uuid means a launcher bound them
+    to one device, and the aggregate rate would be a shared-GPU artefact (and the one-launch MLP's in-launch hand-off would starve,
+    csrc/mlp_engine.h).  Raises on every rank that sees the list (all of them: ``ranks_seen`` is an all-gather)."""
+    ids = [(r.get("uuid") or r.get("device")) for r in seen]
+    dup = sorted({i for i in ids if ids.count(i) > 1})
+    if len(seen) > 1 and dup:
+        raise RuntimeError(f"{len(seen)} ranks but only {len(set(ids))} distinct GPU(s): device id(s) {dup} are shared by several ranks "
+                           f"({[(r['rank'], r.get('device')) for r in seen if (r.get('uuid') or r.get('device')) in dup]})")
+
+
 def gather_floats(x: float, device) -> List[float]:
     """The same scalar from every rank (per-rank timings of the bench record)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

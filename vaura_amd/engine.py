@@ -130,8 +130,10 @@ class DecoderEngine:
         one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
         is eligible (1..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
         decode loop).  Its consumers wait for producers of the SAME launch, so every workgroup must become resident: pass False
-        when several processes share this GPU (two such launches from two processes can starve each other until their bounded
-        waits give up — reported by ``check_status``, never silent)."""
+        when several processes share this GPU, or when several DecoderEngines of ONE process run on different streams at the same
+        time (each launch wants all 256 CUs, one workgroup per CU: two such launches can starve each other until their bounded waits
+        give up).  A give-up is reported by ``check_status`` — which callers of ``generate_codes`` / ``run`` must call themselves,
+        ``VAURAModel.generate_tokens`` does."""
         self.one_launch_mlp = bool(one_launch_mlp)
         _require_cuda(device)
         self.cfg = cfg
@@ -183,6 +185,8 @@ class DecoderEngine:
         self.dims = L.Dims(cfg.num_layers, D, cfg.nhead, F, K, cfg.d_codebook, cfg.cond_dim, cfg.tok_dim, cfg.cond_in,
                            cfg.codebook_dim, 7, cfg.layer_norm_eps)
         self.dec: Optional[L.Decoder] = None
+        self.state = None
+        self._carried_status = 0             # status bits read off a state buffer that prepare() was about to replace
         self._shape = None
         self._graph, self._graph_key = None, None
         self.weight_bytes = sum(t.numel() * t.element_size() for t in self._keep)
@@ -222,6 +226,8 @@ class DecoderEngine:
         self._fc = None                       # whoever prepares the engine is about to overwrite the K/V cache
         if self._shape == key:
             return
+        if getattr(self, "state", None) is not None:      # an unread status bit must survive the reallocation below
+            self._carried_status |= int(self.state[4].item())
         with torch.cuda.device(self.dev):
             pp = min(self.PREFILL_POSITIONS, S) if self.planes else 1
             rp = self._rows_padded(rows) * pp     # decode uses the first position's worth of row blocks
@@ -373,23 +379,29 @@ class DecoderEngine:
 
     def check_status(self):
         """Read AND clear the sticky device status word (one host-device synchronisation; ``VAURAModel.generate`` folds it into
-        the reference's own post-condition checks, vaura_model.py:550-572).  Raises when the sampler met a non-finite logit:
-        with activations carried as (hi, lo) fp16 planes between kernels that is what an activation beyond fp16's range
-        (|x| > 65504: inf in the hi plane, NaN from then on in that row's residual stream) turns into — the tokens decoded
-        after it are garbage, so it is an error, not a result."""
-        st = int(self.state[4].item())
+        the reference's own post-condition checks, vaura_model.py:550-572) and raise ONE error naming every condition it holds:
+        a non-finite logit at the sampler (what an activation beyond the fp16-plane range turns into — the tokens decoded after it
+        are garbage), and / or a hand-off of the one-launch MLP that gave up (every later hand-off then returns at once: wrong
+        tokens AND an optimistic time).  ``generate_codes`` / ``run`` are asynchronous and do NOT call this: whoever drives them
+        directly (bench.py, tools/, tests) must call it after synchronising — ``VAURAModel.generate_tokens``, ``forward_cached`` and
+        ``logits_all_positions`` do."""
+        st = int(self.state[4].item()) | self._carried_status
+        self._carried_status = 0
         if st:
             self.state[4:5].zero_()
+        msgs = []
         if st & 2:
-            raise L.VauraHipError(
-                "decode loop: a consumer of the one-launch MLP gave up waiting for its producers (csrc/mlp_engine.h: its 256 workgroups "
-                "must all become resident — is another process running the same kernels on this GPU?); the tokens of this call are "
-                "not valid.  DecoderEngine(..., one_launch_mlp=False) keeps the two-launch path")
+            msgs.append(
+                "a consumer of the one-launch MLP gave up waiting for its producers (csrc/mlp_engine.h: its 256 workgroups must all become "
+                "resident — is another process, or a second DecoderEngine of this process on another stream, running the same kernels on "
+                "this GPU?); every hand-off after the give-up returned without waiting, so the tokens of this call are not valid and its "
+                "timing is meaningless.  DecoderEngine(..., one_launch_mlp=False) keeps the two-launch path")
         if st & 1:
-            raise L.VauraHipError(
-                "decode loop: non-finite logits reached the sampler — an activation left the range of the fp16-plane format "
-                "(|x| > 65504 in the residual stream x next-norm gain, the SwiGLU output or the attention output) or the "
-                "checkpoint holds non-finite weights; weight_dtype='f32' keeps fp32 activations (exact-fp32-MFMA path)")
+            msgs.append(
+                "non-finite logits reached the sampler — an activation left even the pre-scaled fp16-plane range, or the checkpoint holds "
+                "non-finite weights; weight_dtype='f32' keeps fp32 activations (exact-fp32-MFMA path)")
+        if msgs:
+            raise L.VauraHipError(f"decode loop (status word {st:#x}): " + "; ALSO: ".join(msgs))
 
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T
@@ -457,6 +469,7 @@ class DecoderEngine:
             self.cached_forward_steps = getattr(self, "cached_forward_steps", 0) + 1
         st["idx"][:, :, n0:Lq] = idx[:, :, n0:Lq]
         st["n"] = Lq
+        self.check_status()                  # the caller consumes these logits on the host side anyway (one synchronisation)
         return st["logits"][:, :, :Lq].clone()      # a copy: the cache must survive in-place edits by the caller
 
     # ------------------------------------------------------------------ op-level access (tests)
@@ -479,6 +492,7 @@ class DecoderEngine:
             L.check(self.lib.vaura_decode_step(C.byref(self.dec), C.byref(sp), 1, st), "vaura_decode_step")
             out[:, :, p] = self.ws_logits.view(Bs, K, -1)
             self.seq.copy_(keep)  # the sampler only fills -1 slots, but keep the input pristine anyway
+        self.check_status()
         return out
 
 
