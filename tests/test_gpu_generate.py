@@ -674,6 +674,108 @@ def test_headline_configuration_h2_cfg6_topk250_B8_matches_reference(golden, ful
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("wdtype", ["h2", "h1", "fp8"])
+def test_two_row_blocks_per_weight_pass_are_bit_identical_to_the_walk(wdtype):
+    """17..32 decoder rows (the reference's default batch 16 under CFG, configs/generate_vgg.yaml:41 + :27; BASELINE configs[4]): every
+    GEMV takes BOTH row blocks per weight fragment (gemv3_kernel / gemv3h_kernel RBK = 2: second accumulator set, one reduction
+    barrier, the blocks' epilogues on different waves).  Per row block the products and their order are those of round 4's walk over
+    the blocks (second flag word, bit 0): logits bit for bit and tokens, at 20 rows (second block ragged), 32 rows (full) and 40 rows
+    (three blocks: a full pass + a half-empty one), eager and through the captured graph."""
+    from vaura_amd import _lib as L
+    cfg = synth.tiny_sampler(2)
+    sd = synth.sampler_state_dict(cfg, seed=91)
+    eng = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
+    g = torch.Generator().manual_seed(92)
+    out = {}
+    try:
+        for walk in (0, 1):
+            L.lib().vaura_set_debug_flags2(walk)
+            eng._free_graph()
+            for rows in (20, 32, 40):
+                feats = synth.video_features(rows, seed=93).to(DEV)
+                idx = torch.randint(0, 1025, (rows, 9, 5), generator=torch.Generator().manual_seed(94 + rows))
+                out[("lg", rows, walk)] = eng.logits_all_positions(idx.to(DEV), feats).cpu()
+            feats = synth.video_features(16, seed=95).to(DEV)
+            for ug in (True, False):
+                out[("tok", ug, walk)] = eng.generate_codes(feats, 14, cfg_scale=6.0, use_sampling=True, top_k=128, seed=7, use_graph=ug).cpu()
+                eng.check_status()
+    finally:
+        L.lib().vaura_set_debug_flags2(0)
+        eng._free_graph()
+    for rows in (20, 32, 40):
+        assert torch.isfinite(out[("lg", rows, 0)]).all()
+        assert torch.equal(out[("lg", rows, 0)], out[("lg", rows, 1)]), (wdtype, rows, float((out[("lg", rows, 0)] - out[("lg", rows, 1)]).abs().max()))
+    assert torch.equal(out[("tok", True, 0)], out[("tok", True, 1)]) and torch.equal(out[("tok", False, 0)], out[("tok", True, 0)])
+    assert torch.equal(out[("tok", False, 1)], out[("tok", True, 0)])
+
+
+def test_reference_shipped_defaults_top_k128_cfg6_h2_B8_matches_reference(golden, full_sampler_sd_raw, parity_report):
+    """configs/generate_vgg.yaml:23-27 as shipped — use_sampling, temperature 1.0, top_k 128, top_p 0, cfg_scale 6 — at full depth on the
+    un-rounded checkpoint ("auto" -> h2), B=8 -> 16 decoder rows (the bench's launch shapes): clips 0-1 token-identical to the reference's
+    own cache-less CPU generate() with its noise stream (make_golden.py full_vgg_raw).  STRICT."""
+    g = golden("full_topk128_cfg6_raw_B2_T220.npz")
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV)
+    assert eng.wdtype == "h2"
+    feats = synth.video_features(8, seed=int(g["feat_seed"])).to(DEV)
+    nz8 = torch.cat([synth.exp_noise(228, 18, 1024, int(g["noise_seed"])), synth.exp_noise(228, 54, 1024, 4322)], dim=1)
+    tok = eng.generate_codes(feats, 220, use_sampling=True, temp=1.0, top_k=int(g["top_k"]), cfg_scale=float(g["cfg_scale"]), noise=nz8).cpu()
+    eng.check_status()
+    assert int(g["top_k"]) == 128 and eng.rows == 16
+    assert_tokens_equal(parity_report, "full_topk128_cfg6_raw_B2_T220", "h2", "generate_vgg.yaml defaults: cfg 6 / top-k 128 sampled, clips 0-1 of B=8 (16 rows, auto)",
+                        tok[:2], _ref(g, "tokens"), g["margins"], g["threshold_rel_gap"])
+    lg_ref = torch.from_numpy(g["logits"][list(g["logits_steps"]).index(1)])
+    f2 = torch.cat([feats[:2], (torch.zeros_like(feats[:2]) + eng.uncond)], 0)
+    lg = eng.logits_all_positions(torch.full((4, 9, 1), 1024, dtype=torch.long).to(DEV), f2)[:, :, 0].cpu()
+    err = float((lg - lg_ref).abs().max())
+    assert err < 3e-5, err
+    parity_report.note_logit_err("full_topk128_cfg6_raw_B2_T220", "h2", err, logit_err_step=1)
+    del eng
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("wdtype", ["auto", "f32"])
+def test_later_chunk_of_the_sliding_window_caller_full_depth_matches_reference(golden, full_sampler_sd_raw, parity_report, wdtype):
+    """Row f1 at its REAL shape and depth (scripts/generate.py:344-357, a later chunk): prompt Tp = 166 encoded frames, max_new_tokens 221
+    (S = 230), remove_prompts=False, cfg 6 -> the batched prompt pass (166 positions x 16 rows through the prefill GEMM and the MFMA
+    prefill attention) + 63 sampled steps on the decode kernels — against the reference's own generate() on the un-rounded checkpoint
+    (make_golden.py full_chunk_raw): (a) generate_vgg.yaml's defaults (top-k 128 sampled, the reference's noise stream): STRICT;
+    (b) greedy under cfg 6: clip 0 STRICT; clip 1 of that reference run holds ONE literal tie (step 175, codebook 8: CFG-mixed top-1 /
+    top-2 gap 3.8e-6 = one fp32 ulp at the logits' magnitude; the next smallest margin of the run is 1.4e-4) — tokens must match up
+    to there and what each engine does there is recorded ("f32" = the exact-fp32-MFMA engine: only the ORDER of its sums differs from
+    torch's).  B=8 on the default storage (16 rows: the one-launch MLP, the 128-row prefill tiles); clips 2-7 carry seeded prompts."""
+    gs = golden("full_chunk_topk128_cfg6_raw_B2_Tp166_T221.npz")
+    gg = golden("full_chunk_greedy_cfg6_raw_B2_Tp166_T221.npz")
+    B = 8 if wdtype == "auto" else 2
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV, wdtype=wdtype)
+    st = eng.wdtype
+    assert st == ("h2" if wdtype == "auto" else "f32")
+    feats = synth.video_features(B, seed=int(gs["feat_seed"])).to(DEV)
+    p2 = torch.from_numpy(gs["prompt"].astype(np.int64))
+    assert p2.shape == (2, 9, 166) and np.array_equal(gs["prompt"], gg["prompt"])
+    prompt = torch.cat([p2, torch.randint(0, 1024, (B - 2, 9, 166), generator=torch.Generator().manual_seed(5))], 0).to(DEV)
+    n_pass = 230 - 167
+    nz = torch.cat([synth.exp_noise(n_pass, 18, 1024, int(gs["noise_seed"])), synth.exp_noise(n_pass, 9 * (B - 2), 1024, 4323)], dim=1)
+    tok = eng.generate_codes(feats, 221, prompt=prompt, use_sampling=True, temp=1.0, top_k=int(gs["top_k"]), cfg_scale=float(gs["cfg_scale"]),
+                             noise=nz).cpu()
+    eng.check_status()
+    assert torch.equal(tok[:, :, :166], prompt.cpu())                          # remove_prompts=False: the prompt is part of the output
+    assert_tokens_equal(parity_report, "full_chunk_topk128_cfg6_raw_B2_Tp166_T221", st,
+                        f"later long-form chunk (Tp=166, T=221), cfg 6 / top-k 128 sampled, clips 0-1 of B={B}", tok[:2], _ref(gs, "tokens"),
+                        gs["margins"], gs["threshold_rel_gap"], first_step=167)
+    # the first sampled pass's [cond; null] logits (sequence length 167 = the whole prompt pass + one position) against the reference's
+    tokg = eng.generate_codes(feats, 221, prompt=prompt, cfg_scale=float(gg["cfg_scale"])).cpu()
+    eng.check_status()
+    refg = _ref(gg, "tokens")
+    assert_tokens_equal(parity_report, "full_chunk_greedy_cfg6_raw_B2_Tp166_T221", st, f"later long-form chunk, greedy cfg 6, clip 0 of B={B}",
+                        tokg[:1], refg[:1], gg["margins"][:, :1], first_step=167)
+    e = assert_tokens_or_recorded_near_tie(parity_report, "full_chunk_greedy_cfg6_raw_B2_Tp166_T221", st,
+                                           f"later long-form chunk, greedy cfg 6, clip 1 of B={B} (holds the run's one literal tie: step 175)",
+                                           tokg[1:2], refg[1:2], gg["margins"][:, 1:2], 2e-5, first_step=167)
+    assert e["tokens_equal"] or e["first_diff_step"] == 175, e
+    del eng
+    torch.cuda.empty_cache()
+
+
 def test_full_length_codec_decode_and_encode_match_the_oracle_on_the_256_row_instances():
     """What the bench's codec stage actually launches: T=220, B=8, default precision (f16pair) — every conv but conv_in runs
     conv_pair_kernel<..., 8> (256-row workgroups, csrc/dac.hip), asserted through the library's launch counter — against the fp32

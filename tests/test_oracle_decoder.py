@@ -152,3 +152,46 @@ def test_headline_configuration_golden_first_frames(golden, full_sampler_sd_raw)
             mixed = r[2:] + (r[:2] - r[2:]) * s
             assert (trace["logits"][int(L)] - mixed).abs().max() < 5e-4
     assert g["tokens"].shape == (2, 9, 220) and g["margins"].shape == (228, 2, 9) and float(g["margins"].min()) > 1e-5
+
+
+@pytest.mark.slow
+def test_reference_shipped_defaults_golden_first_frames(golden, full_sampler_sd_raw):
+    """configs/generate_vgg.yaml:23-27 as shipped (top-k 128, cfg 6, temperature 1) on the un-rounded checkpoint (make_golden.py
+    full_vgg_raw): the cached oracle reproduces the first 12 frames of the reference's tokens (bounded; the GPU suite runs all 220)."""
+    g = golden("full_topk128_cfg6_raw_B2_T220.npz")
+    cfg = synth.FULL_SAMPLER
+    dec = DecoderOracle(full_sampler_sd_raw, cfg.num_layers, cfg.nhead)
+    feats = synth.video_features(2, seed=int(g["feat_seed"]))
+    nz = synth.exp_noise(29, 18, 1024, int(g["noise_seed"]))
+    tok = go.generate(dec, feats, 21, mode="cached", cfg_scale=float(g["cfg_scale"]), use_sampling=True, temp=1.0, top_k=int(g["top_k"]), noise=nz)
+    assert int(g["top_k"]) == 128 and float(g["cfg_scale"]) == 6.0
+    assert torch.equal(tok[..., :12], torch.from_numpy(g["tokens"].astype(np.int64))[..., :12])
+    assert g["tokens"].shape == (2, 9, 220) and float(g["margins"].min()) > 1e-5
+
+
+@pytest.mark.slow
+def test_later_longform_chunk_golden_first_steps(golden, full_sampler_sd_raw):
+    """A later chunk of the sliding-window caller at full depth (make_golden.py full_chunk_raw: Tp = 166, T = 221, cfg 6): the cached
+    oracle — 166 teacher-forced positions, then sampling — reproduces the reference's [cond; null] logits of its first pass (sequence
+    length 167) after the CFG mix and the tokens of its first 10 sampled steps, for the top-k-128 run and the greedy one.  Bounded by a
+    shorter T (the steps compared, 167..176, do not depend on it); the GPU suite runs all 63 passes."""
+    gs, gg = golden("full_chunk_topk128_cfg6_raw_B2_Tp166_T221.npz"), golden("full_chunk_greedy_cfg6_raw_B2_Tp166_T221.npz")
+    cfg = synth.FULL_SAMPLER
+    dec = DecoderOracle(full_sampler_sd_raw, cfg.num_layers, cfg.nhead)
+    feats = synth.video_features(2, seed=int(gs["feat_seed"]))
+    prompt = torch.from_numpy(gs["prompt"].astype(np.int64))
+    Tshort = 176
+    steps = torch.arange(Tshort)[None, :] + 1 + torch.arange(9)[:, None]
+    same_steps = (steps <= Tshort)[None].expand(2, -1, -1)               # steps whose validity mask is the one of the T = 221 run
+    nz = synth.exp_noise(Tshort + 9 - 167, 18, 1024, int(gs["noise_seed"]))
+    trace = {}
+    tok = go.generate(dec, feats, Tshort, prompt=prompt, mode="cached", cfg_scale=6.0, use_sampling=True, temp=1.0, top_k=128, noise=nz, trace=trace)
+    ref = torch.from_numpy(gs["tokens"].astype(np.int64))[..., :Tshort]
+    assert torch.equal(tok[same_steps], ref[same_steps])
+    r = torch.from_numpy(gs["logits"][list(gs["logits_steps"]).index(167)])
+    assert (trace["logits"][167] - (r[2:] + (r[:2] - r[2:]) * 6.0)).abs().max() < 5e-4
+    # greedy: the same prefix, so the same first-pass logits; tokens of clip 0 (clip 1 holds the run's literal tie at step 175)
+    tokg = go.generate(dec, feats[:1], Tshort, prompt=prompt[:1], mode="cached", cfg_scale=6.0)
+    refg = torch.from_numpy(gg["tokens"].astype(np.int64))[:1, :, :Tshort]
+    assert torch.equal(tokg[same_steps[:1]], refg[same_steps[:1]])
+    assert float(gg["margins"][175 - 167, 1, 8]) < 1e-5                  # the run's literal tie (clip 1, step 175, codebook 8)

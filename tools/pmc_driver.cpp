@@ -66,11 +66,17 @@ int main(int argc, char** argv) {
   int wd = VAURA_W_H1, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1;
   const char* stamps_out = nullptr;
   std::vector<unsigned> variants{0u};
+  std::vector<unsigned> variants2{0u};        // the second flag word of each variant: --flags F or F:F2 (vaura_set_debug_flags2)
   for (int i = 2; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--time")) rounds = atoi(argv[i + 1]);
     if (!strcmp(argv[i], "--flags")) {
       variants.clear();
-      for (char* t = strtok(argv[i + 1], ","); t; t = strtok(nullptr, ",")) variants.push_back((unsigned)strtoul(t, nullptr, 0));
+      variants2.clear();
+      for (char* t = strtok(argv[i + 1], ","); t; t = strtok(nullptr, ",")) {
+        char* colon = nullptr;
+        variants.push_back((unsigned)strtoul(t, &colon, 0));
+        variants2.push_back(colon && *colon == ':' ? (unsigned)strtoul(colon + 1, nullptr, 0) : 0u);
+      }
     }
     if (!strcmp(argv[i], "--weights")) wd = (!strcmp(argv[i + 1], "h2") || !strcmp(argv[i + 1], "f32")) ? VAURA_W_H2 : VAURA_W_H1;   // h1 | h2
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
@@ -134,6 +140,7 @@ int main(int argc, char** argv) {
     unsigned long long hdr[3] = {0, cap, getenv("PMC_STAMP_ALL_WAVES") ? 1ull : 0ull};
     vaura_step_graph_t g;
     if (auto setf = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags")) setf(variants[0]);    // --flags F: the variant to stamp
+    if (auto setf2 = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags2")) setf2(variants2[0]);
     if (gbuild(&d, &sp, st, &g)) { fprintf(stderr, "graph build\n"); return 3; }
     const int32_t st0[4] = {pos0, 0, 0, 1};
     CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
@@ -213,12 +220,16 @@ int main(int argc, char** argv) {
   if (rounds > 0) {
     auto gbuild = (int (*)(const vaura_decoder*, const vaura_sampling*, vaura_stream_t, vaura_step_graph_t*))dlsym(lib, "vaura_step_graph_build");
     auto gloop = (int (*)(const vaura_decoder*, const vaura_sampling*, int, int, vaura_step_graph_t, vaura_stream_t))dlsym(lib, "vaura_generate_loop");
-    auto setf = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags");
+    auto setf1 = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags");
+    auto setf2 = (void (*)(unsigned))dlsym(lib, "vaura_set_debug_flags2");      // absent in experiment builds of older trees
+    size_t cur_v = 0;
+    auto setf = [&](unsigned f) { setf1(f); if (setf2) setf2(f == 0 && cur_v >= variants2.size() ? 0u : variants2[cur_v]); };
     auto prof = (int (*)(const vaura_decoder*, const vaura_sampling*, int, unsigned, double*, int64_t*, vaura_stream_t))dlsym(lib, "vaura_profile_loop");
-    if (!gbuild || !gloop || !setf || !prof) { fprintf(stderr, "missing symbols\n"); return 1; }
+    if (!gbuild || !gloop || !setf1 || !prof) { fprintf(stderr, "missing symbols\n"); return 1; }
     const int n = S - 1;
     std::vector<vaura_step_graph_t> graphs(variants.size());
     for (size_t v = 0; v < variants.size(); ++v) {
+      cur_v = v;
       setf(variants[v]);
       const int rc = gbuild(&d, &sp, st, &graphs[v]);
       if (rc) { fprintf(stderr, "graph build (flags %u): %d\n", variants[v], rc); return 3; }
@@ -234,6 +245,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
         const auto h0 = std::chrono::steady_clock::now();
+        cur_v = v;
         if (eager) setf(variants[v]);
         const int rc = gloop(&d, &sp, 0, n, eager ? nullptr : graphs[v], st);
         const auto h1 = std::chrono::steady_clock::now();
@@ -248,18 +260,20 @@ int main(int argc, char** argv) {
       std::sort(ms[v].begin(), ms[v].end());
       std::sort(host_ms[v].begin(), host_ms[v].end());
       printf("host enqueue of the loop (%s): median %.3f ms\n", eager ? "eager launches" : "graph replays", host_ms[v][host_ms[v].size() / 2]);
+      cur_v = v;
       setf(variants[v]);
       zero[3] = (zero[3] + 1) & 0x7FF;
       CK(hipMemcpy(d.state, zero, sizeof zero, hipMemcpyHostToDevice));
       double tot[8]; int64_t cnt[8];
       const int rc = prof(&d, &sp, n, 0xFF, tot, cnt, st);
       if (rc) { fprintf(stderr, "profile_loop: %d\n", rc); return 3; }
-      printf("flags %u weights %s rows %d: loop of %d steps median %.3f ms min %.3f ms (%.1f us/step) |", variants[v],
+      printf("flags %u:%u weights %s rows %d: loop of %d steps median %.3f ms min %.3f ms (%.1f us/step) |", variants[v], variants2[v],
              wd == VAURA_W_H2 ? "h2" : "h1", rows, n, ms[v][ms[v].size() / 2], ms[v][0], 1e3 * ms[v][ms[v].size() / 2] / n);
       for (int k = 0; k < 8; ++k) printf(" %s %.2f", kinds[k], 1e3 * tot[k] / (cnt[k] ? cnt[k] : 1));
       printf("\n");
     }
-    setf(0);
+    setf1(0);
+    if (setf2) setf2(0);
     return 0;
   }
   const int32_t st0[4] = {pos0, 0, 0, 1};

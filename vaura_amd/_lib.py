@@ -117,6 +117,7 @@ SIGNATURES = {
     "vaura_avclip_workspace_bytes": (C.c_size_t, [C.POINTER(Vit), C.c_int, C.c_int]),
     "vaura_version": (C.c_char_p, []),
     "vaura_set_debug_flags": (None, [C.c_uint]),
+    "vaura_set_debug_flags2": (None, [C.c_uint]),
     "vaura_debug_counter": (C.c_longlong, [C.c_int]),
     "vaura_struct_size": (C.c_size_t, [C.c_int]),
     "vaura_packed_weight_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int]),

@@ -279,18 +279,20 @@ struct StepGraph {
   hipGraph_t graph = nullptr, graphm = nullptr;
   hipGraphExec_t exec = nullptr, execm = nullptr;
   int multi = 1;
-  unsigned flags = 0;      // debug flags at build time: the lazily captured multi-step graph is the same variant
+  unsigned flags = 0, flags2 = 0;      // debug flags at build time: the lazily captured multi-step graph is the same variant
 };
 
-extern unsigned va_debug_flags;   // gemv3.hip
+extern unsigned va_debug_flags, va_debug_flags2;   // gemv3.hip
 static int build_multi(StepGraph* g, const vaura_decoder* dec, const vaura_sampling* sp, hipStream_t st) {
   hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return (int)e;
   int rc = 0;
-  const unsigned now = va_debug_flags;
+  const unsigned now = va_debug_flags, now2 = va_debug_flags2;
   va_debug_flags = g->flags;                        // the kernel variants of the handle, whatever the caller has set since
+  va_debug_flags2 = g->flags2;
   for (int i = 0; i < g->multi && !rc; ++i) rc = enqueue_step(dec, sp, 1, st);
   va_debug_flags = now;
+  va_debug_flags2 = now2;
   e = hipStreamEndCapture(st, &g->graphm);
   if (rc) return rc;
   if (e != hipSuccess) return (int)e;
@@ -352,6 +354,7 @@ int vaura_step_graph_build(const vaura_decoder* dec, const vaura_sampling* sp, v
   // steps per graph launch: bits 24..27 of vaura_set_debug_flags (0 = the default VA_GRAPH_STEPS), clamped to 1..16.  The long
   // graph is captured lazily by the first vaura_generate_loop that has at least that many steps to run (build_multi).
   g->flags = va_debug_flags_get();
+  g->flags2 = va_debug_flags2_get();
   const int req = (int)((g->flags >> 24) & 15u);
   g->multi = req ? std::min(16, std::max(1, req)) : VA_GRAPH_STEPS;
   *out = g;

@@ -14,18 +14,39 @@ unsigned va_debug_flags = 0;
 VA_STAMP_SETTER(vaura_stamps_set_gemv3)
 unsigned va_debug_flags_get() { return va_debug_flags; }
 
-template <int WT, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1>
+// second flag word (vaura_set_debug_flags2), bit 0: more than one row block -> still ONE row block per weight pass (round 4's walk: the
+// A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows
+unsigned va_debug_flags2 = 0;
+unsigned va_debug_flags2_get() { return va_debug_flags2; }
+static bool rb2(const Gemv3Args& a) { return a.R >= 2 && !(va_debug_flags2 & 1u); }
+
+// RB2 = true: the instance exists with two row blocks per weight pass as well (the decode step's shapes), taken when there are >= 2
+// (XBR = plane batches of THAT instance: with two row blocks' planes and accumulators in registers the K = 1536 instances of two and
+// three tiles take the planes in three batches, two in flight — all up front they spill)
+template <int WT, int G, int NW, int T, int EPI, bool NORM, int XB = 1, int KS = 1, bool RB2 = false, int XBR = XB>
 static int launch3(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   if (n_tiles % T) return VAURA_ERR_SHAPE;
+  if constexpr (RB2) {
+    if (rb2(a)) {
+      VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XBR, 0, WT, KS, 2>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a.W, a.XP, a);
+      return 0;
+    }
+  }
   VA_LAUNCH((gemv3_kernel<G, NW, T, EPI, NORM, XB, 0, WT, KS>), dim3((unsigned)(n_tiles / T * KS)), dim3(NW * 64), 0, s, a.W, a.XP, a);
   return 0;
 }
 
 
-template <int WT, int G2, int EPI, int XB, int NBF = 2, int NW = 8>
+template <int WT, int G2, int EPI, int XB, int NBF = 2, int NW = 8, bool RB2 = false>
 static int launch3h(const Gemv3Args& a, int64_t n_tiles, hipStream_t s) {
   const int halves = (a.R == 1 && a.rows <= 8) ? 1 : 2;    // at most 8 live rows: the second half would multiply zeros
   if (halves == 2 && (n_tiles % 8)) return VAURA_ERR_SHAPE;
+  if constexpr (RB2) {
+    if (rb2(a)) {
+      VA_LAUNCH((gemv3h_kernel<G2, NW, EPI, XB, WT, NBF, 2>), dim3((unsigned)(n_tiles * halves)), dim3(NW * 64), 0, s, a.W, a.XP, a, halves);
+      return 0;
+    }
+  }
   VA_LAUNCH((gemv3h_kernel<G2, NW, EPI, XB, WT, NBF>), dim3((unsigned)(n_tiles * halves)), dim3(NW * 64), 0, s, a.W, a.XP, a, halves);
   return 0;
 }
@@ -37,22 +58,22 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
   constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
   if constexpr (WT != 1) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
     if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
-      if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1>(a, tiles, s);
+      if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1, 2, 8, true>(a, tiles, s);
       if (K == 1536 && epilogue == E3_STORE) return launch3h<WT, 3, E3_STORE, 1>(a, tiles, s);
       // fp32 weights at K = 4096: four batches of two k-group pairs, two in flight.  (Three in flight measured the same 11.4 us:
       // this instance is bound by the bytes through each CU — 262 KB of weights + 196 KB of planes per workgroup — not by latency.)
-      if (K == 4096 && epilogue == E3_RESID) return launch3h<WT, 8, E3_RESID, (WT == 2 ? 4 : 1)>(a, tiles, s);
+      if (K == 4096 && epilogue == E3_RESID) return launch3h<WT, 8, E3_RESID, (WT == 2 ? 4 : 1), 2, 8, true>(a, tiles, s);
       if (K == 4096 && epilogue == E3_STORE) return launch3h<WT, 8, E3_STORE, (WT == 2 ? 4 : 1)>(a, tiles, s);
     }
   }
   if (K == 1536) {
     if (epilogue == E3_STORE && norm) return launch3<WT, 6, 8, 2, E3_STORE, true, XB2>(a, tiles, s);
     if (epilogue == E3_STORE && !norm) return launch3<WT, 6, 8, 1, E3_STORE, false>(a, tiles, s);
-    if (epilogue == E3_RESID && !norm) return launch3<WT, 6, 8, 1, E3_RESID, false>(a, tiles, s);
-    if (epilogue == E3_SWIGLU && norm) return launch3<WT, 6, 8, 2, E3_SWIGLU, true, XB2>(a, tiles, s);
-    if (epilogue == E3_LOGITS && norm) return launch3<WT, 6, 8, 3, E3_LOGITS, true, XB2>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<WT, 6, 8, 1, E3_RESID, false, 1, 1, true>(a, tiles, s);
+    if (epilogue == E3_SWIGLU && norm) return launch3<WT, 6, 8, 2, E3_SWIGLU, true, XB2, 1, true, 3>(a, tiles, s);
+    if (epilogue == E3_LOGITS && norm) return launch3<WT, 6, 8, 3, E3_LOGITS, true, XB2, 1, true, 3>(a, tiles, s);
   } else if (K == 4096) {
-    if (epilogue == E3_RESID && !norm) return launch3<WT, 16, 8, 1, E3_RESID, false, XB4>(a, tiles, s);
+    if (epilogue == E3_RESID && !norm) return launch3<WT, 16, 8, 1, E3_RESID, false, XB4, 1, true>(a, tiles, s);
     if (epilogue == E3_STORE && !norm) return launch3<WT, 16, 8, 1, E3_STORE, false, XB4>(a, tiles, s);
   }
   return VAURA_ERR_SHAPE;
@@ -179,9 +200,9 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   a.wscale = weight_scales(a, n_weight_rows, K);
   if (a.out2) {   // the caller asked for two K-half partials (decode qkv): fused norm, K = 1536 only
     if (K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
-    if (a.wq == 1) return launch3<1, 6, 4, 3, E3_STORE, true, 1, 2>(a, tiles, s);   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
-    if (a.wq == 2) return launch3<2, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
-    return launch3<0, 3, 8, 3, E3_STORE, true, 1, 2>(a, tiles, s);
+    if (a.wq == 1) return launch3<1, 6, 4, 3, E3_STORE, true, 1, 2, true>(a, tiles, s);   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
+    if (a.wq == 2) return launch3<2, 3, 8, 3, E3_STORE, true, 1, 2, true, 3>(a, tiles, s);
+    return launch3<0, 3, 8, 3, E3_STORE, true, 1, 2, true>(a, tiles, s);
   }
   // GEMM tiling only when there are enough row blocks to fill the chip with 64 x 256 tiles (a prompt pass); a decode
   // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
@@ -402,6 +423,7 @@ __global__ void split_rows_kernel(const float* __restrict__ src, uint16_t* __res
 extern "C" {
 
 void vaura_set_debug_flags(unsigned flags) { va_debug_flags = flags; }
+void vaura_set_debug_flags2(unsigned flags) { va_debug_flags2 = flags; }
 
 int vaura_split_rows(const float* src, uint16_t* dst, const float* gain, float* ss, int64_t rows, int64_t C, vaura_stream_t s) {
   if (!src || !dst || rows <= 0 || C <= 0 || (C % 16)) return VAURA_ERR_ARG;

@@ -200,7 +200,12 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
 // which the CONSUMER adds (attention gathers q, k, v anyway: one more 16-byte load).  For the qkv GEMV this turns
 // 144 workgroups into 192 with half the activation bytes each: more CUs, fewer bytes through each CU's memory pipeline, no
 // in-kernel seam.
-template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, int WT = 0, int KS = 1>
+// RBK = row blocks per WEIGHT PASS (round 5): with 17..32 decoder rows (the reference's default batch 16 under CFG, BASELINE configs[4])
+// a workgroup multiplies each weight fragment against the planes of RBK = 2 row blocks — second accumulator set, both blocks' planes
+// requested up front, ONE reduction barrier, the two blocks' epilogues on different waves — instead of walking the blocks one after
+// the other (which re-fetched the weights where they travel in batches, WT = 2 / XB > 1, and paid a reduction + epilogue round per
+// block everywhere: w1||w3 18.7 us against 10.0 at 16 rows).  Per row block the same products in the same order: bit-identical.
+template <int G, int NW, int T, int EPI, bool NORM, int XB = 1, int ABL = 0, int WT = 0, int KS = 1, int RBK = 1>
 __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a) {
   // Wq / XPq duplicate a.W / a.XP as explicit scalar arguments: with -amdgpu-kernarg-preload-count they arrive in SGPRs
   // at wave launch, so the address arithmetic of the first (weight) loads does not wait for a kernarg s_load
@@ -220,9 +225,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   constexpr int WH = F32 ? 2 : 1;             // 16-byte loads per lane, tile and k-group
   constexpr int GW = FP8 ? G / 2 : (WBATCH ? 2 * GB : G);   // weight register groups per tile
   constexpr int NACC = 2;
-  __shared__ f32x4 red[NW][T][64];
+  __shared__ f32x4 red[RBK][NW][T][64];
   constexpr int NSS = K / 64;            // partial sums of squares per lane: n_ss_in = K / 16 tiles, 4 lane groups
-  constexpr int EWN = (EPI == E3_SWIGLU) ? 1 : T;   // waves that run the epilogue (see below)
+  constexpr int EWN = (EPI == E3_SWIGLU) ? 1 : T;   // waves that run the epilogue of ONE row block (see below)
+  // epilogue groups: the row blocks of a pass finish side by side on different waves where the workgroup has enough of them
+  // (group e = waves [e EWN, (e + 1) EWN) takes row block rb0 + e), else one group walks them
+  constexpr int EG = (EWN * RBK <= NW) ? RBK : 1;
+  constexpr int EPW = RBK / EG;          // row blocks per epilogue wave
   // the epilogue waves fetch them straight into registers (24 VGPRs next to the weight slice); instances with more than 8
   // waves would park them in LDS instead (whole workgroup, one load each)
   constexpr bool SS_DIRECT = NORM && NW <= 8;
@@ -276,23 +285,29 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   // activation planes of the current batch of k-groups; the first batch of the NEXT row block is requested as soon as
   // the last MFMA of this one has been issued, so its round trip runs under the reduction / barrier / epilogue
   constexpr int NXB = XB > 1 ? 2 : 1;   // with several batches two are in flight (double buffer)
-  u32x4 xb[NXB][GB][VA_NPL];
-  auto load_x = [&](int rb, int b) {
-    const int xl16 = rb * 16 + m < a.rows ? lane16 : 0x7ffffff0;
+  u32x4 xb[RBK][NXB][GB][VA_NPL];
+  auto load_x1 = [&](int r, int rb, int b) {
+    const int xl16 = rb * 16 + m < a.rows ? lane16 : 0x7ffffff0;      // (a row block past the last one: every lane out of range -> zeros)
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
       for (int p = 0; p < VA_NPL; ++p)
-        xb[b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
+        xb[r][b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
                                       : __builtin_amdgcn_raw_buffer_load_b128(
                                             xrs, xl16, (int)(((rb * VA_NPL + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
+  };
+  auto load_x = [&](int rb0, int b) {
+#pragma unroll
+    for (int r = 0; r < RBK; ++r) load_x1(r, rb0 + r, b);
   };
 
   // the power-of-two row scales of the epilogue waves' tiles: requested with the first row block's operands (round 4: they were a
   // dependent L2 round trip BEHIND the reduction barrier of every GEMV: -0.2 .. -0.9 us per launch)
-  constexpr int EWN_ = (EPI == E3_SWIGLU) ? 1 : T, ET_ = (EPI == E3_SWIGLU) ? T : 1;
+  constexpr int ET_ = (EPI == E3_SWIGLU) ? T : 1;
   f32x4 wsc[ET_];
-  auto row_block = [&](const int rb, const bool first) {
+  const int eg = wid / EWN, ewi = wid - eg * EWN;   // this wave's epilogue group and its index inside it (waves past the groups: no epilogue)
+  const bool epi_wave = wid < EWN * EG;
+  auto row_block = [&](const int rb, const bool first) {     // rb = first row block of the pass
     if (first || WBATCH) {
       // all weight tiles first (HBM misses), then the planes (L2 hits)
       if constexpr (WBATCH) load_w(0, GB, 0);
@@ -305,16 +320,21 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
     // add them in tile order after their last MFMA and have rinv in a register BEFORE the reduction barrier.  (Round 2 parked
     // the partials in LDS and added them after the barrier in a load -> wait -> add loop of 24 dependent LDS round trips:
     // 1.0-1.3 us on the critical path of every normed GEMV, profiles/r03_stage_stamps.json.  Same sums, same order.)
-    float ssv[SS_DIRECT ? NSS : 1];
+    static_assert(RBK == 1 || !NORM || (NORM && NW <= 8), "several row blocks per pass: the partial sums travel in registers");
+    float ssv[EPW][SS_DIRECT ? NSS : 1];
     constexpr int SSN = (NORM && !SS_DIRECT) ? (K + NW * 64 - 1) / (NW * 64) : 1;
     float ssr[SSN];
     if constexpr (SS_DIRECT) {
-      if (wid < EWN) {
-        const float* sp = a.ss_in + (size_t)rb * a.n_ss_in * 16 + m;
+      if (epi_wave) {
 #pragma unroll
-        for (int j = 0; j < NSS; ++j) {
-          const int i = q + 4 * j;
-          ssv[j] = (i < a.n_ss_in) ? sp[i * 16] : 0.f;
+        for (int e = 0; e < EPW; ++e) {
+          const int rbe = min(rb + eg * EPW + e, a.R - 1);       // (a pass's row block past the last: any valid address, never used)
+          const float* sp = a.ss_in + (size_t)rbe * a.n_ss_in * 16 + m;
+#pragma unroll
+          for (int j = 0; j < NSS; ++j) {
+            const int i = q + 4 * j;
+            ssv[e][j] = (i < a.n_ss_in) ? sp[i * 16] : 0.f;
+          }
         }
       }
     } else if constexpr (NORM) {
@@ -329,20 +349,22 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
     // residual / gain of the epilogue wave's tile: behind the stream loads in issue order, landed long before the barrier
     EpiPre pre;
     pre.have = false;
-    if constexpr (EPI == E3_RESID && T == 1) {
-      if (wid == 0) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile0, lane);
+    if constexpr (EPI == E3_RESID && T == 1 && EPW == 1) {
+      if (epi_wave && rb + eg < a.R) pre = gemv3_epilogue_prefetch<EPI>(a, rb + eg, tile0, lane);
     }
-    if (first && wid < EWN_) {
+    if (first && epi_wave) {
 #pragma unroll
       for (int e = 0; e < ET_; ++e)
-        wsc[e] = *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + ((EPI == E3_SWIGLU) ? e : wid)) * 16 + 4 * q);
+        wsc[e] = *reinterpret_cast<const f32x4*>(a.wscale + (size_t)(tile0 + ((EPI == E3_SWIGLU) ? e : ewi)) * 16 + 4 * q);
     }
 
-    f32x4 acc[T][NACC];
+    f32x4 acc[RBK][T][NACC];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
-      for (int p = 0; p < NACC; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int p = 0; p < NACC; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (first) {
       VA_STAMP(stamps, 1);                   // every request of the first batch issued
       VA_WAIT_VM(GB * VA_NPL + (SS_DIRECT ? NSS : (NORM ? SSN : 0)));
@@ -373,27 +395,35 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
             wf[0] = __builtin_bit_cast(f16x8, wb[t][b * GB + g][0]);
           }
           if constexpr (ABL & 1) {
-            asm volatile("" ::"v"(wf[0]), "v"(xb[b % NXB][g][0]), "v"(xb[b % NXB][g][1]));
+            asm volatile("" ::"v"(wf[0]), "v"(xb[0][b % NXB][g][0]), "v"(xb[0][b % NXB][g][1]));
           } else {
-            mfma_group<WT>(wf, xb[b % NXB][g], acc[t]);
+#pragma unroll
+            for (int r = 0; r < RBK; ++r) mfma_group<WT>(wf, xb[r][b % NXB][g], acc[r][t]);
           }
         }
         if (first) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (rb + 1 < a.R) load_x(rb + 1, 0);
+    if (rb + RBK < a.R) load_x(rb + RBK, 0);
 
 #pragma unroll
-    for (int t = 0; t < T; ++t) red[wid][t][lane] = acc_sum<WT>(acc[t]);
-    float rinv = 1.f;
-    if constexpr (SS_DIRECT) {
-      if (wid < EWN) {
-        float ssp = 0.f;
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
-        for (int j = 0; j < NSS; ++j) ssp += ssv[j];      // tile order q, q + 4, ... (slots past n_ss_in hold 0)
-        ssp += va_xor16(ssp);
-        ssp += va_xor32(ssp);
-        rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+      for (int t = 0; t < T; ++t) red[r][wid][t][lane] = acc_sum<WT>(acc[r][t]);
+    float rinv[EPW];
+#pragma unroll
+    for (int e = 0; e < EPW; ++e) rinv[e] = 1.f;
+    if constexpr (SS_DIRECT) {
+      if (epi_wave) {
+#pragma unroll
+        for (int e = 0; e < EPW; ++e) {
+          float ssp = 0.f;
+#pragma unroll
+          for (int j = 0; j < NSS; ++j) ssp += ssv[e][j];      // tile order q, q + 4, ... (slots past n_ss_in hold 0)
+          ssp += va_xor16(ssp);
+          ssp += va_xor32(ssp);
+          rinv[e] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+        }
       }
     } else if constexpr (NORM) {
 #pragma unroll
@@ -410,7 +440,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
     constexpr int EW = (EPI == E3_SWIGLU) ? 1 : T;     // waves taking part
     constexpr int ET = (EPI == E3_SWIGLU) ? T : 1;     // tiles per such wave
     static_assert(EW == EWN, "the waves that fetched the partial sums run the epilogue");
-    if (wid < EW) {
+    if (epi_wave) {
       if constexpr (NORM && !SS_DIRECT) {
         // every LDS read issued before the first add (a fixed trip count: the round-2 loop over a.n_ss_in waited for each read)
         float pv[NSS];
@@ -421,19 +451,24 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         for (int j = 0; j < NSS; ++j) ssp += pv[j];
         ssp += va_xor16(ssp);
         ssp += va_xor32(ssp);
-        rinv = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
+        rinv[0] = 1.0f / sqrtf(ssp * (1.0f / (float)a.k_total) + a.eps);
       }
-      f32x4 v[ET];
 #pragma unroll
-      for (int e = 0; e < ET; ++e) {
-        const int t = (EPI == E3_SWIGLU) ? e : wid;
-        f32x4 sacc = red[0][t][lane];
+      for (int er = 0; er < EPW; ++er) {
+        const int r = eg * EPW + er;                      // row block of the pass this wave finishes
+        if (rb + r >= a.R) break;
+        f32x4 v[ET];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) sacc += red[i][t][lane];
-        sacc *= wsc[e];                                   // power-of-two row scales: exact
-        v[e] = sacc * rinv;
+        for (int e = 0; e < ET; ++e) {
+          const int t = (EPI == E3_SWIGLU) ? e : ewi;
+          f32x4 sacc = red[r][0][t][lane];
+#pragma unroll
+          for (int i = 1; i < NW; ++i) sacc += red[r][i][t][lane];
+          sacc *= wsc[e];                                   // power-of-two row scales: exact
+          v[e] = sacc * rinv[er];
+        }
+        gemv3_epilogue<ET, EPI>(a, rb + r, (EPI == E3_SWIGLU) ? tile0 : tile0 + ewi, lane, v, &pre);
       }
-      gemv3_epilogue<ET, EPI>(a, rb, (EPI == E3_SWIGLU) ? tile0 : tile0 + wid, lane, v, &pre);
     }
   };
 
@@ -443,7 +478,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   VA_STAMP(stamps, 6);                       // wave 0's epilogue stores acknowledged
   VA_STAMP_FLUSH(stamps, EPI == E3_SWIGLU ? 4 : (EPI == E3_LOGITS ? 6 : ((EPI == E3_STORE && NORM) ? 1 : 9)));
 #endif
-  for (int rb = 1; rb < a.R; ++rb) {
+  for (int rb = RBK; rb < a.R; rb += RBK) {
     __syncthreads();
     row_block(rb, false);
   }
@@ -462,7 +497,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
 // waves.  Every load instruction still moves 64 x 16 B in 128-byte runs.  Weight bytes per workgroup are unchanged (the two
 // workgroups of a tile read the same tiles: ids b and b + 8, i.e. the same XCD's L2 under round-robin placement — speed only).
 // G2 = k-group pairs per wave, XB = batches (weights and planes together, two in flight), WT = 0 bf16 | 2 fp32 weights.
-template <int G2, int NW, int EPI, int XB = 1, int WT = 0, int NBF = 2>
+// RBK = row blocks per weight pass (see gemv3_kernel): the workgroup of row half h takes rows 8 h .. 8 h + 7 of RBK row blocks at once.
+template <int G2, int NW, int EPI, int XB = 1, int WT = 0, int NBF = 2, int RBK = 1>
 __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict__ Wq, const uint16_t* __restrict__ XPq, Gemv3Args a, int halves) {
   VA_STAMP_DECL(stamps);
   VA_STAMP(stamps, 0);
@@ -480,7 +516,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   constexpr int NB = XB > 1 ? NBF : 1;        // batches in flight (buffers)
   static_assert(NBF >= 2 && NBF <= XB + 1, "two or three batches in flight");
   constexpr int BS = 1024 * WH;               // bytes of one (tile, k-group) block
-  __shared__ f32x4 red[NW][2][64];
+  __shared__ f32x4 red[RBK][NW][2][64];
+  static_assert(RBK <= NW, "one epilogue wave per row block of a pass");
 
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -496,7 +533,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;   // batch row la + 8 h of the block (out of range below when it does not exist)
 
   u32x4 wb[NB][GB][2][WH];
-  u32x4 xb[NB][GB][VA_NPL];
+  u32x4 xb[RBK][NB][GB][VA_NPL];
   f32x4 wsc = f32x4{1.f, 1.f, 1.f, 1.f};
   auto load_w = [&](int b) {
 #pragma unroll
@@ -509,16 +546,20 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
           wb[b % NB][g][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
     }
   };
-  auto load_x = [&](int rb, int b) {
+  auto load_x = [&](int rb0, int b) {
 #pragma unroll
-    for (int g = 0; g < GB; ++g)
+    for (int r = 0; r < RBK; ++r) {
+      const int rb = rb0 + r;
 #pragma unroll
-      for (int p = 0; p < VA_NPL; ++p)
-        xb[b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, rb * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0,
-                                                                 ((rb * VA_NPL + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int p = 0; p < VA_NPL; ++p)
+          xb[r][b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, rb * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0,
+                                                                      ((rb * VA_NPL + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
+    }
   };
 
-  for (int rb = 0; rb < a.R; ++rb) {
+  for (int rb = 0; rb < a.R; rb += RBK) {          // rb = first row block of the pass
     if (rb > 0) __syncthreads();
     if (rb == 0 || XB > 1) load_w(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -529,14 +570,17 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
     }
     EpiPre pre;
     pre.have = false;
-    if (wid == 0 && ((lane >> 3) & 1) == h) pre = gemv3_epilogue_prefetch<EPI>(a, rb, tile, lane);
-    if (wid == 0 && rb == 0) wsc = *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);   // with the operands, not behind the barrier
+    // epilogue waves: wave r finishes row block rb + r of the pass
+    if (wid < RBK && rb + wid < a.R && ((lane >> 3) & 1) == h) pre = gemv3_epilogue_prefetch<EPI>(a, rb + wid, tile, lane);
+    if (wid < RBK && rb == 0) wsc = *reinterpret_cast<const f32x4*>(a.wscale + (size_t)tile * 16 + 4 * q);   // with the operands, not behind the barrier
 
-    f32x4 acc[2][NACC];
+    f32x4 acc[RBK][2][NACC];
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
-      for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int p = 0; p < NACC; ++p) acc[r][nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (rb == 0) {
       VA_STAMP(stamps, 1);
       VA_WAIT_VM(GB * VA_NPL + 2);           // wave 0 also holds the residual / gain requests
@@ -554,37 +598,40 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
           f16x8 wf[F32 ? 2 : 1];
           wf[0] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][0]);
           if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][WH - 1]);
-          mfma_group<WT>(wf, xb[b % NB][g], acc[nh]);
+#pragma unroll
+          for (int r = 0; r < RBK; ++r) mfma_group<WT>(wf, xb[r][b % NB][g], acc[r][nh]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     // the two k-groups of a pair sit in lanes (s' = 0, q < 2) and (s' = 1, q >= 2) of the same (n, row): lane ^ 40
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-      f32x4 v = acc_sum<WT>(acc[nh]);
-      f32x4 o;
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x = v[r];
-        o[r] = x + va_dpp<VA_DPP_ROR8>(va_xor32(x));      // lane ^ 40
+      for (int nh = 0; nh < 2; ++nh) {
+        f32x4 v = acc_sum<WT>(acc[r][nh]);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = v[c];
+          o[c] = x + va_dpp<VA_DPP_ROR8>(va_xor32(x));      // lane ^ 40
+        }
+        red[r][wid][nh][lane] = o;
       }
-      red[wid][nh][lane] = o;
-    }
     if (rb == 0) VA_STAMP(stamps, 4);
     __syncthreads();
     if (rb == 0) VA_STAMP(stamps, 5);
-    if (wid == 0) {
+    if (wid < RBK && rb + wid < a.R) {
       // epilogue lane (m = lane & 15, q' = lane >> 4) = row m, columns 4 q' .. 4 q' + 3 of the tile: weight rows n = 4 q' + r
       // -> nh = q' >> 1, source lane (s' = 0 copy) = (m & 7) + 16 (q' & 1); rows of the other half are not this workgroup's
       const int m = lane & 15;
       const bool mine = (m >> 3) == h;
       const int src = (m & 7) + 16 * (q & 1);
-      f32x4 v = red[0][q >> 1][src];
+      f32x4 v = red[wid][0][q >> 1][src];
 #pragma unroll
-      for (int i = 1; i < NW; ++i) v += red[i][q >> 1][src];
+      for (int i = 1; i < NW; ++i) v += red[wid][i][q >> 1][src];
       v *= wsc;                                         // power-of-two row scales: exact
-      if (mine) gemv3_epilogue<1, EPI>(a, rb, tile, lane, &v, &pre);
+      if (mine) gemv3_epilogue<1, EPI>(a, rb + wid, tile, lane, &v, &pre);
     }
 #ifdef VAURA_STAMPS
     if (rb == 0) {
