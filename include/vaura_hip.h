@@ -136,10 +136,10 @@ typedef struct vaura_decoder {
                                 where every overflow of the fp16-plane activation format ends up (|activation| > 65504 -> inf
                                 in the hi plane -> NaN in the residual stream).  [5]=launch-epoch counter of the in-launch hand-offs,
                                 OWNED BY THE LIBRARY: whatever ends a decode step (sampler, teacher-forced advance) bumps it and
-                                nothing rewinds it, so every launch that shares the hand-off flag words (ws_sync) gets a fresh
-                                epoch even when the caller rewinds [0] or restarts a sequence with [3] unchanged.  Contract:
-                                zero it only together with ws_sync (a fresh allocation of both is fine), never write it
-                                otherwise.  [6..7] spare */
+                                nothing rewinds it.  A hand-off epoch is (state[3] sequence id, state[5], layer): rewinding [0]
+                                inside a sequence is safe; a NEW sequence, a state buffer that starts from zero again, or another
+                                decoder instance in the same process must come with a new sequence id in [3] (10 bits are
+                                used) — the arrival words of the hand-offs live in LDS and outlive launches.  [6..7] spare */
   const float* noise;        /* optional (n_steps, B*K, vocab) Exp(1) draws; NULL -> Philox */
 
   float* ws_h;               /* packed rows (rows x d_model) residual stream        */

@@ -844,7 +844,7 @@ def test_full_length_codec_decode_and_encode_match_the_oracle_on_the_256_row_ins
     assert min(agree_all) > 0.9
 
 
-def test_range_guard_raises_instead_of_decoding_garbage():
+def test_range_guard_detects_overflow_and_the_checked_call_reruns_it_in_fp32():
     """Activations travel between the decode kernels as (hi, lo) fp16 planes: |x| > 65504 becomes inf / NaN.  A checkpoint whose
     residual stream x next-norm gain leaves that range (token embedding and norm gains scaled up: values ~1e5..1e6) must end in
     VauraHipError from check_status() — the sampler raises the sticky device status bit on non-finite logits — not in tokens;
@@ -872,6 +872,21 @@ def test_range_guard_raises_instead_of_decoding_garbage():
     tok = e3.generate_codes(feats, 12, cfg_scale=6.0).cpu()
     e3.check_status()
     assert int(tok.min()) >= 0 and int(tok.max()) < 1024
+    # RANGE SAFETY BY CONSTRUCTION (generate_codes_checked, what VAURAModel.generate calls): the overflowing call is re-run on the
+    # exact-fp32 twin — the x3000 checkpoint decodes token-exact against the oracle, greedy and sampled, instead of raising
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    dec = DecoderOracle(big, cfg.num_layers, cfg.nhead)
+    ref = go.generate(dec, feats.cpu(), 12, mode="cached", cfg_scale=6.0)
+    got = e2.generate_codes_checked(feats, 12, cfg_scale=6.0).cpu()
+    assert e2.range_fallbacks == 1 and torch.equal(got, ref) and torch.equal(got, tok)
+    nz = synth.exp_noise(12 + 9 - 1, 18, 1024, 83)
+    refs = go.generate(dec, feats.cpu(), 12, mode="cached", cfg_scale=6.0, use_sampling=True, top_k=128, noise=nz)
+    gots = e2.generate_codes_checked(feats, 12, cfg_scale=6.0, use_sampling=True, top_k=128, noise=nz).cpu()
+    assert e2.range_fallbacks == 2 and torch.equal(gots, refs)
+    e2.check_status()                                   # nothing left behind
+    # a checkpoint that stays in range never takes the detour
+    assert torch.equal(eng.generate_codes_checked(feats, 12, cfg_scale=6.0), eng.generate_codes(feats, 12, cfg_scale=6.0)) and eng.range_fallbacks == 0
 
 
 @pytest.mark.parametrize("precision", ["f16pair", "f16", "f16pair_w8"])
@@ -953,7 +968,7 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
     assert err < 3e-5 * max(1.0, float(lg_ref.abs().max())), err
 
 
-@pytest.mark.parametrize("clips", [6, 3])
+@pytest.mark.parametrize("clips", [6, 3, 16, 10])
 @pytest.mark.parametrize("wdtype", ["h2", "h1"])
 def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     """csrc/mlp_engine.h, the default where eligible: the MLP of a layer (w1||w3 + SwiGLU -> w2 + residual) as ONE launch with an
@@ -962,7 +977,10 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     logits must be BIT-identical, tokens (greedy + CFG, and Philox-sampled) identical, through the eager path and through the
     captured step graph, and no consumer may have given up waiting (status word clean).  6 clips x cfg = 12 decoder rows (both row
     halves live) and 3 clips = 6 rows (configs[3]'s regime: one live half; the separate launches then use one workgroup per tile, the
-    one-launch form keeps its (tile, row half) workgroups and the second half multiplies zeros)."""
+    one-launch form keeps its (tile, row half) workgroups and the second half multiplies zeros).  Round 5: 16 clips x cfg = 32 rows (the
+    reference's default batch, configs/generate_vgg.yaml:41) and 10 clips = 20 rows (second row block ragged): the two-row-block
+    instances (mlp_engine_kernel<.., RBK = 2>) against the separate two-row-block launches; the attention + wo and tail experiments
+    do not exist there (the flags then select the default)."""
     from vaura_amd import _lib as L
     cfg = synth.tiny_sampler(3)
     sd = synth.sampler_state_dict(cfg, seed=101, round_bf16=(wdtype == "h1"))
@@ -994,8 +1012,9 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     assert torch.equal(out[4][1], out[4][3])
 
 
+@pytest.mark.parametrize("clips", [8, 16])
 @pytest.mark.parametrize("one_launch", [True, False])
-def test_one_launch_mlp_under_concurrent_load_and_repeats(one_launch):
+def test_one_launch_mlp_under_concurrent_load_and_repeats(one_launch, clips):
     """The in-launch hand-offs of csrc/mlp_engine.h under conditions an idle chip hides (MI355X_MICROARCH.md: "test every hand-off under
     UNEVEN load"): (1) the decode loop replayed many times on the same inputs must give the same tokens every time (a stale plane or a
     flag seen too early would show as a difference sooner or later); (2) with a SECOND stream keeping the chip busy with full-chip
@@ -1005,7 +1024,7 @@ def test_one_launch_mlp_under_concurrent_load_and_repeats(one_launch):
     sd = synth.sampler_state_dict(cfg, seed=111, round_bf16=False)
     eng = DecoderEngine(cfg, sd, DEV, one_launch_mlp=one_launch)     # False: the control (separate launches under the same load)
     assert eng.wdtype == "h2" and eng.one_launch_mlp == one_launch
-    feats = synth.video_features(8, seed=112).to(DEV)
+    feats = synth.video_features(clips, seed=112).to(DEV)            # 16 clips: 32 rows, the two-row-block instances
     kw = dict(cfg_scale=6.0, use_sampling=True, top_k=250, seed=5)
     ref = eng.generate_codes(feats, 60, **kw).clone()
     eng.check_status()

@@ -121,7 +121,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // EXPERIMENT (debug flag bit 12): attention + wo as one launch too (csrc/attention.hip attn_wo_kernel; single-round-trip attention
   // only: cache <= 256 positions, 16 heads).  Bit-identical and measured SLOWER than the two launches (13.7 us against 7.05 + 0.7 +
   // 4.8: the loop +3.3 % two planes / +3.8 % one): wo's stream is 1.5 us, nothing a run-ahead could hide pays for the hand-off.
-  const bool attn_wo = mlp_engine && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u);
+  const bool attn_wo = mlp_engine && rows <= 16 && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u);
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -153,7 +153,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     if (rc) return rc;
     }
     const Gemv3Args awo = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
-    if (mlp_engine && (va_debug_flags_get() & 8u)) {
+    if (mlp_engine && rows <= 16 && (va_debug_flags_get() & 8u)) {
       // EXPERIMENT (debug flag bit 3): the whole layer TAIL as one launch — wo + residual -> hand-off -> w1||w3 + SwiGLU -> hand-off
       // -> w2 + residual (csrc/mlp_engine.h tail_engine_kernel).  Bit-identical, and measured no faster than wo + the two-phase
       // engine (two planes -0.5 %, one plane +1.5 % on the loop): the first hand-off costs what wo's kernel boundary costs, and

@@ -207,12 +207,14 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
 int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);
 int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n_pos, hipStream_t s);
 
-// Epoch of an in-launch hand-off (mlp_engine.h, the attention + wo experiment): the flag words are never reset, a hand-off passes when
-// every producer's word holds THIS launch's epoch, so no two launches that share flag words may share an epoch while a stale word can
-// still be seen.  state[5] is a launch-epoch counter OWNED BY THE LIBRARY: bumped by whatever ends a decode step (the sampler's last
-// workgroup, advance_kernel), never rewound — so a caller that rewinds the position (state[0]) or restarts a sequence without changing
-// state[3] still gets fresh epochs (round 4's epoch was (state[3], state[0] + 1, layer): re-running a (sequence, position) step on the
-// same flags matched stale words).  27 bits of counter x 32 layers; + 1 keeps zeroed flag words below every epoch.
+// Epoch of an in-launch hand-off (mlp_engine.h, the attention + wo experiment): neither the flag words in global memory nor the arrival
+// words in LDS are ever reset — a hand-off passes when every producer's word holds THIS launch's epoch — so no two launches that can
+// see each other's words may share an epoch.  epoch = (sequence id state[3], 10 bits | launch-epoch counter state[5], 17 bits | layer)
+// + 1.  state[5] is OWNED BY THE LIBRARY: bumped by whatever ends a decode step (the sampler's last workgroup, advance_kernel), never
+// rewound — a caller that rewinds the position (state[0]) within a sequence still gets fresh epochs (round 4's epoch used state[0] and
+// matched stale words when a (sequence, position) step was re-run).  state[3] is the CALLER's: a new value for every sequence start
+// and for every decoder instance of the process — LDS keeps its words across launches and instances, so a state buffer that starts
+// from zero again must come with a new sequence id (DecoderEngine._reset_state: a process-wide counter).
 __device__ __forceinline__ uint32_t va_handoff_epoch(const int32_t* state, int layer) {
-  return ((((uint32_t)state[5] & 0x7ffffffu) << 5) | ((uint32_t)layer & 31u)) + 1u;
+  return ((((uint32_t)state[3] & 0x3ffu) << 22) | (((uint32_t)state[5] & 0x1ffffu) << 5) | ((uint32_t)layer & 31u)) + 1u;
 }

@@ -218,7 +218,8 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
 // second row half of phases 2 / 3 multiplies zeros (the separate launches use one workgroup per tile there) — still the faster form:
 // configs[3] (4 rows, 10.24 s) 33.7 k -> 36.9 k tokens/s.
 bool va_mlp_engine_eligible(const vaura_decoder* d) {
-  if (!d->ws_sync || !d->state || d->rows < 1 || d->rows > 16) return false;
+  if (!d->ws_sync || !d->state || d->rows < 1 || d->rows > 32) return false;
+  if (d->rows > 16 && (va_debug_flags2 & 2u)) return false;          // second flag word, bit 1: 17..32 rows keep the separate launches
   if (d->wdtype != VAURA_W_H1 && d->wdtype != VAURA_W_H2) return false;
   if (d->dims.d_model != 1536 || d->dims.ffn_dim != 4096) return false;
   static int cus[64] = {};
@@ -232,12 +233,12 @@ bool va_mlp_engine_eligible(const vaura_decoder* d) {
   return cus[dev] >= 256;
 }
 
-template <int WT, bool QKV>
+template <int WT, bool QKV, int RBK = 1>
 static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
-  using SH = MlpEngineShape<WT>;
+  using SH = MlpEngineShape<WT, RBK>;
   static unsigned long long big = 0;
-  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT, QKV>), SH::LDS, &big)) return VAURA_ERR_STATE;
-  VA_LAUNCH((mlp_engine_kernel<WT, QKV>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
+  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT, QKV, RBK>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  VA_LAUNCH((mlp_engine_kernel<WT, QKV, RBK>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
   return 0;
 }
 
@@ -249,16 +250,20 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
   e.p2 = a2;
   e.p3 = aq ? *aq : a2;
   if (aq) {
-    if (!aq->W || !aq->out || !aq->out2 || !aq->ss_in || aq->XP != a2.outp || aq->ss_in != a2.ss_out || aq->R != 1) return VAURA_ERR_ARG;
+    if (!aq->W || !aq->out || !aq->out2 || !aq->ss_in || aq->XP != a2.outp || aq->ss_in != a2.ss_out || aq->R != a2.R) return VAURA_ERR_ARG;
     if (aq->wq != a2.wq || aq->N != 3 * 1536 || aq->k_total != 1536 || aq->n_ss_in != 96) return VAURA_ERR_SHAPE;
     e.p3.wscale = weight_scales(*aq, 3 * 1536, 1536);
   }
-  if (!a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || a13.R != 1 || a2.R != 1) return VAURA_ERR_ARG;
+  if (!a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || a13.R < 1 || a13.R > 2 || a2.R != a13.R) return VAURA_ERR_ARG;
   if (a13.wq != a2.wq || (a13.wq != 0 && a13.wq != 2) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 || a13.n_ss_in != 96) return VAURA_ERR_SHAPE;
   e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
+  if (a13.R == 2) {       // 17..32 decoder rows: both row blocks per weight fragment
+    if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 2>(e, s) : launch_mlp_engine_t<0, true, 2>(e, s);
+    return a13.wq == 2 ? launch_mlp_engine_t<2, false, 2>(e, s) : launch_mlp_engine_t<0, false, 2>(e, s);
+  }
   if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true>(e, s) : launch_mlp_engine_t<0, true>(e, s);
   return a13.wq == 2 ? launch_mlp_engine_t<2, false>(e, s) : launch_mlp_engine_t<0, false>(e, s);
 }

@@ -67,13 +67,15 @@ struct MlpEngineArgs {
 #define MLPE_NW 8
 #define MLPE_SPIN_LIMIT 20000
 
-template <int WT>
+// RBK = row blocks per weight pass (round 5; gemv3_kernel.h): 2 for 17..32 decoder rows.  The reduction tiles double (48 KB), so the
+// ring gives up a quarter (12 KB per wave) and one more k-group pair per plane travels in registers.
+template <int WT, int RBK = 1>
 struct MlpEngineShape {
   static constexpr int WH = WT == 2 ? 2 : 1;
   static constexpr int G2 = 8;                         // k-group pairs per wave in phase 2 (K = 4096)
-  static constexpr int PL = WT == 2 ? 4 : 8;           // pairs per wave whose weights wait in LDS (the rest in registers)
-  static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB
-  static constexpr int RED = MLPE_NW * 3 * 64 * 16;    // reduction tiles (every phase; the qkv phase has three tiles per wave)
+  static constexpr int PL = RBK == 2 ? (WT == 2 ? 3 : 6) : (WT == 2 ? 4 : 8);   // pairs per wave whose weights wait in LDS (the rest in registers)
+  static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB (12 KB with two row blocks)
+  static constexpr int RED = RBK * MLPE_NW * 3 * 64 * 16;    // reduction tiles (every phase; the qkv phase has three tiles per wave)
   static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 128;     // + the arrival / hand-shake words
 };
 
@@ -131,10 +133,14 @@ __device__ __forceinline__ uint32_t mlpe_ld_sc1(const uint32_t* p) {
   return v;
 }
 
-template <int WT, bool QKV>
+// RBK = 2 (17..32 decoder rows): every phase multiplies each weight fragment against the planes of BOTH row blocks (second accumulator
+// set, the planes of both requested together); wave r finishes row block r of a phase (waves 3 r .. 3 r + 2 in the qkv phase) and wave
+// 0 publishes once wave 1 has drained its stores too (an LDS word).  Per row block the same products in the same order as the separate
+// two-row-block launches (gemv3_kernel / gemv3h_kernel RBK = 2): bit-identical to them.
+template <int WT, bool QKV, int RBK = 1>
 __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __restrict__ W13q, const uint16_t* __restrict__ XPq,
                                                                   const void* __restrict__ W2q, MlpEngineArgs e) {
-  using SH = MlpEngineShape<WT>;
+  using SH = MlpEngineShape<WT, RBK>;
   constexpr bool F32 = WT == 2;
   constexpr int WH = SH::WH, NW = MLPE_NW, NACC = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlpe_lds[];
@@ -158,6 +164,8 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   EpiPre pre;
   pre.have = false;
   f32x4 ws1[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}}, ws2 = f32x4{1.f, 1.f, 1.f, 1.f};
+  // LDS words of the two-row-block instances: arrive[18] / arrive[19] <- wave 1 has drained its phase-1 / phase-2 epilogue stores
+  const bool epw = wid < RBK;                  // this wave finishes a row block (wave r: row block r) in phases 1 and 2
 
   // ================================================================ phase 1: w1||w3 + SwiGLU (gemv3_kernel<6, 8, 2, E3_SWIGLU, true>)
   {
@@ -190,32 +198,35 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       }
     };
     constexpr int NXB = XB > 1 ? 2 : 1;
-    u32x4 xb[NXB][GB][VA_NPL];
+    u32x4 xb[RBK][NXB][GB][VA_NPL];
     auto load_x = [&](int b) {
-      const int xl16 = m < a.rows ? lane16 : 0x7ffffff0;
 #pragma unroll
-      for (int g = 0; g < GB; ++g)
+      for (int r = 0; r < RBK; ++r) {
+        const int xl16 = r * 16 + m < a.rows ? lane16 : 0x7ffffff0;
 #pragma unroll
-        for (int p = 0; p < VA_NPL; ++p)
-          xb[b % NXB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xl16, (int)((p * (K / 8) * 16 + (w * G + b * GB + g) * 64) * 16), 0);
+        for (int g = 0; g < GB; ++g)
+#pragma unroll
+          for (int p = 0; p < VA_NPL; ++p)
+            xb[r][b % NXB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xl16, (int)(((r * VA_NPL + p) * (K / 8) * 16 + (w * G + b * GB + g) * 64) * 16), 0);
+      }
     };
     if constexpr (WBATCH) load_w(0, GB, 0);
     else load_w(0, G, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_x(0);
     float ssv[NSS];                                    // n_ss_in == K / 16 == 4 NSS (checked by the launcher): no bounds to test
-    if (wid == 0) {
-      const float* sp = a.ss_in + m;
+    if (epw) {
+      const float* sp = a.ss_in + (size_t)wid * a.n_ss_in * 16 + m;         // row block wid
 #pragma unroll
       for (int j = 0; j < NSS; ++j) ssv[j] = sp[(q + 4 * j) * 16];
     }
     // wave 0, behind its stream requests (HBM misses first): what the two epilogues need and earlier KERNELS wrote — the residual
     // tile and next norm's gain of phase 2, the power-of-two row scales of both (a dependent L2 round trip behind the reduction
     // otherwise)
-    if (wid == 0) {
+    if (epw) {
       if (bid < 192) {
         const int h2_ = (bid >> 3) & 1, tile2_ = (bid & 7) + 8 * (bid >> 4);
-        if (((lane >> 3) & 1) == h2_) pre = gemv3_epilogue_prefetch<E3_RESID>(e.p2, 0, tile2_, lane);
+        if (((lane >> 3) & 1) == h2_) pre = gemv3_epilogue_prefetch<E3_RESID>(e.p2, wid, tile2_, lane);
         ws2 = *reinterpret_cast<const f32x4*>(e.p2.wscale + (size_t)tile2_ * 16 + 4 * q);
       }
       ws1[0] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2) * 16 + 4 * q);
@@ -223,11 +234,13 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     }
     __builtin_amdgcn_sched_barrier(0);                 // every request of the first batch is out before anything is waited for
     VA_STAMP(stamps, 1);                               // phase 1: first batch requested
-    f32x4 acc[T][NACC];
+    f32x4 acc[RBK][T][NACC];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
-      for (int p = 0; p < NACC; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int p = 0; p < NACC; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < XB; ++b) {
       if (b + 1 < XB) {
@@ -246,13 +259,16 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
           } else {
             wf[0] = __builtin_bit_cast(f16x8, wb[t][b * GB + g][0]);
           }
-          mfma_group<WT>(wf, xb[b % NXB][g], acc[t]);
+#pragma unroll
+          for (int r = 0; r < RBK; ++r) mfma_group<WT>(wf, xb[r][b % NXB][g], acc[r][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
-    for (int t = 0; t < T; ++t) red[(wid * T + t) * 64 + lane] = acc_sum<WT>(acc[t]);
+    for (int r = 0; r < RBK; ++r)
+#pragma unroll
+      for (int t = 0; t < T; ++t) red[((r * NW + wid) * T + t) * 64 + lane] = acc_sum<WT>(acc[r][t]);
     // arrival words instead of a workgroup barrier: waves 1..7 go on to request their w2 slice at once; wave 0 alone waits for
     // the tiles.  A wave's word carries this launch's epoch mixed with the workgroup id (LDS keeps what the previous workgroup on
     // this CU left: another epoch or another workgroup's tag, never this one), so nothing has to be initialised and no barrier
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // the word lands behind the tiles (release: the compiler keeps that order too).
     if (lane == 0) __hip_atomic_store(arrive + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     VA_STAMP(stamps, 2);                               // phase 1: products done, tiles in LDS
-    if (wid == 0) {
+    if (epw) {
       float ssp = 0.f;
 #pragma unroll
       for (int j = 0; j < NSS; ++j) ssp += ssv[j];
@@ -280,16 +296,24 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       f32x4 v[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        f32x4 sacc = red[(0 * T + t) * 64 + lane];
+        f32x4 sacc = red[((wid * NW + 0) * T + t) * 64 + lane];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) sacc += red[(i * T + t) * 64 + lane];
+        for (int i = 1; i < NW; ++i) sacc += red[((wid * NW + i) * T + t) * 64 + lane];
         sacc *= ws1[t];
         v[t] = sacc * rinv;
       }
-      gemv3_epilogue<T, E3_SWIGLU>(a, 0, tile0, lane, v, nullptr);
+      if (wid * 16 < a.rows) gemv3_epilogue<T, E3_SWIGLU>(a, wid, tile0, lane, v, nullptr);
 #ifdef MLPE_DIAG
       VA_STAMP(stamps, 5);
 #endif
+      if constexpr (RBK == 2) {
+        if (wid == 1) {      // the second row block's tile: stored (write-through), drained, then the word wave 0 waits for before it publishes
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(arrive + 18, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    if (wid == 0) {
       if (!MLPE_REL && lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // releases the held part of the other waves' run-ahead (phase 2)
       // (Measured and rejected, round 4: holding the other waves' run-ahead requests back until these stores are in the CU's memory
       // pipeline.  A CU serves its vector-memory requests in order, so the publish waits behind the seven waves' 224 KB of requests
@@ -298,6 +322,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       // second phase is the 393 KB each CU has to take in, in whatever order.)
       // publish: this wave stored the workgroup's whole ffn tile (write-through); drained, then the flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (RBK == 2) {
+        while (__hip_atomic_load(arrive + 18, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag) __builtin_amdgcn_s_sleep(1);
+      }
       if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + bid), "v"(epoch) : "memory");
       if (MLPE_REL && lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       VA_STAMP(stamps, 3);                             // wave 0: published
@@ -362,7 +389,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       // partial hold: waves 1..7 request MLPE_Q2 quarters of their slice at once and the rest only when wave 0's epilogue stores are in
       // the CU's memory pipeline (ablation bit 3: no hold, round 4's first form); wave 0 comes here behind its publish and holds nothing
       constexpr int Q2 = MlpeThrottle<WT>::Q2;
-      const bool hold = wid != 0;
+      const bool hold = wid >= RBK;                    // (the waves that finish a row block come here behind their own stores and hold nothing)
       if (!hold || Q2 > 0) prefetch_q(std::integral_constant<int, 0>{});
       if (!hold || Q2 > 1) prefetch_q(std::integral_constant<int, 1>{});
       if (!hold || Q2 > 2) prefetch_q(std::integral_constant<int, 2>{});
@@ -400,16 +427,25 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     VA_STAMP(stamps, 4);                               // hand-off barrier passed (wave 0: its poll matched just before)
     if (e.abl & 4) prefetch_w2();
 
-    // ---- the planes of this workgroup's 8 rows over its wave's K slice: every load sc1 (the producers stored write-through)
-    u32x4 xb[G2][VA_NPL];
-    {
-      const int vx = la + 8 * h < a.rows ? voffx : 0x7ffffff0;
+    // ---- the planes of this workgroup's 8 rows (of every row block) over its wave's K slice: every load sc1 (the producers stored
+    //      write-through).  Two row blocks: the second block's last four pairs are requested into the registers the first block's
+    //      first four release (all 32 fragments at once do not fit next to the weights).
+    u32x4 xb[RBK][G2][VA_NPL];
+    auto load_xr = [&](auto rc, auto j0c, auto j1c) {
+      constexpr int r = decltype(rc)::value, j0 = decltype(j0c)::value, j1 = decltype(j1c)::value;
+      const int vx = r * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0;
 #pragma unroll
-      for (int j = 0; j < G2; ++j)
+      for (int j = j0; j < j1; ++j)
 #pragma unroll
         for (int p = 0; p < VA_NPL; ++p)
-          xb[j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, (p * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
-    }
+          xb[r][j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, ((r * VA_NPL + p) * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IH = std::integral_constant<int, G2 / 2>;
+    using IG = std::integral_constant<int, G2>;
+    load_xr(I0{}, I0{}, IG{});
+    if constexpr (RBK == 2) load_xr(I1{}, I0{}, IH{});
     __builtin_amdgcn_sched_barrier(0);                 // ONE round trip for the planes: all 16 requests before the first wait
     // The ring was filled by LDS-DMA: the compiler does not know those instructions write LDS and would read fragments while they
     // are still in flight (it issued the first ds_reads AHEAD of its own wait for the planes).  On a quiet chip the DMA has landed
@@ -422,50 +458,70 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #ifndef MLPE_DIAG
     VA_STAMP(stamps, 5);                               // (diagnostic build) weights and planes landed
 #endif
-    f32x4 acc[2][NACC];
+    f32x4 acc[RBK][2][NACC];
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
-      for (int p = 0; p < NACC; ++p) acc[nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-    for (int j = 0; j < G2; ++j) {
+        for (int p = 0; p < NACC; ++p) acc[r][nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // products of row block r over pairs [j0, j1): k order inside a row block is that of gemv3h_kernel, whatever the interleaving
+    auto products = [&](auto rc, auto j0c, auto j1c) {
+      constexpr int r = decltype(rc)::value, j0 = decltype(j0c)::value, j1 = decltype(j1c)::value;
+#pragma unroll
+      for (int j = j0; j < j1; ++j) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          f16x8 wf[F32 ? 2 : 1];
+          if (j < PL) {
+            const u32x4* fr = reinterpret_cast<const u32x4*>(myring + ((2 * j + sb) * WH) * 1024) + (la + 8 * nh + 16 * q);
+            wf[0] = __builtin_bit_cast(f16x8, fr[0]);
+            if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, fr[64]);
+          } else {
+            wf[0] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][0]);
+            if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][WH - 1]);
+          }
+          mfma_group<WT>(wf, xb[r][j], acc[r][nh]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if constexpr (RBK == 1) {
+      products(I0{}, I0{}, IG{});
+    } else {
+      products(I0{}, I0{}, IH{});
+      load_xr(I1{}, IH{}, IG{});                       // into the registers block 0's first half has just released
+      __builtin_amdgcn_sched_barrier(0);
+      products(I0{}, IH{}, IG{});
+      products(I1{}, I0{}, IH{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      products(I1{}, IH{}, IG{});
+    }
+#pragma unroll
+    for (int r = 0; r < RBK; ++r)
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
-        f16x8 wf[F32 ? 2 : 1];
-        if (j < PL) {
-          const u32x4* fr = reinterpret_cast<const u32x4*>(myring + ((2 * j + sb) * WH) * 1024) + (la + 8 * nh + 16 * q);
-          wf[0] = __builtin_bit_cast(f16x8, fr[0]);
-          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, fr[64]);
-        } else {
-          wf[0] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][0]);
-          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][WH - 1]);
+        const f32x4 v = acc_sum<WT>(acc[r][nh]);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = v[c];
+          o[c] = x + va_dpp<VA_DPP_ROR8>(va_xor32(x));
         }
-        mfma_group<WT>(wf, xb[j], acc[nh]);
+        red[((r * NW + wid) * 2 + nh) * 64 + lane] = o;
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-      const f32x4 v = acc_sum<WT>(acc[nh]);
-      f32x4 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float x = v[r];
-        o[r] = x + va_dpp<VA_DPP_ROR8>(va_xor32(x));
-      }
-      red[(wid * 2 + nh) * 64 + lane] = o;
-    }
     if constexpr (!QKV) {
       __syncthreads();
-      if (wid == 0) {
+      if (epw && wid * 16 < a.rows) {
         const int m = lane & 15;
         const bool mine = (m >> 3) == h;
         const int src = (m & 7) + 16 * (q & 1);
-        f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
+        f32x4 v = red[((wid * NW + 0) * 2 + (q >> 1)) * 64 + src];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
+        for (int i = 1; i < NW; ++i) v += red[((wid * NW + i) * 2 + (q >> 1)) * 64 + src];
         v *= ws2;
-        if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
+        if (mine) gemv3_epilogue<1, E3_RESID>(a, wid, tile, lane, &v, &pre);
       }
       VA_WAIT_VM(0);
       VA_STAMP(stamps, 6);                               // done (wave 0: epilogue stores acknowledged)
@@ -502,7 +558,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       };
       if (lane == 0) __hip_atomic_store(arrive2 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
-      if (wid != 0) {
+      const bool epq = wid < TQ * RBK;                 // this wave finishes tile (wid % TQ) of row block (wid / TQ) of the qkv phase
+      const int rq = wid / TQ, tq = wid - rq * TQ;
+      if (!epw) {
         if (!(e.abl & 8)) {   // PRE3 of the three k-groups at once, the rest once wave 0's phase-2 stores are in the memory pipeline
           // in ninths (k-group g, tile t; unit = 3 g + t): PRE3U of them at once, the rest behind the hold
           constexpr int PRE3U = MlpeThrottle<WT>::PRE3U;
@@ -521,51 +579,62 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
           load_wq();
         }
       }
-      if (wid < TQ) wsq = *reinterpret_cast<const f32x4*>(aq.wscale + (size_t)(tile0q + wid) * 16 + 4 * q);
-      if (wid == 0) {
+      if (epq) wsq = *reinterpret_cast<const f32x4*>(aq.wscale + (size_t)(tile0q + tq) * 16 + 4 * q);
+      if (epw) {
         mlpe_wait_words(arrive2, ltag);
         const int m = lane & 15;
         const bool mine = (m >> 3) == h;
         const int src = (m & 7) + 16 * (q & 1);
-        f32x4 v = red[(0 * 2 + (q >> 1)) * 64 + src];
+        f32x4 v = red[((wid * NW + 0) * 2 + (q >> 1)) * 64 + src];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) v += red[(i * 2 + (q >> 1)) * 64 + src];
+        for (int i = 1; i < NW; ++i) v += red[((wid * NW + i) * 2 + (q >> 1)) * 64 + src];
         v *= ws2;
-        if (mine) gemv3_epilogue<1, E3_RESID>(a, 0, tile, lane, &v, &pre);
-        if (!MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // publish phase 2: h, its partial sums of squares and its planes are out (write-through), drained, then the flag
+        if (mine && wid * 16 < a.rows) gemv3_epilogue<1, E3_RESID>(a, wid, tile, lane, &v, &pre);
+        if (wid == 0 && !MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // publish phase 2: h, its partial sums of squares and its planes are out (write-through), drained, then the flag (two row
+        // blocks: wave 1 drains its block's stores and tells wave 0, which publishes for both)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 256 + bid), "v"(epoch) : "memory");
-        if (MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (RBK == 2) {
+          if (wid == 1) {
+            if (lane == 0) __hip_atomic_store(arrive + 19, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            while (__hip_atomic_load(arrive + 19, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag) __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (wid == 0 && lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 256 + bid), "v"(epoch) : "memory");
+        if (wid == 0 && MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         load_wq();
       }
       (void)mlpe_poll_flags(e.flags + 256, 48, epoch, e, wid, lane);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aq.XP), 0, aq.R * VA_NPL * (KQ / 8) * 256, 0x00020000);
-      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.ss_in), 0, 96 * 16 * 4, 0x00020000);
-      u32x4 xq[G][VA_NPL];
-      {
-        const int xl16 = mq < aq.rows ? lane16 : 0x7ffffff0;
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.ss_in), 0, RBK * 96 * 16 * 4, 0x00020000);
+      u32x4 xq[RBK][G][VA_NPL];
+#pragma unroll
+      for (int r = 0; r < RBK; ++r) {
+        const int xl16 = r * 16 + mq < aq.rows ? lane16 : 0x7ffffff0;
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
           for (int p = 0; p < VA_NPL; ++p)
-            xq[g][p] = __builtin_amdgcn_raw_buffer_load_b128(hrs, xl16, (int)((p * (KQ / 8) * 16 + (kgo + w3 * G + g) * 64) * 16), 16 /* sc1 */);
+            xq[r][g][p] = __builtin_amdgcn_raw_buffer_load_b128(hrs, xl16, (int)(((r * VA_NPL + p) * (KQ / 8) * 16 + (kgo + w3 * G + g) * 64) * 16), 16 /* sc1 */);
       }
       constexpr int NSSQ = KQ / 64;
       float ssq[NSSQ];
-      if (wid < TQ) {
+      if (epq) {
 #pragma unroll
         for (int j = 0; j < NSSQ; ++j)                   // written by phase 2's epilogues in THIS launch: sc1
-          ssq[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, ((q + 4 * j) * 16 + mq) * 4, 0, 16 /* sc1 */));
+          ssq[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srs, ((rq * 96 + q + 4 * j) * 16 + mq) * 4, 0, 16 /* sc1 */));
       }
       __builtin_amdgcn_sched_barrier(0);
-      f32x4 accq[TQ][NACC];
+      f32x4 accq[RBK][TQ][NACC];
 #pragma unroll
-      for (int t = 0; t < TQ; ++t)
+      for (int r = 0; r < RBK; ++r)
 #pragma unroll
-        for (int p = 0; p < NACC; ++p) accq[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TQ; ++t)
+#pragma unroll
+          for (int p = 0; p < NACC; ++p) accq[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -573,14 +642,17 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
           f16x8 wf[F32 ? 2 : 1];
           wf[0] = __builtin_bit_cast(f16x8, wq[t][g][0]);
           if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wq[t][g][WH - 1]);
-          mfma_group<WT>(wf, xq[g], accq[t]);
+#pragma unroll
+          for (int r = 0; r < RBK; ++r) mfma_group<WT>(wf, xq[r][g], accq[r][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int t = 0; t < TQ; ++t) red[(wid * TQ + t) * 64 + lane] = acc_sum<WT>(accq[t]);
+      for (int r = 0; r < RBK; ++r)
+#pragma unroll
+        for (int t = 0; t < TQ; ++t) red[((r * NW + wid) * TQ + t) * 64 + lane] = acc_sum<WT>(accq[r][t]);
       float rinvq = 1.f;
-      if (wid < TQ) {
+      if (epq) {
         float ssp = 0.f;
 #pragma unroll
         for (int j = 0; j < NSSQ; ++j) ssp += ssq[j];
@@ -589,14 +661,14 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         rinvq = 1.0f / sqrtf(ssp * (1.0f / (float)aq.k_total) + aq.eps);
       }
       __syncthreads();
-      if (wid < TQ) {
-        f32x4 sacc = red[(0 * TQ + wid) * 64 + lane];
+      if (epq && rq * 16 < aq.rows) {
+        f32x4 sacc = red[((rq * NW + 0) * TQ + tq) * 64 + lane];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) sacc += red[(i * TQ + wid) * 64 + lane];
+        for (int i = 1; i < NW; ++i) sacc += red[((rq * NW + i) * TQ + tq) * 64 + lane];
         sacc *= wsq;
         const f32x4 v = sacc * rinvq;
         if (ks > 0) aq.out = aq.out2;
-        gemv3_epilogue<1, E3_STORE>(aq, 0, tile0q + wid, lane, &v, nullptr);
+        gemv3_epilogue<1, E3_STORE>(aq, rq, tile0q + tq, lane, &v, nullptr);
       }
       VA_WAIT_VM(0);
       VA_STAMP(stamps, 6);

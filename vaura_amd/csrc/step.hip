@@ -193,8 +193,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
   // hi plane, inf - inf = NaN in the lo plane, and from there NaN in the residual stream of that row for the rest of the clip —
   // so EVERY overflow anywhere in the step (or in a teacher-forced prefix, through the K/V cache) arrives here as a non-finite
   // logit.  Raise the sticky status bit the host checks after generate() instead of sampling from garbage.
-  if (a.state_rw && !(fabsf(x[0]) < INFINITY && fabsf(x[1]) < INFINITY && fabsf(x[2]) < INFINITY && fabsf(x[3]) < INFINITY))
-    __hip_atomic_fetch_or(&a.state_rw[4], VAURA_STATUS_NONFINITE_LOGITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!(fabsf(x[0]) < INFINITY && fabsf(x[1]) < INFINITY && fabsf(x[2]) < INFINITY && fabsf(x[3]) < INFINITY)) {
+    if (a.state_rw) __hip_atomic_fetch_or(&a.state_rw[4], VAURA_STATUS_NONFINITE_LOGITS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ... and keep the rest of this launch on finite numbers: the selection networks below (radix select on the IEEE bits, the
+    // bitonic sort, argmax of p / q) are written for ordered values; on NaN they can return an index outside the codebook, which
+    // the NEXT step's embedding gather would follow out of its table (round 5: a memory fault, seen on the x3000 checkpoint under
+    // top-k sampling).  The token drawn from the sanitised row is meaningless — the status bit says so — but it is a valid id.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = fabsf(x[j]) < INFINITY ? x[j] : 0.f;
+  }
 
   int token;
   if (!(a.use_sampling && a.temp > 0.0f)) {

@@ -125,7 +125,7 @@ class DecoderEngine:
     _sequence_id = 0
 
     def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
-                 one_launch_mlp: bool = True):
+                 one_launch_mlp: bool = True, range_fallback: bool = True):
         """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "f32" (``resolve_weight_dtype``).
         one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
         is eligible (1..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
@@ -135,6 +135,13 @@ class DecoderEngine:
         give up).  A give-up is reported by ``check_status`` — which callers of ``generate_codes`` / ``run`` must call themselves,
         ``VAURAModel.generate_tokens`` does."""
         self.one_launch_mlp = bool(one_launch_mlp)
+        # Range safety (``generate_codes_checked``): the fp16-plane activation format ends at |x| = 65504; a call that overflows it is
+        # DETECTED on the device (sticky status bit) and re-run from its start on a twin engine with weight_dtype="f32" (fp32
+        # activations and weights on the exact-fp32 matrix instruction: no range limit, the reference's own arithmetic), built lazily
+        # from the same state dict the first time it is needed.  The dict is kept by reference only (no copy).
+        self._twin_sd = sd if range_fallback else None
+        self._range_twin: Optional["DecoderEngine"] = None
+        self.range_fallbacks = 0             # calls re-run on the exact-fp32 twin so far
         _require_cuda(device)
         self.cfg = cfg
         self.dev = torch.device(device)
@@ -373,7 +380,7 @@ class DecoderEngine:
     def _reset_state(self):
         """position / arrivals / step back to 0; state[3] carries a sequence id (reserved for in-launch hand-off epochs)."""
         self._fc = None                       # position 0 again: a cached forward() prefix no longer matches the K/V cache
-        DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x7FF
+        DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x3FF      # 10 bits enter the hand-off epoch (csrc/common.h)
         self.state[:4].zero_()                               # two tiny device fills: no host-device synchronisation
         self.state[3:4].fill_(DecoderEngine._sequence_id)    # state[4] (status bits) is sticky until check_status() reads it
 
@@ -401,7 +408,9 @@ class DecoderEngine:
                 "non-finite logits reached the sampler — an activation left even the pre-scaled fp16-plane range, or the checkpoint holds "
                 "non-finite weights; weight_dtype='f32' keeps fp32 activations (exact-fp32-MFMA path)")
         if msgs:
-            raise L.VauraHipError(f"decode loop (status word {st:#x}): " + "; ALSO: ".join(msgs))
+            err = L.VauraHipError(f"decode loop (status word {st:#x}): " + "; ALSO: ".join(msgs))
+            err.status = st
+            raise err
 
     def revert(self) -> torch.Tensor:
         K, T = self.cfg.num_codebooks, self.T
@@ -431,6 +440,29 @@ class DecoderEngine:
         if caller is not None:
             out.record_stream(caller)
         return out
+
+    @torch.no_grad()
+    def generate_codes_checked(self, feats: torch.Tensor, max_new_tokens: int, **kw) -> torch.Tensor:
+        """``generate_codes`` + ``check_status`` (ONE host-device synchronisation) with range safety BY CONSTRUCTION: when — and only
+        when — the status word reports non-finite logits (an activation left the fp16-plane range somewhere in the loop: every such
+        overflow arrives at the sampler as NaN), the whole call is run again on the exact-fp32 twin engine
+        (weight_dtype="f32": fp32 activations between kernels, the reference's own arithmetic and range), with the same condition,
+        prompt, sampling parameters and noise (an explicit tensor, or Philox keyed by (seed, clip, codebook, step) — not by the engine), so
+        the result is what the fp32 path would have produced from the start.  A checkpoint with massive activations therefore decodes
+        correctly (at the f32 engine's speed) instead of raising; every other error still raises.  Counted in ``range_fallbacks``."""
+        codes = self.generate_codes(feats, max_new_tokens, **kw)
+        try:
+            self.check_status()
+        except L.VauraHipError as e:
+            st = getattr(e, "status", 0)
+            if st != 1 or self.wdtype == "f32" or self._twin_sd is None:       # a broken hand-off, or nothing wider to fall back to
+                raise
+            if self._range_twin is None:
+                self._range_twin = DecoderEngine(self.cfg, self._twin_sd, self.dev, wdtype="f32", range_fallback=False)
+            self.range_fallbacks += 1
+            codes = self._range_twin.generate_codes(feats, max_new_tokens, **kw)
+            self._range_twin.check_status()
+        return codes
 
     # ------------------------------------------------------------------ the reference host's call pattern, with a cache
     def forward_cached(self, idx: torch.Tensor, feats: torch.Tensor, tokens_per_frame: int = 7) -> torch.Tensor:

@@ -241,12 +241,12 @@ class VAURAModel(nn.Module):
         start = Tp + 1  # Pattern.get_first_step_with_timesteps(Tp), delayed pattern
         greedy = not (use_sampling and temp > 0.0)
         noise = None if greedy else self._exp_noise(S - start, B * K, self.sampler.d_codebook)
-        codes = eng.generate_codes(
+        # decode loop + its status word in one synchronisation (the reference's own post-conditions, :550-572, synchronise too); an
+        # activation beyond the fp16-plane range is re-run on the exact-fp32 engine instead of raising (engine.generate_codes_checked)
+        codes = eng.generate_codes_checked(
             vis.float(), max_new_tokens, prompt=audio if Tp else None, use_sampling=use_sampling, temp=temp,
             top_k=top_k, top_p=top_p, cfg_scale=cfg_scale if use_cfg else 1.0, noise=noise, seed=self.seed,
             clip_base=self.clip_base, tokens_per_frame=self.sampler.audio_tokens_per_video_frame)
-        # the reference's post-conditions (:550-572), checked once on the finished tensor
-        eng.check_status()        # non-finite logits anywhere in the loop (fp16-plane range guard): raises instead of returning garbage
         bad = (codes < 0) | (codes > self.sampler.d_codebook)
         assert not bool(bad.any()), "generated sequence is incomplete or out of range"
         if check:
