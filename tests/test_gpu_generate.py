@@ -992,8 +992,11 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     try:
         # the default (w1||w3 -> w2 -> next layer's qkv in one launch) | + attention and wo in one launch (experiment) | qkv separate |
         # the three-phase tail experiment | every GEMV and the attention their own launches
-        for flags in (0, 0x1000, 0x2, 8, 4):
-            L.lib().vaura_set_debug_flags(flags)
+        # ... | (round 5, experiment) the default WITH the next layer's attention as the launch's fourth phase (second flag word, bit 2)
+        for flags in (0, 0x1000, 0x2, 8, 4, (0, 4)):
+            f1, f2 = flags if isinstance(flags, tuple) else (flags, 0)
+            L.lib().vaura_set_debug_flags(f1)
+            L.lib().vaura_set_debug_flags2(f2)
             eng._free_graph()
             out[flags] = (eng.logits_all_positions(idx, f12).clone(),
                           eng.generate_codes(feats, 24, cfg_scale=6.0).clone(),
@@ -1002,10 +1005,11 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
             eng.check_status()
     finally:
         L.lib().vaura_set_debug_flags(0)
+        L.lib().vaura_set_debug_flags2(0)
         eng._free_graph()
     torch.cuda.synchronize()
     assert torch.isfinite(out[4][0]).all()
-    for flags in (0, 0x1000, 0x2, 8):
+    for flags in (0, 0x1000, 0x2, 8, (0, 4)):
         assert torch.equal(out[flags][0], out[4][0]), (flags, float((out[flags][0] - out[4][0]).abs().max()))
         for i in (1, 2, 3):
             assert torch.equal(out[flags][i], out[4][i]), (flags, i)

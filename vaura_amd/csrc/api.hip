@@ -122,6 +122,14 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // only: cache <= 256 positions, 16 heads).  Bit-identical and measured SLOWER than the two launches (13.7 us against 7.05 + 0.7 +
   // 4.8: the loop +3.3 % two planes / +3.8 % one): wo's stream is 1.5 us, nothing a run-ahead could hide pays for the hand-off.
   const bool attn_wo = mlp_engine && rows <= 16 && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u);
+  // EXPERIMENT (second flag word, bit 2): that layer's ATTENTION as the launch's fourth phase too (16 heads of 96, single-round-trip
+  // attention: cache <= 256, one row block; csrc/mlp_engine.h ATT instances).  Bit-identical, and measured SLOWER than the separate
+  // launch (round 5: the loop 204.2 -> 207.8 ms two planes, 163.4 -> 176.4 ms one): the serial chain behind the qkv products — drain,
+  // flag, poll, the q / k / v quads' round trip, two barriers of softmax arithmetic — is as long inside the launch as the kernel
+  // boundary it replaces, and the K / V rows were already hidden under that chain in the separate kernel.  Off by default.
+  const bool fuse_attn = fuse_qkv && rows <= 16 && H == 16 && hd == 96 && d->max_len <= 256 && d->ws_attn_split && !attn_wo &&
+                         !(va_debug_flags_get() & 8u) && (va_debug_flags2_get() & 4u);
+  bool attn_done = false;                    // layer l's attention was computed by layer l - 1's engine launch
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
     const float* next_attn_gain = (l + 1 < m.n_layer) ? d->layers_host[l + 1].attn_norm : d->final_norm;
@@ -135,7 +143,9 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     }
     qkv_done = false;
     const Gemv3Args awo0 = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
-    if (attn_wo) {
+    if (attn_done) {
+      attn_done = false;                     // (computed by the previous layer's one-launch MLP)
+    } else if (attn_wo) {
       // attention + wo as ONE launch (csrc/attention.hip attn_wo_kernel): wo's weights stream under the attention, the attention's
       // planes are handed over inside the launch; booked under the attention kind by the per-launch profiler
       PROF_B(VAURA_K_ATTN);
@@ -183,11 +193,17 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
         aqn = g3(d->layers_host[l + 1].wqkv, d->ws_h_split, d->ws_ss, nullptr, d->ws_qkv, nullptr, nullptr, nullptr, d, 3 * D);
         aqn.out2 = qkv2;
       }
+      VaEngineAttention att;
+      const bool with_attn = with_qkv && fuse_attn;
+      if (with_attn)
+        att = VaEngineAttention{d->rope, d->kcache + (size_t)(l + 1) * kv_layer, d->vcache + (size_t)(l + 1) * kv_layer, d->ws_attn,
+                                d->ws_attn_split, H, d->max_len};
       PROF_B(VAURA_K_W13);
-      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s);
+      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s, with_attn ? &att : nullptr);
       PROF_A(VAURA_K_W13);
       if (rc) return rc;
       qkv_done = with_qkv;
+      attn_done = with_attn;
       continue;
     }
     PROF_B(VAURA_K_W13);   // ffn = silu(W1 x) * (W3 x), x = rmsnorm(h)                  llama.py:282, 177

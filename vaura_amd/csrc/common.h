@@ -191,8 +191,16 @@ int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStr
 int va_pack_weight_h(const float* src, void* dst, int64_t N, int64_t K, int planes, hipStream_t s);   // fp16 plane(s) + row scales
 int va_launch_gemv3(const Gemv3Args& a, int64_t n_weight_rows, int64_t K, int epilogue, bool norm, hipStream_t s);
 bool va_mlp_engine_eligible(const vaura_decoder* d);
+struct VaEngineAttention {     // the next layer's attention as a fourth phase of the one-launch MLP (mlp_engine.h, ATT instances)
+  const float* rope;
+  float* kc;                   // K / V cache of THAT layer: (rows, n_head, max_len, 96)
+  float* vc;
+  float* out;                  // fp32 packed rows (rows x d_model)
+  uint16_t* outp;              // planes for wo
+  int n_head, max_len;
+};
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq_next, uint32_t* flags, int32_t* state, int layer,
-                         hipStream_t s);
+                         hipStream_t s, const VaEngineAttention* att = nullptr);
 int va_launch_attn_wo(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out, uint16_t* outp,
                       int rows, int n_head, int max_len, const int32_t* state, const Gemv3Args& awo, uint32_t* flags, int layer, hipStream_t s);
 int va_launch_tail_engine(const Gemv3Args& awo, const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer,

@@ -15,7 +15,8 @@ VA_STAMP_SETTER(vaura_stamps_set_gemv3)
 unsigned va_debug_flags_get() { return va_debug_flags; }
 
 // second flag word (vaura_set_debug_flags2), bit 0: more than one row block -> still ONE row block per weight pass (round 4's walk: the
-// A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows
+// A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows;
+// bit 2: EXPERIMENT, the next layer's attention as a fourth phase of the one-launch MLP (api.hip: measured slower)
 unsigned va_debug_flags2 = 0;
 unsigned va_debug_flags2_get() { return va_debug_flags2; }
 static bool rb2(const Gemv3Args& a) { return a.R >= 2 && !(va_debug_flags2 & 1u); }
@@ -233,19 +234,26 @@ bool va_mlp_engine_eligible(const vaura_decoder* d) {
   return cus[dev] >= 256;
 }
 
-template <int WT, bool QKV, int RBK = 1>
+template <int WT, bool QKV, int RBK = 1, bool ATT = false>
 static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
   using SH = MlpEngineShape<WT, RBK>;
   static unsigned long long big = 0;
-  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT, QKV, RBK>), SH::LDS, &big)) return VAURA_ERR_STATE;
-  VA_LAUNCH((mlp_engine_kernel<WT, QKV, RBK>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
+  if (va_big_lds_once(reinterpret_cast<const void*>(mlp_engine_kernel<WT, QKV, RBK, ATT>), SH::LDS, &big)) return VAURA_ERR_STATE;
+  VA_LAUNCH((mlp_engine_kernel<WT, QKV, RBK, ATT>), dim3(256), dim3(MLPE_NW * 64), SH::LDS, s, e.p1.W, e.p1.XP, e.p2.W, e);
   return 0;
 }
 
 // aq != nullptr: the next layer's qkv GEMV (K-split, two partial outputs) as a third phase of the same launch
+// att != nullptr (with aq, one row block): the next layer's attention as a fourth phase (flags: 704 words)
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq, uint32_t* flags, int32_t* state, int layer,
-                         hipStream_t s) {
+                         hipStream_t s, const VaEngineAttention* att) {
   MlpEngineArgs e;
+  e.att_rope = nullptr; e.att_kc = e.att_vc = e.att_out = nullptr; e.att_outp = nullptr; e.att_max_len = 0;
+  if (att) {
+    if (!aq || a13.R != 1 || !att->rope || !att->kc || !att->vc || !att->out || att->n_head != 16 || att->max_len > 256 || att->max_len < 1)
+      return VAURA_ERR_ARG;
+    e.att_rope = att->rope; e.att_kc = att->kc; e.att_vc = att->vc; e.att_out = att->out; e.att_outp = att->outp; e.att_max_len = att->max_len;
+  }
   e.p1 = a13;
   e.p2 = a2;
   e.p3 = aq ? *aq : a2;
@@ -264,6 +272,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
     if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 2>(e, s) : launch_mlp_engine_t<0, true, 2>(e, s);
     return a13.wq == 2 ? launch_mlp_engine_t<2, false, 2>(e, s) : launch_mlp_engine_t<0, false, 2>(e, s);
   }
+  if (att) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 1, true>(e, s) : launch_mlp_engine_t<0, true, 1, true>(e, s);
   if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true>(e, s) : launch_mlp_engine_t<0, true>(e, s);
   return a13.wq == 2 ? launch_mlp_engine_t<2, false>(e, s) : launch_mlp_engine_t<0, false>(e, s);
 }

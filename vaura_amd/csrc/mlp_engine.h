@@ -34,12 +34,12 @@ __device__ __forceinline__ void va_static_for9(F&& f) {
   f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});
   f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{}); f(std::integral_constant<int, 8>{});
 }
-template <int WT>
+template <int WT, int RBK = 1>
 struct MlpeThrottle {
 #ifdef MLPE_Q2
-  static constexpr int Q2 = MLPE_Q2;
+  static constexpr int Q2_1 = MLPE_Q2;
 #else
-  static constexpr int Q2 = WT == 2 ? 2 : 1;
+  static constexpr int Q2_1 = WT == 2 ? 2 : 1;
 #endif
 #ifdef MLPE_PRE3
   static constexpr int PRE3 = MLPE_PRE3;
@@ -47,10 +47,23 @@ struct MlpeThrottle {
   static constexpr int PRE3 = WT == 2 ? 1 : 2;
 #endif
 #ifdef MLPE_PRE3U
-  static constexpr int PRE3U = MLPE_PRE3U;      // the same in ninths (finer experiment builds)
+  static constexpr int PRE3U_1 = MLPE_PRE3U;      // the same in ninths (finer experiment builds)
 #else
-  static constexpr int PRE3U = 3 * PRE3;
+  static constexpr int PRE3U_1 = 3 * PRE3;
 #endif
+  // two row blocks per pass (RBK = 2): their own optimum (-DMLPE_Q2R / -DMLPE_PRE3UR in experiment builds)
+#ifdef MLPE_Q2R
+  static constexpr int Q2_2 = MLPE_Q2R;
+#else
+  static constexpr int Q2_2 = Q2_1;
+#endif
+#ifdef MLPE_PRE3UR
+  static constexpr int PRE3U_2 = MLPE_PRE3UR;
+#else
+  static constexpr int PRE3U_2 = PRE3U_1;
+#endif
+  static constexpr int Q2 = RBK == 2 ? Q2_2 : Q2_1;
+  static constexpr int PRE3U = RBK == 2 ? PRE3U_2 : PRE3U_1;
 };
 struct MlpEngineArgs {
   Gemv3Args p1;            // w1||w3: W, XP (h planes), ss_in, outp (ffn planes), N = ffn_dim, rows, R = 1, eps, k_total, wscale
@@ -62,6 +75,14 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
+  // ATT instances (round 5): the NEXT layer's attention as a fourth phase — K / V cache of that layer (this (row, head)'s rows are
+  // requested while the qkv phase still runs), rope table, outputs (fp32 packed rows + planes for wo); flags + 512 .. 703: qkv producers
+  const float* att_rope;
+  float* att_kc;           // (rows, n_head, max_len, 96) of layer + 1
+  float* att_vc;
+  float* att_out;
+  uint16_t* att_outp;
+  int att_max_len;
 };
 
 #define MLPE_NW 8
@@ -137,7 +158,15 @@ __device__ __forceinline__ uint32_t mlpe_ld_sc1(const uint32_t* p) {
 // set, the planes of both requested together); wave r finishes row block r of a phase (waves 3 r .. 3 r + 2 in the qkv phase) and wave
 // 0 publishes once wave 1 has drained its stores too (an LDS word).  Per row block the same products in the same order as the separate
 // two-row-block launches (gemv3_kernel / gemv3h_kernel RBK = 2): bit-identical to them.
-template <int WT, bool QKV, int RBK = 1>
+// ATT (QKV instances, one row block, 16 heads, cache <= 256 positions: the headline shape): the NEXT layer's attention as a FOURTH
+// phase.  All 256 workgroups stay; workgroup b is (head b & 15, row b >> 4) of attention_step256_kernel's grid and runs its arithmetic
+// (csrc/attention.hip attention256_body: same sums in the same order -> bit-identical).  What the fusion buys over the separate launch:
+// the cached K / V rows of that (row, head) depend on nothing this launch computes, so they are requested as soon as a wave's qkv
+// products are issued (workgroups 192..255, which have no w2 / qkv tile: right after phase 1) and stream under the qkv epilogue and its
+// hand-off — and the kernel boundary in front of the attention (~2.7 us of ramp + the dispatch gap) is gone.  The hand-off itself is
+// small: (row, head) needs the q, k and v quads of ITS head = 18 column tiles = 12 of the 192 qkv producers (three aligned groups of
+// four flags), not all of them.
+template <int WT, bool QKV, int RBK = 1, bool ATT = false>
 __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __restrict__ W13q, const uint16_t* __restrict__ XPq,
                                                                   const void* __restrict__ W2q, MlpEngineArgs e) {
   using SH = MlpEngineShape<WT, RBK>;
@@ -166,6 +195,175 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   f32x4 ws1[2] = {f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{1.f, 1.f, 1.f, 1.f}}, ws2 = f32x4{1.f, 1.f, 1.f, 1.f};
   // LDS words of the two-row-block instances: arrive[18] / arrive[19] <- wave 1 has drained its phase-1 / phase-2 epilogue stores
   const bool epw = wid < RBK;                  // this wave finishes a row block (wave r: row block r) in phases 1 and 2
+  static_assert(!ATT || (QKV && RBK == 1), "the attention phase follows the qkv phase of a one-row-block launch");
+
+  // ---- attention phase (ATT): the cached K / V rows of this workgroup's (row, head), 8 lanes per position, 64 positions per pass,
+  //      up to four passes (cache <= 256); requested by att_request() wherever the wave has registers and nothing left to request
+  constexpr int AQ = 3;                        // 16-byte quads of a 96-wide row per lane (8 lanes per position)
+  const int att_h = bid & 15, att_row = bid >> 4;
+  const int att_pos = ATT ? e.state[0] : 0;    // the cache holds positions [0, pos)
+  const int att_nu = (att_pos + 63) >> 6;
+  const bool att_live = ATT && att_row < e.p1.rows;
+  f32x4 kf[ATT ? 4 : 1][AQ], vf[ATT ? 4 : 1][AQ];
+  auto att_request = [&]() {
+    if constexpr (ATT) {
+      if (!att_live) return;
+      const int sub = threadIdx.x & 7, prow = threadIdx.x >> 3;
+      const float* kc = e.att_kc + ((size_t)att_row * 16 + att_h) * (size_t)e.att_max_len * 96;
+      const float* vc = e.att_vc + ((size_t)att_row * 16 + att_h) * (size_t)e.att_max_len * 96;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < att_nu) {                      // uniform: whole passes only (slots past the end of the last pass re-read the last row)
+          const int p = min(u * 64 + prow, att_pos - 1);
+#pragma unroll
+          for (int i = 0; i < AQ; ++i) kf[u][i] = reinterpret_cast<const f32x4*>(kc + (size_t)p * 96)[sub + 8 * i];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < att_nu) {
+          const int p = min(u * 64 + prow, att_pos - 1);
+#pragma unroll
+          for (int i = 0; i < AQ; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * 96)[sub + 8 * i];
+        }
+    }
+  };
+
+  // ----============================================================ phase 4 (ATT): the next layer's attention for (head att_h, row att_row)
+  auto att_phase = [&]() {
+    if (!att_live) return;
+    constexpr int HD = 96, QUADS = HD / 4, DM = 16 * HD;
+    f32x4* sqkv = red;                                   // rotated q | rotated k | v of the new position | scratch   (3 QUADS + 64 quads)
+    f32x4(*wacc)[QUADS] = reinterpret_cast<f32x4(*)[QUADS]>(red + 3 * QUADS + 64);     // [NW][QUADS]
+    float* wm = reinterpret_cast<float*>(red + 3 * QUADS + 64 + NW * QUADS);
+    float* wl = wm + NW;
+    // ---- hand-off: the q, k and v quads of head h are column tiles 6h .. 6h + 5 of each section = qkv producers 4h .. 4h + 3,
+    //      64 + 4h .. and 128 + 4h .. (workgroup = 2 (tile / 3) + K half): lanes 0 .. 2 of wave 0 poll one aligned group of four
+    if (wid == 0) {
+      const bool broken = (mlpe_ld_sc1(reinterpret_cast<const uint32_t*>(e.state + 4)) & VAURA_STATUS_HANDOFF_TIMEOUT) != 0;
+      const uint32_t* fp = e.flags + 512 + 64 * (lane < 3 ? lane : 0) + 4 * att_h;
+      int spin = 0;
+      for (;;) {
+        u32x4 f;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(f) : "v"(fp) : "memory");
+        const bool ok = f.x == epoch && f.y == epoch && f.z == epoch && f.w == epoch;
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull || broken || (e.abl & 1)) break;
+        if (++spin >= MLPE_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_fetch_or(e.state_rw + 4, VAURA_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- from here on: attention256_body (csrc/attention.hip), steps 2 .. 5, on the rows requested above
+    const int tid = threadIdx.x;
+    const int sub = tid & 7, prow = tid >> 3;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const int gt = min(tid, 3 * QUADS - 1);
+    const int which = gt / QUADS, cq = gt % QUADS;
+    const Gemv3Args& aq = e.p3;
+    // the new position's q / k / v quad: both K-half partials, written in THIS launch -> sc1
+    const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.out), 0, 16 * 3 * DM * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t q2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.out2), 0, 16 * 3 * DM * 4, 0x00020000);
+    const int qoff = (int)(packed_quad(att_row, (which * DM + att_h * HD + cq * 4) >> 2, 3 * DM) * 16);
+    f32x4 gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q1, qoff, 0, 16 /* sc1 */));
+    const f32x4 gx2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q2, qoff, 0, 16 /* sc1 */));
+    const f32x4 gcs = *reinterpret_cast<const f32x4*>(e.att_rope + ((size_t)att_pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
+    float* kc = e.att_kc + ((size_t)att_row * 16 + att_h) * (size_t)e.att_max_len * HD;
+    float* vc = e.att_vc + ((size_t)att_row * 16 + att_h) * (size_t)e.att_max_len * HD;
+    gx = gx + gx2;
+    f32x4 y;
+    y[0] = gx[0] * gcs[0] - gx[1] * gcs[1];
+    y[1] = gx[1] * gcs[0] + gx[0] * gcs[1];
+    y[2] = gx[2] * gcs[2] - gx[3] * gcs[3];
+    y[3] = gx[3] * gcs[2] + gx[2] * gcs[3];
+    if (which == 2) y = gx;   // v is not rotated
+    sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
+    if (tid >= QUADS && tid < 3 * QUADS)
+      va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)att_pos * HD) + cq, y);
+    __syncthreads();                                       // (also drains this wave's K / V requests: needed next anyway)
+    const f32x4* sq4 = sqkv;
+    const f32x4* sk4 = sqkv + QUADS;
+    const f32x4* sv4 = sqkv + 2 * QUADS;
+    f32x4 qf[AQ];
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) qf[i] = sq4[sub + 8 * i];
+    auto dot8 = [&](const f32x4* kv) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < AQ; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d = fmaf(qf[i][c], kv[i][c], d);
+      d += va_dpp<VA_DPP_XOR1>(d);
+      d += va_dpp<VA_DPP_XOR2>(d);
+      d += va_dpp<VA_DPP_HALF_MIRROR>(d);
+      return d;
+    };
+    f32x4 knew[AQ];
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) knew[i] = sk4[sub + 8 * i];
+    const float snew = dot8(knew) * scale;
+    float sc[4];
+    float m = snew;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < att_nu) {
+        const float d = dot8(kf[u]) * scale;
+        sc[u] = (u * 64 + prow < att_pos) ? d : -INFINITY;
+        m = fmaxf(m, sc[u]);
+      }
+    m = wave_max(m);
+    float l = 0.f;
+    f32x4 av[AQ];
+#pragma unroll
+    for (int i = 0; i < AQ; ++i) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < att_nu) {
+        const float ex = expf(sc[u] - m);
+        if (sub == 0) l += ex;
+#pragma unroll
+        for (int i = 0; i < AQ; ++i) av[i] += vf[u][i] * ex;
+      }
+    l = wave_sum(l);
+#pragma unroll
+    for (int i = 0; i < AQ; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = av[i][c];
+        v += va_dpp<VA_DPP_ROR8>(v);
+        v += va_xor16(v);
+        v += va_xor32(v);
+        av[i][c] = v;
+      }
+    if (lane < 8) {
+#pragma unroll
+      for (int i = 0; i < AQ; ++i) wacc[wid][lane + 8 * i] = av[i];
+    }
+    if (lane == 0) { wm[wid] = m; wl[wid] = l; }
+    __syncthreads();
+    if (tid < QUADS) {
+      float M = wm[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) M = fmaxf(M, wm[w]);
+      const float en = expf(snew - M);
+      float denom = en;
+      f32x4 o = sv4[tid] * en;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float f = expf(wm[w] - M);
+        denom += f * wl[w];
+        o += wacc[w][tid] * f;
+      }
+      o *= 1.0f / denom;
+      va_st16(reinterpret_cast<f32x4*>(e.att_out) + packed_quad(att_row, (att_h * HD) / 4 + tid, DM), o);
+      if (e.att_outp) store_split4(e.att_outp, att_row, att_h * HD + 4 * tid, DM, o);
+    }
+    VA_WAIT_VM(0);
+    VA_STAMP(stamps, 6);
+    VA_STAMP_FLUSH(stamps, 11);
+  };
 
   // ================================================================ phase 1: w1||w3 + SwiGLU (gemv3_kernel<6, 8, 2, E3_SWIGLU, true>)
   {
@@ -331,7 +529,12 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     }
   }
   if (bid >= 192) {
-    VA_STAMP_FLUSH(stamps, 11);
+    if constexpr (!ATT) {
+      VA_STAMP_FLUSH(stamps, 11);
+    } else {
+      att_request();                           // no w2 / qkv tile here: this (row, head)'s K / V rows at once,
+      att_phase();                             // then straight to the attention (its own copy of the code: the rows' registers are not
+    }                                          // live through the phases these workgroups skip)
     return;
   }
 
@@ -388,7 +591,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     if (!(e.abl & 8) && !(e.abl & 4)) {
       // partial hold: waves 1..7 request MLPE_Q2 quarters of their slice at once and the rest only when wave 0's epilogue stores are in
       // the CU's memory pipeline (ablation bit 3: no hold, round 4's first form); wave 0 comes here behind its publish and holds nothing
-      constexpr int Q2 = MlpeThrottle<WT>::Q2;
+      constexpr int Q2 = MlpeThrottle<WT, RBK>::Q2;
       const bool hold = wid >= RBK;                    // (the waves that finish a row block come here behind their own stores and hold nothing)
       if (!hold || Q2 > 0) prefetch_q(std::integral_constant<int, 0>{});
       if (!hold || Q2 > 1) prefetch_q(std::integral_constant<int, 1>{});
@@ -563,7 +766,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       if (!epw) {
         if (!(e.abl & 8)) {   // PRE3 of the three k-groups at once, the rest once wave 0's phase-2 stores are in the memory pipeline
           // in ninths (k-group g, tile t; unit = 3 g + t): PRE3U of them at once, the rest behind the hold
-          constexpr int PRE3U = MlpeThrottle<WT>::PRE3U;
+          constexpr int PRE3U = MlpeThrottle<WT, RBK>::PRE3U;
           auto unit = [&](auto uc) {
             constexpr int u = decltype(uc)::value, g = u / 3, t = u % 3;
             const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
@@ -660,6 +863,8 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         ssp += va_xor32(ssp);
         rinvq = 1.0f / sqrtf(ssp * (1.0f / (float)aq.k_total) + aq.eps);
       }
+      // ATT: the waves without a tile to finish have nothing left to request for this phase: their share of the K / V rows now
+      if (ATT && !epq) att_request();
       __syncthreads();
       if (epq && rq * 16 < aq.rows) {
         f32x4 sacc = red[((rq * NW + 0) * TQ + tq) * 64 + lane];
@@ -670,11 +875,31 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         if (ks > 0) aq.out = aq.out2;
         gemv3_epilogue<1, E3_STORE>(aq, rq, tile0q + tq, lane, &v, nullptr);
       }
-      VA_WAIT_VM(0);
-      VA_STAMP(stamps, 6);
-      VA_STAMP_FLUSH(stamps, 11);
+      if constexpr (ATT) {
+        // publish the qkv tiles (write-through stores): waves 0 .. 2 stored one each — drained, waves 1 and 2 tell wave 0 (LDS words),
+        // wave 0 stores the flag; then these waves request their share of the K / V rows (behind their stores: a wave's vector-memory
+        // counter retires in order, a drain in front of the flag would otherwise wait for the rows)
+        if (epq) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (wid > 0) {
+            if (lane == 0) __hip_atomic_store(arrive + 20 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            while (__hip_atomic_load(arrive + 21, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag ||
+                   __hip_atomic_load(arrive + 22, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag)
+              __builtin_amdgcn_s_sleep(1);
+            if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 512 + bid), "v"(epoch) : "memory");
+          }
+          att_request();
+        }
+      } else {
+        VA_WAIT_VM(0);
+        VA_STAMP(stamps, 6);
+        VA_STAMP_FLUSH(stamps, 11);
+      }
     }
   }
+
+  if constexpr (ATT) att_phase();
 }
 
 
