@@ -1053,3 +1053,25 @@ def test_one_launch_mlp_under_concurrent_load_and_repeats(one_launch, clips):
     eng.check_status()                       # a consumer that gave up waiting raises here
     for o in outs:
         assert torch.equal(o, ref)
+
+
+def test_handoff_timeout_switches_the_engine_to_separate_launches_instead_of_failing():
+    """the one-launch MLP needs all 256 workgroups resident; on a SHARED GPU (MPS, a second tenant, a CU mask) a
+    consumer gives up waiting (bounded spin) and raises VAURA_STATUS_HANDOFF_TIMEOUT — after which every hand-off returns at once and
+    the tokens are garbage.  `generate_codes_checked` (what VAURAModel.generate calls) must turn that into a slower, CORRECT run: switch
+    the engine to the separate launches for good and run the call again.  The timeout is simulated by raising the status bit before the
+    call (so the first pass really decodes with every wait disabled), the result must equal the quiet run's."""
+    cfg = synth.tiny_sampler(3)
+    sd = synth.sampler_state_dict(cfg, seed=121, round_bf16=False)
+    eng = DecoderEngine(cfg, sd, DEV)
+    feats = synth.video_features(8, seed=122).to(DEV)
+    kw = dict(cfg_scale=6.0, use_sampling=True, top_k=250, seed=5)
+    ref = eng.generate_codes_checked(feats, 40, **kw).clone()
+    assert eng.one_launch_mlp and eng.dec.ws_sync
+    eng.state[4:5].fill_(2)                              # VAURA_STATUS_HANDOFF_TIMEOUT
+    with pytest.warns(UserWarning, match="hand-off timed out"):
+        got = eng.generate_codes_checked(feats, 40, **kw)
+    assert torch.equal(got, ref)
+    assert not eng.one_launch_mlp and not eng.dec.ws_sync and eng.handoff_fallbacks == 1
+    assert torch.equal(eng.generate_codes_checked(feats, 40, **kw), ref)       # and it stays on the separate launches, clean
+    eng.check_status()

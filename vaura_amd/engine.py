@@ -449,13 +449,28 @@ class DecoderEngine:
         (weight_dtype="f32": fp32 activations between kernels, the reference's own arithmetic and range), with the same condition,
         prompt, sampling parameters and noise (an explicit tensor, or Philox keyed by (seed, clip, codebook, step) — not by the engine), so
         the result is what the fp32 path would have produced from the start.  A checkpoint with massive activations therefore decodes
-        correctly (at the f32 engine's speed) instead of raising; every other error still raises.  Counted in ``range_fallbacks``."""
+        correctly (at the f32 engine's speed) instead of raising.  Counted in ``range_fallbacks``.  The other status bit — a hand-off of
+        the one-launch MLP that gave up because the GPU is shared — switches this engine to the separate launches and re-runs the
+        call as well (``handoff_fallbacks``): a slower run, not an error.  Anything else still raises."""
         codes = self.generate_codes(feats, max_new_tokens, **kw)
         try:
             self.check_status()
         except L.VauraHipError as e:
             st = getattr(e, "status", 0)
-            if st != 1 or self.wdtype == "f32" or self._twin_sd is None:       # a broken hand-off, or nothing wider to fall back to
+            if (st & 2) and self.one_launch_mlp:
+                # A consumer of the one-launch MLP gave up waiting: its 256 workgroups were not all resident — the GPU is shared
+                # (another process / tenant, a CU mask, a second engine on another stream).  Not an error of the model: switch THIS
+                # engine to the separate launches for good (no in-launch hand-off, nothing to starve; same bits) and run the call again.
+                import warnings
+                warnings.warn("vaura_amd: the one-launch MLP's in-launch hand-off timed out (GPU shared?); this engine now uses the "
+                              "separate launches (slower by 5-7 %, same results)")
+                self.one_launch_mlp = False
+                self.handoff_fallbacks = getattr(self, "handoff_fallbacks", 0) + 1
+                if self.dec is not None:
+                    self.dec.ws_sync = 0
+                self._free_graph()
+                return self.generate_codes_checked(feats, max_new_tokens, **kw)
+            if st != 1 or self.wdtype == "f32" or self._twin_sd is None:       # nothing wider to fall back to
                 raise
             if self._range_twin is None:
                 self._range_twin = DecoderEngine(self.cfg, self._twin_sd, self.dev, wdtype="f32", range_fallback=False)
