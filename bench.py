@@ -479,9 +479,10 @@ def main():
         ach = ab / ((per[dom] + gap_us) * 1e-6) / 1e9          # dispatch-to-dispatch: what rocprofv3's kernel trace calls the duration
         names = json.load(open(os.path.join(REPO, "profiles", "kernel_names.json"))) if os.path.exists(
             os.path.join(REPO, "profiles", "kernel_names.json")) else {}
-        kname = names.get("c4" if long_ctx else storage, {}).get(dom, dom)
+        nkey = "c4" if long_ctx else (f"{storage}_rows32" if rows > 16 and f"{storage}_rows32" in names else storage)
+        kname = names.get(nkey, {}).get(dom, dom)
         if dom == "mlp" and not qkv_in_mlp:
-            kname = names.get(storage, {}).get("mlp_last", kname)
+            kname = names.get(nkey, {}).get("mlp_last", kname)
         # the committed rocprofv3 --kernel-trace --stats summary of this command (tools/profile_round.sh): its average duration of the
         # same kernel, quoted next to the live one so that the two can be seen to agree
         rocprof = None
@@ -502,7 +503,8 @@ def main():
         # HBM traffic of that kernel from the PMC passes over the SAME library (tools/pmc_driver.cpp + tools/profile_pmc.sh):
         # only quoted when the committed record is for this kernel instance and storage, else null
         traffic, tsrc = None, None
-        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith(f"_pmc_hbm_bytes_{storage}.json")), reverse=True):
+        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles"))
+                            if f.endswith(f"_pmc_hbm_bytes_{storage}.json") or f.endswith(f"_pmc_hbm_bytes_{storage}_rows{rows}.json")), reverse=True):
             try:
                 rec = json.load(open(os.path.join(REPO, "profiles", cand)))
                 hit = rec.get("weights") == storage and rec.get("rows") == rows and rec.get("kernels", {}).get(kname)

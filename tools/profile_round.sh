@@ -32,6 +32,13 @@ for W in h2 h1; do
   done
   tail -n 1 $OUT/drv_stats_$W.log
 done
+# 17..32 decoder rows (the reference's default batch 16 under CFG): the two-row-block instances, two planes
+W=h2_rows32
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights h2 --rows 32 --steps 24 --pos0 100 > $OUT/drv_stats_$W.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights h2 --rows 32 --steps 24 --pos0 100 > $OUT/drv_${C}_$W.log 2>&1
+done
+tail -n 1 $OUT/drv_stats_$W.log
 for M in codec avclip prefill_h2 prefill_h1; do
   case $M in prefill_h2) A="prefill 8 4";; prefill_h1) A="prefill 8 3";; *) A="$M 8";; esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_stats_$M -- $MDRV $LIB $A > $OUT/mfma_stats_$M.log 2>&1

@@ -45,8 +45,9 @@ def stage_of(name):
             return "w13"
         if epi == 4:
             return "heads"
-    if name.startswith("mlp_engine_kernel"):          # w1||w3 -> w2 (-> next layer's qkv) in one launch (csrc/mlp_engine.h)
-        return "mlp" if name.rstrip(">").endswith("true") else "mlp_last"
+    m = re.match(r"mlp_engine_kernel<(\d+), (true|false)", name)   # <WT, QKV, RBK, ATT>: w1||w3 -> w2 (-> next layer's qkv) in one launch
+    if m:
+        return "mlp" if m.group(2) == "true" else "mlp_last"
     m = re.match(r"gemv3h_kernel<(\d+), ", name)      # row-split pair kernels: G2 = k-group pairs per wave
     if m:
         return "w2" if int(m.group(1)) == 8 else "wo"
@@ -91,12 +92,13 @@ def per_kernel(path, counter):
 
 
 names = {}
-for w in ("h2", "h1"):
+for w in ("h2", "h1", "h2_rows32"):
     st = newest(f"{src}/drv_stats_{w}/**/*kernel_stats.csv")
     if not st:
         continue
+    rows_n = 32 if w.endswith("rows32") else 16
     drows = write_stats(st, f"profiles/{tag}_driver_kernel_stats_{w}.csv",
-                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {w} --steps 24 --pos0 100")
+                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {w[:2]} --rows {rows_n} --steps 24 --pos0 100")
     avg_ns = {clean(r["Name"]): float(r["AverageNs"]) for r in drows}
     names[w] = {stage_of(n): n for n in avg_ns if stage_of(n)}
     fetch = per_kernel(f"{src}/drv_FETCH_SIZE_{w}", "FETCH_SIZE")
@@ -106,9 +108,9 @@ for w in ("h2", "h1"):
         missing = sorted(step_kernels - bench_names)
         if missing:
             raise SystemExit(f"PMC kernel names not in the bench's kernel stats (stale build?): {missing}")
-    out = {"weights": w, "rows": 16, "kernels": {},
+    out = {"weights": w[:2], "rows": rows_n, "kernels": {},
            "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- tools/pmc_driver libvaura_hip.so "
-                     f"--weights {w} --steps 24 --pos0 100 (cache length 100..123)",
+                     f"--weights {w[:2]} --rows {rows_n} --steps 24 --pos0 100 (cache length 100..123)",
            "formula": "hbm_bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half the "
                       "bytes of wide coalesced reads on gfx950; WRITE_SIZE is exact)"}
     for k in sorted(step_kernels):

@@ -187,6 +187,36 @@ def sampler_state_dict(cfg: SamplerCfg = FULL_SAMPLER, seed: int = 0,
 
 
 # ----------------------------------------------------------------------------- codec
+def trained_like(sd: Dict[str, torch.Tensor], seed: int = 0, massive: float = 0.0) -> Dict[str, torch.Tensor]:
+    """A sampler state dict with the STATISTICS of a trained transformer laid over a synthetic one (tests: there is no network for a
+    real V-AURA checkpoint, and N(0, 0.02^2) weights with unit gains exercise none of this): heavy-tailed streamed matrices (one
+    element in 2 000 scaled x 25: kurtosis in the hundreds), log-normal RMSNorm gains (sigma 0.5) with six outlier channels x 20, and
+    two token-embedding output channels x 100 — "massive activations": a few residual-stream dimensions two orders of magnitude above
+    the rest from the first layer on.  massive > 0 additionally scales two norm gains deep in the stack by that factor: activations
+    then leave the fp16-plane range (what DecoderEngine.generate_codes_checked must survive).  Deterministic in (sd, seed)."""
+    out = dict(sd)
+    for k in sorted(sd):
+        g = _gen("trained_like/" + k, seed)
+        if is_streamed_weight(k):
+            w = sd[k].clone()
+            n = max(1, w.numel() // 2000)
+            idx = torch.randint(0, w.numel(), (n,), generator=g)
+            w.view(-1)[idx] *= 25.0
+            out[k] = w
+        elif k.endswith("attention_norm.weight") or k.endswith("ffn_norm.weight") or k == "norm.weight":
+            gain = sd[k] * torch.exp(0.5 * torch.randn(sd[k].shape, generator=g))
+            gain[torch.randperm(gain.numel(), generator=g)[:6]] *= 20.0
+            out[k] = gain
+        elif "tok_embeddings" in k and k.endswith("out_proj.weight_g"):
+            wg = sd[k].clone()
+            wg.view(-1)[[7, 300]] *= 100.0
+            out[k] = wg
+    if massive > 0.0:
+        for k in ("layers.1.ffn_norm.weight", f"layers.{max(1, len([x for x in sd if x.endswith('ffn_norm.weight')]) * 2 // 3)}.attention_norm.weight"):
+            out[k] = out[k] * massive
+    return out
+
+
 def _wn_conv(sd, prefix, cout, cin, k, seed, gain=1.0, transposed=False):
     if transposed:   # ConvTranspose1d weight (Cin, Cout, k); weight_norm dim=0 -> g (Cin,1,1)
         sd[prefix + "weight_v"] = normal(prefix + "weight_v", (cin, cout, k), 1.0, seed)
