@@ -55,4 +55,7 @@ def parity_report():
     if rep.entries:
         for line in rep.summary_lines():
             print("parity:", line)
-        rep.write(os.path.join(REPO, "gpurun_out", "r05_parity.json"))
+        # a partial session (-k ...) must not overwrite the record of a whole one: the headline golden is the marker
+        whole = any(e.get("golden") == "full_topk250_cfg6_raw_B2_T220" and e.get("storage") == "h2" for e in rep.entries) and \
+            any(e.get("golden") == "full_c4_greedy_B1_T880" for e in rep.entries)
+        rep.write(os.path.join(REPO, "gpurun_out", "r05_parity.json" if whole else "r05_parity_partial.json"))
