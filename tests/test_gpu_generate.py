@@ -303,20 +303,28 @@ def test_dac_decode_plain_fp16_against_its_emulation_and_the_fp32_oracle():
     assert rms_ref <= 1.5 * rms_model and rms_ref <= 5e-3 * sig, (rms_ref, rms_model, sig)
 
 
-def test_two_row_blocks_with_cfg_against_live_oracle():
-    """B=10 with CFG -> 20 decoder rows = two 16-row blocks (the second one ragged): every GEMV loops
-    row blocks, attention / sampler grids grow.  Token-exact vs the oracle."""
+@pytest.mark.parametrize("B", [10, 16, 20])
+def test_two_row_blocks_with_cfg_against_live_oracle(B):
+    """B=10 with CFG -> 20 decoder rows = two 16-row blocks (the second one ragged), B=16 -> 32 rows (two full blocks: the
+    reference's default batch, configs/generate_vgg.yaml:41; both on the two-row-block GEMVs and the two-row-block one-launch MLP),
+    B=20 -> 40 rows (three blocks: a full two-block pass + a half-empty one, no one-launch MLP): attention / sampler grids grow.
+    Token-exact vs the oracle, greedy and top-k-128 sampled with a recorded noise stream."""
     from oracle import generate_oracle as go
     from oracle.decoder_oracle import DecoderOracle
     cfg = synth.tiny_sampler(2)
     sd = synth.sampler_state_dict(cfg, seed=31)
-    feats = synth.video_features(10, seed=32)
+    feats = synth.video_features(B, seed=32)
     dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
     ref = go.generate(dec, feats, 14, mode="cached", cfg_scale=6.0)
+    nz = synth.exp_noise(14 + 9 - 1, B * 9, 1024, 33)
+    refs = go.generate(dec, feats, 14, mode="cached", cfg_scale=6.0, use_sampling=True, top_k=128, noise=nz)
     for wd in ("f32", "h1", "h2"):
         eng = DecoderEngine(cfg, sd, DEV, wdtype=wd)
         got = eng.generate_codes(feats.to(DEV), 14, cfg_scale=6.0).cpu()
         assert torch.equal(got, ref), wd
+        gots = eng.generate_codes(feats.to(DEV), 14, cfg_scale=6.0, use_sampling=True, top_k=128, noise=nz).cpu()
+        eng.check_status()
+        assert torch.equal(gots, refs), wd
 
 
 def test_long_context_single_pass_against_live_oracle():
