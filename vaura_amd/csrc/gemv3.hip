@@ -16,7 +16,8 @@ unsigned va_debug_flags_get() { return va_debug_flags; }
 
 // second flag word (vaura_set_debug_flags2), bit 0: more than one row block -> still ONE row block per weight pass (round 4's walk: the
 // A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows;
-// bit 2: EXPERIMENT, the next layer's attention as a fourth phase of the one-launch MLP (api.hip: measured slower)
+// bit 2: EXPERIMENT, the next layer's attention as a fourth phase of the one-launch MLP (api.hip: measured slower);
+// bit 3: fp8 weights keep round 4's one-workgroup-per-tile kernels for wo / w2 (the A/B of the fp8 row-split instances)
 unsigned va_debug_flags2 = 0;
 unsigned va_debug_flags2_get() { return va_debug_flags2; }
 static bool rb2(const Gemv3Args& a) { return a.R >= 2 && !(va_debug_flags2 & 1u); }
@@ -57,6 +58,14 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
   // two weight planes are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
   // flight) like the K = 4096 instances their four, so that the slice a wave holds fits the register file without spills
   constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
+  if constexpr (WT == 1) {   // fp8 tile pairs (round 5): with 17..32 rows the residual GEMVs on the row-split pair kernel too — one workgroup
+    // per tile takes in BOTH row blocks' planes (524 KB at K = 4096 next to 65 KB of weights): 217.5 -> 214.7 ms on the 32-row loop;
+    // at 16 rows the one-workgroup-per-tile kernels stay (162.3 against 164.8 ms).  Second flag word, bit 3: never (the A/B)
+    if (a.R >= 2 && !norm && !(va_debug_flags & 1u) && !(va_debug_flags2 & 8u) && tiles % 8 == 0 && epilogue == E3_RESID) {
+      if (K == 1536) return launch3h<1, 3, E3_RESID, 1, 2, 8, true>(a, tiles, s);
+      if (K == 4096) return launch3h<1, 8, E3_RESID, 1, 2, 8, true>(a, tiles, s);
+    }
+  }
   if constexpr (WT != 1) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
     if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
       if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1, 2, 8, true>(a, tiles, s);

@@ -504,9 +504,12 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   VA_STAMP(stamps, 0);
   a.W = Wq;
   a.XP = XPq;
-  static_assert(WT == 0 || WT == 2, "one or two fp16 weight planes");
+  // WT = 1 (round 5): fp8 tile pairs.  One 1-KiB fragment holds BOTH k-groups of a pair (lane (n, k-octet): 8 bytes of the even
+  // k-group, 8 of the odd one), so the A operand of lane (la, s, q) is an 8-byte load of half s of that fragment, widened to fp16 in
+  // registers: the same products in the same order as the one-plane instance on the dequantised matrix.
+  static_assert(WT == 0 || WT == 1 || WT == 2, "one or two fp16 weight planes, or fp8 tile pairs");
   static_assert(EPI == E3_RESID || EPI == E3_STORE, "independent output tiles only");
-  constexpr bool F32 = WT == 2;
+  constexpr bool F32 = WT == 2, FP8 = WT == 1;
   constexpr int WH = F32 ? 2 : 1;
   constexpr int NACC = 2;
   constexpr int K = 64 * G2 * NW;
@@ -529,7 +532,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   const int la = lane & 7, sb = (lane >> 3) & 1, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, -16, 0x00020000);
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.XP), 0, a.R * VA_NPL * (K / 8) * 256, 0x00020000);
-  const int voffw0 = (la + 16 * q) * 16 + sb * BS;          // weight rows 0..7 of the tile; + 128 bytes for rows 8..15
+  const int voffw0 = FP8 ? (la + 16 * q) * 16 + sb * 8      // fp8: half s of the pair's fragment
+                         : (la + 16 * q) * 16 + sb * BS;    // weight rows 0..7 of the tile; + 128 bytes for rows 8..15
   const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;   // batch row la + 8 h of the block (out of range below when it does not exist)
 
   u32x4 wb[NB][GB][2][WH];
@@ -538,12 +542,21 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   auto load_w = [&](int b) {
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
-      const int soff = (tile * KG + 2 * (w * G2 + b * GB + g)) * BS;
+      if constexpr (FP8) {
+        const int soff = (tile * (KG / 2) + (w * G2 + b * GB + g)) * 1024;
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
+        for (int nh = 0; nh < 2; ++nh) {
+          const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(wrs, voffw0 + nh * 128, soff, 2 /* nt */);
+          wb[b % NB][g][nh][0] = u32x4{v2[0], v2[1], 0u, 0u};
+        }
+      } else {
+        const int soff = (tile * KG + 2 * (w * G2 + b * GB + g)) * BS;
 #pragma unroll
-        for (int hh = 0; hh < WH; ++hh)
-          wb[b % NB][g][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int hh = 0; hh < WH; ++hh)
+            wb[b % NB][g][nh][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, voffw0 + nh * 128, soff + hh * 1024, 2 /* nt */);
+      }
     }
   };
   auto load_x = [&](int rb0, int b) {
@@ -596,7 +609,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
           f16x8 wf[F32 ? 2 : 1];
-          wf[0] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][0]);
+          if constexpr (FP8) wf[0] = fp8x8_to_f16(wb[b % NB][g][nh][0].x, wb[b % NB][g][nh][0].y);
+          else wf[0] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][0]);
           if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wb[b % NB][g][nh][WH - 1]);
 #pragma unroll
           for (int r = 0; r < RBK; ++r) mfma_group<WT>(wf, xb[r][b % NB][g], acc[r][nh]);
