@@ -35,6 +35,9 @@ for wd, sd in (("h1", synth.sampler_state_dict(cfg, seed=0, round_bf16=True)), (
     screen(f"decode loop, {wd} storage, 8 clips, top-k 250, cfg 6", lambda: eng.generate_codes(feats, 220, **kw), max(4, N // 4))
     prompt = torch.randint(0, 1024, (8, 9, 166), generator=torch.Generator().manual_seed(1)).to(dev)
     screen(f"prompt prefill + loop, {wd} storage", lambda: eng.generate_codes(feats, 221, prompt=prompt, **kw), max(4, N // 4))
+    feats16 = synth.video_features(16, seed=0).to(dev)      # 32 decoder rows: the two-row-block GEMVs and one-launch MLP (round 5)
+    screen(f"decode loop, {wd} storage, 16 clips (32 rows), top-k 250, cfg 6", lambda: eng.generate_codes(feats16, 220, **kw), max(4, N // 4))
+    eng.check_status()
     del eng
     torch.cuda.empty_cache()
 ccfg = synth.FULL_CODEC
