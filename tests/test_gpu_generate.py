@@ -977,7 +977,7 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
 
 
 @pytest.mark.parametrize("clips", [6, 3, 16, 10])
-@pytest.mark.parametrize("wdtype", ["h2", "h1"])
+@pytest.mark.parametrize("wdtype", ["h2", "h1", "fp8"])
 def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     """csrc/mlp_engine.h, the default where eligible: the MLP of a layer (w1||w3 + SwiGLU -> w2 + residual) as ONE launch with an
     in-launch hand-off, w2's weights requested ahead of it (debug flag bit 2: every GEMV its own launch; bit 3: the experimental
@@ -988,7 +988,9 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     one-launch form keeps its (tile, row half) workgroups and the second half multiplies zeros).  Round 5: 16 clips x cfg = 32 rows (the
     reference's default batch, configs/generate_vgg.yaml:41) and 10 clips = 20 rows (second row block ragged): the two-row-block
     instances (mlp_engine_kernel<.., RBK = 2>) against the separate two-row-block launches; the attention + wo and tail experiments
-    do not exist there (the flags then select the default)."""
+    do not exist there (the flags then select the default).  fp8 tile pairs (configs[4]) take the one-launch form with 17..32 rows only
+    (its qkv phase on four waves of six k-groups, like the separate fp8 K-split kernel): 16 and 10 clips test it, 6 and 3 are the
+    separate launches either way."""
     from vaura_amd import _lib as L
     cfg = synth.tiny_sampler(3)
     sd = synth.sampler_state_dict(cfg, seed=101, round_bf16=(wdtype == "h1"))

@@ -17,7 +17,8 @@ unsigned va_debug_flags_get() { return va_debug_flags; }
 // second flag word (vaura_set_debug_flags2), bit 0: more than one row block -> still ONE row block per weight pass (round 4's walk: the
 // A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows;
 // bit 2: EXPERIMENT, the next layer's attention as a fourth phase of the one-launch MLP (api.hip: measured slower);
-// bit 3: fp8 weights keep round 4's one-workgroup-per-tile kernels for wo / w2 (the A/B of the fp8 row-split instances)
+// bit 3: fp8 weights keep round 4's one-workgroup-per-tile kernels for wo / w2 (the A/B of the fp8 row-split instances);
+// bit 4: fp8 weights never take the one-launch MLP
 unsigned va_debug_flags2 = 0;
 unsigned va_debug_flags2_get() { return va_debug_flags2; }
 static bool rb2(const Gemv3Args& a) { return a.R >= 2 && !(va_debug_flags2 & 1u); }
@@ -230,7 +231,9 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
 bool va_mlp_engine_eligible(const vaura_decoder* d) {
   if (!d->ws_sync || !d->state || d->rows < 1 || d->rows > 32) return false;
   if (d->rows > 16 && (va_debug_flags2 & 2u)) return false;          // second flag word, bit 1: 17..32 rows keep the separate launches
-  if (d->wdtype != VAURA_W_H1 && d->wdtype != VAURA_W_H2) return false;
+  // fp8 tile pairs (round 5): the two-row-block instances only (17..32 rows: configs[4]'s per-GPU shape); second flag word, bit 4: no
+  if (d->wdtype == VAURA_W_FP8) { if (d->rows <= 16 || (va_debug_flags2 & 16u)) return false; }
+  else if (d->wdtype != VAURA_W_H1 && d->wdtype != VAURA_W_H2) return false;
   if (d->dims.d_model != 1536 || d->dims.ffn_dim != 4096) return false;
   static int cus[64] = {};
   int dev = 0;
@@ -272,12 +275,14 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
     e.p3.wscale = weight_scales(*aq, 3 * 1536, 1536);
   }
   if (!a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || a13.R < 1 || a13.R > 2 || a2.R != a13.R) return VAURA_ERR_ARG;
-  if (a13.wq != a2.wq || (a13.wq != 0 && a13.wq != 2) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 || a13.n_ss_in != 96) return VAURA_ERR_SHAPE;
+  if (a13.wq != a2.wq || a13.wq < 0 || a13.wq > 2 || (a13.wq == 1 && (a13.R != 2 || att)) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 ||
+      a13.n_ss_in != 96) return VAURA_ERR_SHAPE;
   e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
   if (a13.R == 2) {       // 17..32 decoder rows: both row blocks per weight fragment
+    if (a13.wq == 1) return aq ? launch_mlp_engine_t<1, true, 2>(e, s) : launch_mlp_engine_t<1, false, 2>(e, s);
     if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 2>(e, s) : launch_mlp_engine_t<0, true, 2>(e, s);
     return a13.wq == 2 ? launch_mlp_engine_t<2, false, 2>(e, s) : launch_mlp_engine_t<0, false, 2>(e, s);
   }

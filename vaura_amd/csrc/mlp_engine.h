@@ -94,8 +94,11 @@ template <int WT, int RBK = 1>
 struct MlpEngineShape {
   static constexpr int WH = WT == 2 ? 2 : 1;
   static constexpr int G2 = 8;                         // k-group pairs per wave in phase 2 (K = 4096)
-  static constexpr int PL = RBK == 2 ? (WT == 2 ? 3 : 6) : (WT == 2 ? 4 : 8);   // pairs per wave whose weights wait in LDS (the rest in registers)
-  static constexpr int WAVE_RING = 2 * PL * WH * 1024; // bytes of ring per wave: 16 KB (12 KB with two row blocks)
+  // WT = 1 (fp8 tile pairs, round 5; two row blocks only): ONE 1-KiB fragment holds both k-groups of a pair, so the whole w2 slice of
+  // a wave (8 fragments) waits in LDS
+  static constexpr int PL = WT == 1 ? 8 : (RBK == 2 ? (WT == 2 ? 3 : 6) : (WT == 2 ? 4 : 8));   // pairs per wave whose weights wait in LDS (the rest in registers)
+  static constexpr int NF = WT == 1 ? PL : 2 * PL * WH;   // 1-KiB fragments of ring per wave
+  static constexpr int WAVE_RING = NF * 1024;          // bytes of ring per wave: 16 KB (12 KB with two row blocks, 8 KB fp8)
   static constexpr int RED = RBK * MLPE_NW * 3 * 64 * 16;    // reduction tiles (every phase; the qkv phase has three tiles per wave)
   static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 128;     // + the arrival / hand-shake words
 };
@@ -170,7 +173,8 @@ template <int WT, bool QKV, int RBK = 1, bool ATT = false>
 __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __restrict__ W13q, const uint16_t* __restrict__ XPq,
                                                                   const void* __restrict__ W2q, MlpEngineArgs e) {
   using SH = MlpEngineShape<WT, RBK>;
-  constexpr bool F32 = WT == 2;
+  constexpr bool F32 = WT == 2, FP8 = WT == 1;
+  static_assert(!FP8 || (RBK == 2 && !ATT), "fp8 tile pairs: the two-row-block instances only (configs[4]'s shape)");
   constexpr int WH = SH::WH, NW = MLPE_NW, NACC = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlpe_lds[];
   unsigned char* ring = mlpe_lds;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     constexpr int G = 6, T = 2, XB = F32 ? 3 : 1;
     constexpr int K = 32 * G * NW, KG = K / 32, GB = G / XB;
     constexpr bool WBATCH = F32 && XB > 1;
-    constexpr int GW = WBATCH ? 2 * GB : G;
+    constexpr int GW = FP8 ? G / 2 : (WBATCH ? 2 * GB : G);      // fp8: one 16-byte load carries k-groups g and g + 1
     constexpr int NSS = K / 64;
     const int w = (wid + bid) % NW;
     const int m = lane & 15, q = lane >> 4;
@@ -386,12 +390,14 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         if (g < g0 || g >= g0 + n) continue;
+        if (FP8 && (g & 1)) continue;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const size_t kg = (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+          const size_t kg = FP8 ? (size_t)(tile0 + t) * (KG / 2) + (size_t)((w * G + g) >> 1) : (size_t)(tile0 + t) * KG + (size_t)(w * G + g);
+          const int slot = slot0 + (FP8 ? (g - g0) / 2 : g - g0);
 #pragma unroll
           for (int hh = 0; hh < WH; ++hh)
-            wb[t][slot0 + g - g0][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+            wb[t][slot][hh] = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
         }
       }
     };
@@ -450,7 +456,10 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           f16x8 wf[F32 ? 2 : 1];
-          if constexpr (F32) {
+          if constexpr (FP8) {
+            const u32x4 pr = wb[t][(b * GB + g) / 2][0];
+            wf[0] = (g & 1) ? fp8x8_to_f16(pr.z, pr.w) : fp8x8_to_f16(pr.x, pr.y);
+          } else if constexpr (F32) {
             const int slot = WBATCH ? (b & 1) * GB + g : b * GB + g;
             wf[0] = __builtin_bit_cast(f16x8, wb[t][slot][0]);
             wf[1] = __builtin_bit_cast(f16x8, wb[t][slot][WH - 1]);
@@ -564,13 +573,15 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     auto prefetch_q = [&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       if constexpr (Q < 2) {
-        const unsigned char* src = static_cast<const unsigned char*>(a.W) + ((size_t)tile * KG + 2 * (size_t)(w * G2)) * BS + lane * 16;
+        // the wave's slice = consecutive 1-KiB fragments ((k-group, plane) blocks; fp8: one per k-group PAIR); quarter Q = half of those
+        // that wait in LDS
+        const unsigned char* src = static_cast<const unsigned char*>(a.W) +
+                                   (FP8 ? ((size_t)tile * (KG / 2) + (size_t)(w * G2)) * 1024 : ((size_t)tile * KG + 2 * (size_t)(w * G2)) * BS) + lane * 16;
+        constexpr int NFQ = SH::NF / 2;
 #pragma unroll
-        for (int c = Q * PL; c < (Q + 1) * PL; ++c)
-#pragma unroll
-          for (int hh = 0; hh < WH; ++hh)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(c * WH + hh) * 1024),
-                                             (__attribute__((address_space(3))) void*)(myring + (c * WH + hh) * 1024), 16, 0, 2 /* nt */);
+        for (int f = Q * NFQ; f < (Q + 1) * NFQ; ++f)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)f * 1024),
+                                           (__attribute__((address_space(3))) void*)(myring + f * 1024), 16, 0, 2 /* nt */);
       } else {
         constexpr int HALF = (G2 - PL) / 2;
 #pragma unroll
@@ -676,7 +687,10 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
           f16x8 wf[F32 ? 2 : 1];
-          if (j < PL) {
+          if constexpr (FP8) {      // half sb of the pair's fragment: 8 bytes of lane (la + 8 nh, q)
+            const uint2 pr = *reinterpret_cast<const uint2*>(myring + j * 1024 + (la + 8 * nh + 16 * q) * 16 + sb * 8);
+            wf[0] = fp8x8_to_f16(pr.x, pr.y);
+          } else if (j < PL) {
             const u32x4* fr = reinterpret_cast<const u32x4*>(myring + ((2 * j + sb) * WH) * 1024) + (la + 8 * nh + 16 * q);
             wf[0] = __builtin_bit_cast(f16x8, fr[0]);
             if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, fr[64]);
@@ -737,24 +751,33 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       // producers = these same workgroups); behind the hand-off: one round trip for the planes, 18 products per wave, reduction,
       // rinv, store of the two K-half partials the attention kernel adds on load.  One launch and one kernel boundary less per layer.
       Gemv3Args aq = e.p3;
-      constexpr int G = 3, TQ = 3, KQ = 1536, KGQ = KQ / 32;
-      const int ks = bid & 1, tile0q = (bid >> 1) * TQ, kgo = ks * G * NW;
-      const int w3 = (wid + bid) % NW;
+      // fp8 tile pairs hold two k-groups per fragment, and a K half is 24 k-groups: FOUR waves take six each (three fragments per
+      // tile) — the slices, products and 4-wave reduction of gemv3_kernel<6, 4, 3, E3_STORE, true, 1, 0, 1, 2> — waves 4 .. 7 only
+      // pass the barriers (and finish tiles: any wave can run an epilogue)
+      constexpr int G = FP8 ? 6 : 3, NWQ = FP8 ? 4 : NW, GF = 3, TQ = 3, KQ = 1536, KGQ = KQ / 32;
+      const int ks = bid & 1, tile0q = (bid >> 1) * TQ, kgo = ks * G * NWQ;
+      const bool actq = wid < NWQ;                     // this wave multiplies in the qkv phase
+      const int w3 = (wid + bid) % NWQ;
       const int mq = lane & 15;
       const int lane16 = lane * 16;
       const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(aq.W), 0, -16, 0x00020000);
-      u32x4 wq[TQ][G][WH];
+      u32x4 wq[TQ][GF][WH];                            // GF fragments per tile: k-groups (x planes), or fp8 k-group pairs
+      auto wq_off = [&](int t, int f, int hh) {
+        const size_t kg = FP8 ? (size_t)(tile0q + t) * (KGQ / 2) + (size_t)((kgo + w3 * G + 2 * f) >> 1)
+                              : ((size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + f)) * WH + hh;
+        return (int)(kg * 1024);
+      };
       auto load_wq_g = [&](auto gc) {
         constexpr int g = decltype(gc)::value;
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
-          const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
 #pragma unroll
           for (int hh = 0; hh < WH; ++hh)
-            wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+            wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, wq_off(t, g, hh), 2 /* nt */);
         }
       };
       auto load_wq = [&]() {
+        if (!actq) return;
         load_wq_g(std::integral_constant<int, 0>{});
         load_wq_g(std::integral_constant<int, 1>{});
         load_wq_g(std::integral_constant<int, 2>{});
@@ -763,16 +786,15 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
       const bool epq = wid < TQ * RBK;                 // this wave finishes tile (wid % TQ) of row block (wid / TQ) of the qkv phase
       const int rq = wid / TQ, tq = wid - rq * TQ;
-      if (!epw) {
+      if (!epw && actq) {
         if (!(e.abl & 8)) {   // PRE3 of the three k-groups at once, the rest once wave 0's phase-2 stores are in the memory pipeline
           // in ninths (k-group g, tile t; unit = 3 g + t): PRE3U of them at once, the rest behind the hold
           constexpr int PRE3U = MlpeThrottle<WT, RBK>::PRE3U;
           auto unit = [&](auto uc) {
             constexpr int u = decltype(uc)::value, g = u / 3, t = u % 3;
-            const size_t kg = (size_t)(tile0q + t) * KGQ + (size_t)(kgo + w3 * G + g);
 #pragma unroll
             for (int hh = 0; hh < WH; ++hh)
-              wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, (int)((kg * WH + hh) * 1024), 2 /* nt */);
+              wq[t][g][hh] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane16, wq_off(t, g, hh), 2 /* nt */);
           };
           va_static_for9([&](auto uc) { if constexpr (decltype(uc)::value < PRE3U) unit(uc); });
           if (PRE3U < 9)
@@ -816,7 +838,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       u32x4 xq[RBK][G][VA_NPL];
 #pragma unroll
       for (int r = 0; r < RBK; ++r) {
-        const int xl16 = r * 16 + mq < aq.rows ? lane16 : 0x7ffffff0;
+        const int xl16 = (actq && r * 16 + mq < aq.rows) ? lane16 : 0x7ffffff0;
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -838,22 +860,31 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int t = 0; t < TQ; ++t)
 #pragma unroll
           for (int p = 0; p < NACC; ++p) accq[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (actq) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
 #pragma unroll
         for (int t = 0; t < TQ; ++t) {
           f16x8 wf[F32 ? 2 : 1];
-          wf[0] = __builtin_bit_cast(f16x8, wq[t][g][0]);
-          if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wq[t][g][WH - 1]);
+          if constexpr (FP8) {
+            const u32x4 pr = wq[t][g / 2][0];
+            wf[0] = (g & 1) ? fp8x8_to_f16(pr.z, pr.w) : fp8x8_to_f16(pr.x, pr.y);
+          } else {
+            wf[0] = __builtin_bit_cast(f16x8, wq[t][g][0]);
+            if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wq[t][g][WH - 1]);
+          }
 #pragma unroll
           for (int r = 0; r < RBK; ++r) mfma_group<WT>(wf, xq[r][g], accq[r][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      }
+      if (actq) {
 #pragma unroll
-      for (int r = 0; r < RBK; ++r)
+        for (int r = 0; r < RBK; ++r)
 #pragma unroll
-        for (int t = 0; t < TQ; ++t) red[((r * NW + wid) * TQ + t) * 64 + lane] = acc_sum<WT>(accq[r][t]);
+          for (int t = 0; t < TQ; ++t) red[((r * NW + wid) * TQ + t) * 64 + lane] = acc_sum<WT>(accq[r][t]);
+      }
       float rinvq = 1.f;
       if (epq) {
         float ssp = 0.f;
@@ -869,7 +900,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       if (epq && rq * 16 < aq.rows) {
         f32x4 sacc = red[((rq * NW + 0) * TQ + tq) * 64 + lane];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) sacc += red[((rq * NW + i) * TQ + tq) * 64 + lane];
+        for (int i = 1; i < NWQ; ++i) sacc += red[((rq * NW + i) * TQ + tq) * 64 + lane];
         sacc *= wsq;
         const f32x4 v = sacc * rinvq;
         if (ks > 0) aq.out = aq.out2;
