@@ -1125,3 +1125,50 @@ def test_full_depth_trained_like_statistics_against_live_oracle(full_sampler_sd_
         assert err < 3e-4 * max(1.0, scale), (err, scale)
     del eng
     torch.cuda.empty_cache()
+
+
+_EDGE_CASES = [
+    # B, T, Tp, Tv, kwargs                                       (edge of ...)
+    (1, 1, 0, 32, dict()),                                       # a single frame: S = 10, nine of the ten steps only flush the delay pattern
+    (1, 2, 1, 32, dict(cfg_scale=6.0)),                          # prompt = T - 1: ONE frame to generate, prompt pass of 1 position
+    (3, 10, 9, 32, dict(use_sampling=True, top_k=1)),            # top-k 1 under sampling = argmax whatever the noise
+    (2, 12, 0, 32, dict(use_sampling=True, temp=0.0)),           # temp <= 0 -> greedy (vaura_model.py:816, 825)
+    (2, 12, 0, 32, dict(use_sampling=True, top_k=1024)),         # k = the whole codebook: every token kept
+    (2, 12, 3, 32, dict(use_sampling=True, top_k=250, top_p=1.0, cfg_scale=3.5)),   # top-p wins over top-k (:818-823); p = 1 keeps all
+    (2, 12, 0, 32, dict(use_sampling=True, top_p=0.05, temp=1.7)),                   # tiny nucleus, hot temperature
+    (5, 9, 0, 1, dict(cfg_scale=1.0)),                           # ONE video token: positions >= 7 read empty_video_emb
+    (17, 6, 2, 32, dict(cfg_scale=6.0, use_sampling=True, top_k=128)),               # 34 rows: three row blocks, ragged
+    (9, 7, 0, 32, dict(use_sampling=True)),                      # plain multinomial, 9 rows (ragged single block)
+]
+
+
+@pytest.mark.parametrize("case", range(len(_EDGE_CASES)))
+@pytest.mark.parametrize("wdtype", ["h2", "f32"])
+def test_edge_cases_against_live_oracle(case, wdtype):
+    """Corners of generate() (vaura_model.py:410-597, 775-827; utils/utils.py:139-196) against the live oracle, token for token, on
+    the default arithmetic and on the exact-fp32 engine: a single frame, a prompt of T - 1 frames, top-k 1 / beyond the codebook,
+    temperature 0, top-p with top-k set (top-p wins), a tiny nucleus, one video token, 34 rows, plain multinomial."""
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    B, T, Tp, Tv, kw = _EDGE_CASES[case]
+    cfg = synth.tiny_sampler(2)
+    sd = synth.sampler_state_dict(cfg, seed=141, round_bf16=False)
+    if kw.get("cfg_scale", 1.0) > 1.0 and Tv != 32:
+        pytest.skip("the CFG null embedding is fixed at 32 tokens")
+    feats = synth.video_features(B, tokens=Tv, seed=142 + case)
+    prompt = torch.randint(0, 1024, (B, 9, Tp), generator=torch.Generator().manual_seed(143 + case)) if Tp else None
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
+    n_pass = T + 9 - (Tp + 1)
+    nz = synth.exp_noise(n_pass, B * 9, 1024, 144 + case) if kw.get("use_sampling") else None
+    ref = go.generate(dec, feats, T, prompt=prompt, mode="cached", noise=nz, **kw)
+    eng = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
+    got = eng.generate_codes_checked(feats.to(DEV), T, prompt=None if prompt is None else prompt.to(DEV), noise=nz, **kw).cpu()
+    assert got.shape == (B, 9, T)
+    assert torch.equal(got, ref), (case, wdtype, float((got == ref).float().mean()))
+    assert eng.range_fallbacks == 0
+    if case == 0:
+        # k beyond the codebook: the reference's sample_top_k calls torch.topk(probs, k) and raises (utils/utils.py:172); so does this build
+        from vaura_amd import _lib as L
+        with pytest.raises(L.VauraHipError, match="top_k"):
+            eng.generate_codes(feats.to(DEV), T, use_sampling=True, top_k=5000)
+        eng.generate_codes(feats.to(DEV), T, use_sampling=True, top_k=5000, top_p=0.5)      # top-p wins: top_k is never looked at (:818-823)

@@ -327,6 +327,9 @@ class DecoderEngine:
 
     # ------------------------------------------------------------------ generation
     def _sampling(self, use_sampling, temp, top_k, top_p, cfg_scale, seed, clip_base) -> L.Sampling:
+        if use_sampling and temp > 0.0 and not top_p > 0.0 and int(top_k) > self.cfg.d_codebook:
+            # the reference's sample_top_k is torch.topk(probs, k) (utils/utils.py:172): k beyond the codebook raises there too
+            raise L.VauraHipError(f"top_k = {top_k} exceeds the codebook size {self.cfg.d_codebook} (the reference's torch.topk raises as well)")
         return L.Sampling(int(bool(use_sampling)), float(temp), int(top_k), float(top_p),
                           float(cfg_scale if self.rows == 2 * self.batch else 1.0), int(seed), int(clip_base))
 
