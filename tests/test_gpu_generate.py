@@ -1172,3 +1172,21 @@ def test_edge_cases_against_live_oracle(case, wdtype):
         with pytest.raises(L.VauraHipError, match="top_k"):
             eng.generate_codes(feats.to(DEV), T, use_sampling=True, top_k=5000)
         eng.generate_codes(feats.to(DEV), T, use_sampling=True, top_k=5000, top_p=0.5)      # top-p wins: top_k is never looked at (:818-823)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (3, 7), (2, 33)])
+def test_dac_decode_edge_lengths_against_the_oracle(B, T):
+    """Codec decode at the short end (a single frame = 512 samples: every conv's receptive field is mostly zero padding, every
+    workgroup tile is ragged) and at odd lengths / batches: default precision within the north star's 1e-4 RMS of the fp32 CPU
+    restatement, the exact-fp32 precision within 5e-6; and the plugin's EnCodec-style frame list input gives the same waveform."""
+    from oracle import dac_oracle
+    ccfg = synth.FULL_CODEC
+    sd = synth.codec_state_dict(ccfg, seed=5)
+    codes = torch.randint(0, 1024, (B, 9, T), generator=torch.Generator().manual_seed(100 * B + T))
+    ref = dac_oracle.decode(sd, codes, ccfg.decoder_rates)
+    assert ref.shape == (B, 1, T * 512)
+    for precision, tol in (("f16pair", 1e-4), ("f32", 5e-6)):
+        got = CodecEngine(ccfg, sd, DEV, precision=precision).decode(codes.to(DEV)).cpu()
+        assert got.shape == ref.shape and bool(torch.isfinite(got).all())
+        rms = float(((got - ref) ** 2).mean().sqrt())
+        assert rms <= tol, (precision, B, T, rms)
