@@ -396,3 +396,54 @@ def test_reference_itself_cannot_run_the_trajectory_or_joint_backbone():
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "finding holds" in r.stdout
+
+
+def test_parity_report_helpers_are_strict_and_locate_the_first_difference():
+    """tests/parity_helpers.py (what the -m gpu suite judges token parity with): equal tensors pass and are recorded; one flipped token
+    fails `assert_tokens_equal` with the step, clip and codebook of the FIRST difference (delay pattern: frame t of codebook k is
+    produced at sequence step t + 1 + k; with a prompt the passes start at step Tp + 1) and the reference's margin there; the
+    near-tie form admits a first difference only where the recorded margin is below the tolerance, and only with everything before it
+    identical."""
+    from parity_helpers import ParityReport, assert_tokens_equal, assert_tokens_or_recorded_near_tie, token_diff_summary
+    B, K, T, Tp = 2, 9, 12, 4
+    ref = torch.randint(0, 1024, (B, K, T), generator=torch.Generator().manual_seed(1))
+    margins = np.full((T + K - 1 - Tp, B, K), 1e-2, dtype=np.float32)        # passes fill steps Tp + 1 .. T + K - 1
+    rep = ParityReport()
+    e = assert_tokens_equal(rep, "g", "h2", "case", ref.clone(), ref, margins, first_step=Tp + 1)
+    assert e["tokens_equal"] and e["clips_identical"] == B and e["first_diff_step"] is None and len(rep.entries) == 1
+    tok = ref.clone()
+    tok[1, 3, 7] = (tok[1, 3, 7] + 1) % 1024                                   # produced at step 7 + 1 + 3 = 11
+    tok[1, 5, 9] = (tok[1, 5, 9] + 1) % 1024                                   # a later one (step 15)
+    margins[11 - (Tp + 1), 1, 3] = 3e-6
+    s = token_diff_summary(tok, ref, margins, first_step=Tp + 1)
+    assert not s["tokens_equal"] and s["first_diff_step"] == 11 and s["first_diff_clip"] == 1 and s["first_diff_codebooks"] == [3]
+    assert abs(s["reference_margin_there"] - 3e-6) < 1e-12 and s["clips_identical"] == 1
+    with pytest.raises(AssertionError, match="first differs at step 11"):
+        assert_tokens_equal(rep, "g", "h2", "case", tok, ref, margins, first_step=Tp + 1)
+    # admitted as a recorded near-tie (margin 3e-6 < 2e-5): everything produced before step 11 is identical
+    e = assert_tokens_or_recorded_near_tie(rep, "g", "h2", "case", tok, ref, margins, 2e-5, first_step=Tp + 1)
+    assert not e["tokens_equal"] and e["near_tie_tolerance"] == 2e-5
+    margins[11 - (Tp + 1), 1, 3] = 1e-3                                         # not a near-tie any more: refused
+    with pytest.raises(AssertionError, match="margin"):
+        assert_tokens_or_recorded_near_tie(rep, "g", "h2", "case", tok, ref, margins, 2e-5, first_step=Tp + 1)
+    assert len(list(rep.summary_lines())) == len(rep.entries) == 4
+
+
+def test_trained_like_checkpoint_is_deterministic_and_has_the_advertised_statistics(tiny_sampler_sd):
+    """synth.trained_like (the full-depth robustness tests' checkpoint): deterministic in (state dict, seed), heavy-tailed streamed
+    matrices (kurtosis far above a Gaussian's 3), outlier norm gains, two token-embedding output channels x 100; `massive` scales two
+    norm gains deep in the stack on top."""
+    a, b = synth.trained_like(tiny_sampler_sd, seed=3), synth.trained_like(tiny_sampler_sd, seed=3)
+    assert all(torch.equal(a[k], b[k]) for k in a) and set(a) == set(tiny_sampler_sd)
+    c = synth.trained_like(tiny_sampler_sd, seed=4)
+    assert any(not torch.equal(a[k], c[k]) for k in a)
+    w0, w1 = tiny_sampler_sd["layers.0.feed_forward.w1.weight"].float(), a["layers.0.feed_forward.w1.weight"].float()
+    kurt = lambda w: float(((w - w.mean()) ** 4).mean() / w.var() ** 2)
+    assert kurt(w0) < 3.5 and kurt(w1) > 30.0
+    g = a["layers.0.attention_norm.weight"]
+    assert float(g.max() / g.median()) > 8.0
+    wg0, wg1 = tiny_sampler_sd["tok_embeddings.0.out_proj.weight_g"].reshape(-1), a["tok_embeddings.0.out_proj.weight_g"].reshape(-1)
+    assert torch.allclose(wg1[[7, 300]], wg0[[7, 300]] * 100.0) and torch.equal(wg1[8], wg0[8])
+    m = synth.trained_like(tiny_sampler_sd, seed=3, massive=3000.0)
+    changed = [k for k in a if not torch.equal(a[k], m[k])]
+    assert len(changed) == 2 and all(k.endswith("norm.weight") for k in changed)
