@@ -99,6 +99,32 @@ class DecoderOracle:
         """CFG null branch, vaura_model.py:790-793."""
         return torch.zeros_like(cond) + self.sd["cls_embeddings.uncond_embedding"]
 
+    # ---------------------------------------------------------------- one layer, op by op (pinned by tests/golden/ops.npz)
+    def attention(self, x: torch.Tensor, l: int, tab: torch.Tensor) -> torch.Tensor:
+        """Attention.forward (llama.py:219-260) of layer l on an already-normed x (Bs, L, D): wqkv -> rope(q, k) -> causal SDPA -> wo."""
+        Bs, L, _ = x.shape
+        p = f"layers.{l}."
+        qkv = F.linear(x, self.sd[p + "attention.wqkv.weight"])
+        q, k, v = qkv.split([self.D, self.D, self.D], dim=-1)
+        q = apply_rope(q.view(Bs, L, self.H, self.hd), tab).transpose(1, 2)
+        k = apply_rope(k.view(Bs, L, self.H, self.hd), tab).transpose(1, 2)
+        v = v.view(Bs, L, self.H, self.hd).transpose(1, 2)
+        a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # llama.py:246-255
+        a = a.transpose(1, 2).contiguous().view(Bs, L, self.D)
+        return F.linear(a, self.sd[p + "attention.wo.weight"])
+
+    def feed_forward(self, x: torch.Tensor, l: int) -> torch.Tensor:
+        """FeedForward.forward (llama.py:176-177) of layer l on an already-normed x: w2(silu(w1 x) * w3 x)."""
+        p = f"layers.{l}."
+        g = F.silu(F.linear(x, self.sd[p + "feed_forward.w1.weight"])) * F.linear(x, self.sd[p + "feed_forward.w3.weight"])
+        return F.linear(g, self.sd[p + "feed_forward.w2.weight"])
+
+    def block(self, h: torch.Tensor, l: int, tab: torch.Tensor) -> torch.Tensor:
+        """TransformerBlock.forward (llama.py:272-283): pre-norm residual (DropPath / Dropout are the identity in eval mode)."""
+        p = f"layers.{l}."
+        h = h + self.attention(rmsnorm(h, self.sd[p + "attention_norm.weight"], self.eps), l, tab)
+        return h + self.feed_forward(rmsnorm(h, self.sd[p + "ffn_norm.weight"], self.eps), l)
+
     # ---------------------------------------------------------------- full recompute
     def forward_full(self, idx: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
         """idx (Bs,K,L) int64, cond (Bs,Tv,768) -> logits (Bs,K,L,V); llama.py:445-504."""
@@ -108,20 +134,7 @@ class DecoderOracle:
         h = torch.cat([cp, tok], dim=-1)
         tab = self.rope[:L]
         for l in range(self.L):
-            p = f"layers.{l}."
-            x = rmsnorm(h, self.sd[p + "attention_norm.weight"], self.eps)
-            qkv = F.linear(x, self.sd[p + "attention.wqkv.weight"])
-            q, k, v = qkv.split([self.D, self.D, self.D], dim=-1)
-            q = apply_rope(q.view(Bs, L, self.H, self.hd), tab).transpose(1, 2)
-            k = apply_rope(k.view(Bs, L, self.H, self.hd), tab).transpose(1, 2)
-            v = v.view(Bs, L, self.H, self.hd).transpose(1, 2)
-            a = F.scaled_dot_product_attention(q, k, v, is_causal=True)  # llama.py:246-255
-            a = a.transpose(1, 2).contiguous().view(Bs, L, self.D)
-            h = h + F.linear(a, self.sd[p + "attention.wo.weight"])
-            x = rmsnorm(h, self.sd[p + "ffn_norm.weight"], self.eps)
-            g = F.silu(F.linear(x, self.sd[p + "feed_forward.w1.weight"])) * F.linear(
-                x, self.sd[p + "feed_forward.w3.weight"])
-            h = h + F.linear(g, self.sd[p + "feed_forward.w2.weight"])
+            h = self.block(h, l, tab)
         h = rmsnorm(h, self.sd["norm.weight"], self.eps)
         return torch.einsum("bld,kvd->bklv", h, self.head_w)
 

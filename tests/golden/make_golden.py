@@ -1,6 +1,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (build container only).
 
     python tests/golden/make_golden.py small         # patterns, sampler, tiny-model cases (seconds)
+    python tests/golden/make_golden.py ops           # op-level outputs of the reference's own modules on a 2-layer trained-like checkpoint (seconds)
     python tests/golden/make_golden.py full_greedy   # 24-layer model, B=2, T=220, greedy   (~4 min)
     python tests/golden/make_golden.py full_sample   # 24-layer, B=2, cfg 6, top-k 250      (~8 min)
     python tests/golden/make_golden.py full_greedy_raw   # full_greedy on the UN-rounded checkpoint (~4 min)
@@ -187,6 +188,56 @@ def gold_tiny():
                        use_sampling=False, prompt_is_encoded=True, cfg_scale=1.0, remove_prompts=False)
     out["prompt8_greedy_T20"] = r["sampled_indices"].numpy().astype(np.int16)
     save("tiny_model.npz", **out)
+
+
+def gold_ops():
+    """op-level vectors from the reference's OWN modules — RMSNorm, precompute_freqs_cis / apply_rotary_emb,
+    Attention.forward, FeedForward, TransformerBlock, AVCLIPEmbedder, DacEmbeddingProjection, _repeat_and_pad_video — captured by
+    forward hooks during ONE Transformer.forward of the 2-layer model (full width) on the trained-like checkpoint (non-trivial norm
+    gains, heavy tails: synth.trained_like), plus direct calls of the free functions.  Channels are sub-sampled (every 8th) to keep
+    the fixture small; inputs are regenerated from seeds."""
+    cfg = synth.tiny_sampler(2)
+    sd = synth.trained_like(synth.sampler_state_dict(cfg, seed=3, round_bf16=False), seed=11)
+    model = rh.build_reference_model(cfg.yaml_params(), sd)
+    from models.modules.sampler.llama import apply_rotary_emb, precompute_freqs_cis
+    smp = model.sampler
+    feats = synth.video_features(2, tokens=4, seed=21)                    # 4 video tokens: positions >= 28 read empty_video_emb
+    idx = torch.randint(0, 1025, (2, 9, 12), generator=torch.Generator().manual_seed(22))
+    taps = {}
+
+    def tap(name, with_input=False):
+        def hook(_m, inp, out):
+            taps[name] = out.detach().clone()
+            if with_input:
+                taps[name + "_in"] = inp[0].detach().clone()
+        return hook
+    hooks = [smp.layers[0].attention_norm.register_forward_hook(tap("rmsnorm", True)),
+             smp.layers[0].attention.register_forward_hook(tap("attention", True)),
+             smp.layers[0].feed_forward.register_forward_hook(tap("ffn", True)),
+             smp.layers[0].register_forward_hook(tap("block0", True)),
+             smp.layers[1].register_forward_hook(tap("block1")),
+             smp.cls_embeddings.register_forward_hook(tap("cond_proj")),
+             smp.tok_embeddings[0].register_forward_hook(tap("tok_emb0")),
+             smp.tok_embeddings[8].register_forward_hook(tap("tok_emb8"))]
+    with torch.no_grad():
+        logits, _, _ = smp(tgt=idx, memory=feats)
+        padded = smp._repeat_and_pad_video(taps["cond_proj"], 31)
+        fc = precompute_freqs_cis(40, 96, 10000)
+        x = torch.randn(2, 5, 16, 96, generator=torch.Generator().manual_seed(23))
+        rot = apply_rotary_emb(x, fc[:5])
+    for h in hooks:
+        h.remove()
+    assert torch.equal(taps["rmsnorm_in"], taps["block0_in"]) and torch.equal(taps["attention_in"], taps["rmsnorm"])
+    sub = lambda t: t[..., ::8].numpy()
+    save("ops.npz", layers=np.int64(2), weight_seed=np.int64(3), trained_like_seed=np.int64(11), feat_seed=np.int64(21), idx_seed=np.int64(22),
+         rope_seed=np.int64(23), idx=idx.numpy().astype(np.int16),
+         # block0_in is also RMSNorm's input; RMSNorm's output is also Attention.forward's input
+         block0_in=taps["block0_in"].numpy(), rmsnorm=taps["rmsnorm"].numpy(), attention=sub(taps["attention"]),
+         ffn_in=taps["ffn_in"].numpy(), ffn=sub(taps["ffn"]), block0=sub(taps["block0"]), block1=sub(taps["block1"]),
+         cond_proj=taps["cond_proj"].numpy(), padded_video=padded[:, [0, 6, 7, 27, 28, 30]].numpy(),
+         tok_emb0=sub(taps["tok_emb0"]), tok_emb8=sub(taps["tok_emb8"]),
+         freqs_cis=torch.view_as_real(fc).numpy() if fc.is_complex() else fc.numpy(), rope_out=rot.numpy(),
+         logits_last=logits[:, :, -1, ::16].numpy())
 
 
 # ------------------------------------------------------------------------------------- full size
@@ -505,6 +556,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     if what == "small":
         gold_patterns(); gold_sampling(); gold_tiny()
+    elif what == "ops":
+        gold_ops()
     elif what == "full_greedy":
         gold_full_greedy()
     elif what == "full_greedy_raw":

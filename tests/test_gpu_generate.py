@@ -1190,3 +1190,24 @@ def test_dac_decode_edge_lengths_against_the_oracle(B, T):
         assert got.shape == ref.shape and bool(torch.isfinite(got).all())
         rms = float(((got - ref) ** 2).mean().sqrt())
         assert rms <= tol, (precision, B, T, rms)
+
+
+@pytest.mark.parametrize("wdtype", ["h2", "f32"])
+def test_reference_op_vectors_on_the_trained_like_tiny_checkpoint(golden, wdtype):
+    """tests/golden/ops.npz (outputs of the reference's own modules on a 2-layer TRAINED-LIKE checkpoint: non-trivial norm gains,
+    heavy-tailed matrices, massive token-embedding channels): the hoisted video MLP equals the reference's AVCLIPEmbedder output, and
+    the last-position logits of the same forward (4 video tokens, 12 positions) are within 3e-5 of their scale."""
+    g = golden("ops.npz")
+    cfg = synth.tiny_sampler(2)
+    sd = synth.trained_like(synth.sampler_state_dict(cfg, seed=int(g["weight_seed"]), round_bf16=False), seed=int(g["trained_like_seed"]))
+    eng = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
+    feats = synth.video_features(2, tokens=4, seed=int(g["feat_seed"])).to(DEV)
+    idx = torch.from_numpy(g["idx"].astype(np.int64)).to(DEV)
+    lg = eng.logits_all_positions(idx, feats).cpu()
+    ref = torch.from_numpy(g["logits_last"])
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((lg[:, :, -1, ::16] - ref).abs().max())
+    print(f"reference op vectors [{wdtype}]: last-position logits error {err:.3e} on a scale of {scale:.1f}")
+    assert err < 3e-5 * scale, (err, scale)
+    cp = eng.cond_projection().cpu()
+    assert float((cp - torch.from_numpy(g["cond_proj"])).abs().max()) < 1e-5 * max(1.0, float(np.abs(g["cond_proj"]).max()))

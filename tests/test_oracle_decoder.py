@@ -195,3 +195,46 @@ def test_later_longform_chunk_golden_first_steps(golden, full_sampler_sd_raw):
     refg = torch.from_numpy(gg["tokens"].astype(np.int64))[:1, :, :Tshort]
     assert torch.equal(tokg[same_steps[:1]], refg[same_steps[:1]])
     assert float(gg["margins"][175 - 167, 1, 8]) < 1e-5                  # the run's literal tie (clip 1, step 175, codebook 8)
+
+
+def test_op_level_vectors_of_the_reference_modules(golden):
+    """the oracle's ops, one by one, against outputs captured from the reference's OWN modules (make_golden.py ops:
+    forward hooks on RMSNorm, Attention, FeedForward, TransformerBlock, AVCLIPEmbedder, DacEmbeddingProjection during one forward of
+    the 2-layer model on a trained-like checkpoint; `_repeat_and_pad_video`, `precompute_freqs_cis` and `apply_rotary_emb` called
+    directly)."""
+    from oracle import decoder_oracle as do
+    g = golden("ops.npz")
+    cfg = synth.tiny_sampler(2)
+    sd = synth.trained_like(synth.sampler_state_dict(cfg, seed=int(g["weight_seed"]), round_bf16=False), seed=int(g["trained_like_seed"]))
+    dec = DecoderOracle(sd, cfg.num_layers, cfg.nhead)
+    t = lambda k: torch.from_numpy(g[k])
+    sub = lambda x: x[..., ::8]
+    close = lambda a, b, tol=2e-5: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    h0 = t("block0_in")
+    L = h0.shape[1]
+    tab = dec.rope[:L]
+    # RMSNorm (llama.py:147-158) with a non-trivial gain
+    x = do.rmsnorm(h0, dec.sd["layers.0.attention_norm.weight"], dec.eps)
+    assert float(dec.sd["layers.0.attention_norm.weight"].max()) > 5.0 and close(x, t("rmsnorm"))
+    # rope table + rotation (llama.py:593-603, 633-650)
+    assert close(do.rope_table(40, 96), t("freqs_cis"), 1e-6)
+    xr = torch.randn(2, 5, 16, 96, generator=torch.Generator().manual_seed(int(g["rope_seed"])))
+    assert close(do.apply_rope(xr, do.rope_table(40, 96)[:5]), t("rope_out"), 1e-6)
+    # Attention.forward, FeedForward, TransformerBlock (llama.py:219-283) on the reference's own intermediate inputs
+    assert close(sub(dec.attention(t("rmsnorm"), 0, tab)), t("attention"))
+    assert close(sub(dec.feed_forward(t("ffn_in"), 0)), t("ffn"))
+    b0 = dec.block(h0, 0, tab)
+    assert close(sub(b0), t("block0")) and close(sub(dec.block(b0, 1, tab)), t("block1"))
+    # AVCLIPEmbedder, _repeat_and_pad_video (positions 28.. read empty_video_emb with 4 video tokens), DacEmbeddingProjection
+    feats = synth.video_features(2, tokens=4, seed=int(g["feat_seed"]))
+    cp = dec.cond_projection(feats)
+    assert close(cp, t("cond_proj"))
+    assert close(dec.cond_for_positions(cp, torch.tensor([0, 6, 7, 27, 28, 30])), t("padded_video"))
+    idx = torch.from_numpy(g["idx"].astype(np.int64))
+    import torch.nn.functional as F
+    for k in (0, 8):
+        e = F.linear(F.embedding(idx[:, k], dec.sd[f"tok_embeddings.{k}.emb.weight"]), dec.tok_w[k], dec.tok_b[k])
+        assert close(sub(e), t(f"tok_emb{k}"))
+    # and the whole thing: last-position logits of that forward
+    lg = dec.forward_full(idx, feats)
+    assert close(lg[:, :, -1, ::16], t("logits_last"))
