@@ -49,3 +49,4 @@ with torch.cuda.stream(s):
             hs.append(1e3 * (time.perf_counter() - t0))
             torch.cuda.synchronize()
         print(f"{name:16s} one batch on an idle stream: host enqueue {sorted(hs)[2]:8.3f} ms (median of 5)")
+    eng.check_status()        # a broken hand-off / non-finite logits would make these times meaningless: fail instead
