@@ -162,6 +162,11 @@ def test_two_ranks_on_one_device_uuid_are_refused():
     bad = [dict(ok[0]), dict(ok[1], uuid=ok[0]["uuid"]), dict(ok[2])]
     with pytest.raises(RuntimeError, match="3 ranks but only 2 distinct"):
         vdist.assert_distinct_devices(bad)
+    # a runtime that reports the SAME uuid for every device while the ranks sit on distinct device indices: not a shared GPU
+    vdist.assert_distinct_devices([{"rank": r, "device": f"cuda:{r}", "uuid": "00000000-0000"} for r in range(8)])
+    # ... but one uuid AND one device index is
+    with pytest.raises(RuntimeError, match="shared by several ranks"):
+        vdist.assert_distinct_devices([{"rank": r, "device": "cuda:0", "uuid": "00000000-0000"} for r in range(2)])
     # no uuid reported (older runtime): the device string decides
     with pytest.raises(RuntimeError, match="shared by several ranks"):
         vdist.assert_distinct_devices([{"rank": 0, "device": "cuda:0"}, {"rank": 1, "device": "cuda:0"}])

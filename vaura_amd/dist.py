@@ -74,11 +74,16 @@ def assert_distinct_devices(seen: List[dict]) -> None:
     """Every rank of a clip-parallel job must sit on its OWN GPU: two ranks with the same device uuid means a launcher bound them
     to one device, and the aggregate rate would be a shared-GPU artefact (and the one-launch MLP's in-launch hand-off would starve,
     csrc/mlp_engine.h).  Raises on every rank that sees the list (all of them: ``ranks_seen`` is an all-gather)."""
-    ids = [(r.get("uuid") or r.get("device")) for r in seen]
+    uu, dv = [r.get("uuid") for r in seen], [r.get("device") for r in seen]
+    ids = [(u or d) for u, d in zip(uu, dv)]
+    if len(seen) > 1 and all(uu) and len(set(uu)) == 1 and len(set(dv)) == len(seen):
+        # a runtime that reports ONE uuid for every device (seen on some ROCm builds) while every rank sits on its own device index:
+        # the uuid does not distinguish anything there — judge by the device index instead of failing a correct launch
+        ids = dv
     dup = sorted({i for i in ids if ids.count(i) > 1})
     if len(seen) > 1 and dup:
         raise RuntimeError(f"{len(seen)} ranks but only {len(set(ids))} distinct GPU(s): device id(s) {dup} are shared by several ranks "
-                           f"({[(r['rank'], r.get('device')) for r in seen if (r.get('uuid') or r.get('device')) in dup]})")
+                           f"({[(r['rank'], r.get('device')) for r, i in zip(seen, ids) if i in dup]})")
 
 
 def gather_floats(x: float, device) -> List[float]:
