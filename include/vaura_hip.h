@@ -372,11 +372,19 @@ size_t vaura_dac_encode_workspace_elems(const vaura_codec_encoder* c, int B, int
  * scale_audio / save_results (scripts/generate.py:404, 440-461), per clip.  wav/out: (n_clips, n_samples) fp32 (may
  * alias).  strategy: 0 'clip' (the generate_*.yaml default: clamp to +-10^(-db/20)), 1 'peak', 2 'rms' (then clamp
  * to +-1), 3 'none' (copy).  normalize: the reference's flag (rescale only when it would otherwise clip, if 0).
- * scratch: vaura_audio_scratch_elems(n_clips) floats (strategies 1, 2).  'loudness' (torchaudio) is not built.   */
+ * scratch: vaura_audio_scratch_elems(n_clips) floats (strategies 1, 2).  'loudness': vaura_audio_loudness below.   */
 typedef enum vaura_audio_strategy { VAURA_AUDIO_CLIP = 0, VAURA_AUDIO_PEAK = 1, VAURA_AUDIO_RMS = 2, VAURA_AUDIO_NONE = 3 } vaura_audio_strategy;
 int vaura_audio_normalize(const float* wav, float* out, int n_clips, int64_t n_samples, int strategy, int normalize,
                           float peak_clip_headroom_db, float rms_headroom_db, float* scratch, vaura_stream_t s);
 size_t vaura_audio_scratch_elems(int n_clips);
+/* f3, strategy 'loudness' (utils/data_utils.py:453-458 -> normalize_loudness :347-387 -> _clip_wav :389-404): per clip, gain to
+ * -loudness_headroom_db LKFS (ITU-R BS.1770-4 integrated loudness as torchaudio 2.2.1's transforms.Loudness computes it — a
+ * third-party dependency absent from the reference tree: restated from the published algorithm, PARITY UNPINNED), optional tanh
+ * compressor, clamp to [-1, 1]; clips below energy_floor rms (reference: 2e-3) or shorter than one 400 ms gating block are only clamped.
+ * scratch: vaura_audio_loudness_scratch_elems(n_clips) floats; its first n_clips floats hold the applied gains afterwards. */
+int vaura_audio_loudness(const float* wav, float* out, int n_clips, int64_t n_samples, int sample_rate, float loudness_headroom_db,
+                         int compressor, float energy_floor, float* scratch, vaura_stream_t s);
+size_t vaura_audio_loudness_scratch_elems(int n_clips);
 
 /* -------------------------------------------------------------------------------------------
  * f2 (the step before the path) Segment-AVCLIP visual features: MotionFormer.forward

@@ -158,8 +158,6 @@ def test_scale_audio_and_wav_write(tmp_path):
     from scipy.io import wavfile
     sr, data = wavfile.read(str(tmp_path / "a.wav"))
     assert sr == 44100 and data.dtype == np.float32 and np.array_equal(data, out.numpy().reshape(-1))
-    with pytest.raises(NotImplementedError):
-        post.normalize_audio(wav.float(), strategy="loudness", sample_rate=44100)
 
 
 def test_sliding_window_caller_against_oracle_loop(model, tiny_sampler_sd):
@@ -274,3 +272,40 @@ def test_full_depth_generate_through_the_plugin_surface_matches_reference(golden
     assert_tokens_equal(parity_report, "full_topk250_cfg6_raw_B2_T220", "h2", "VAURAModel.generate() through the plugin surface, B=2 (4 rows)", tok,
                         _ref(g, "tokens"), g["margins"], g["threshold_rel_gap"])
     assert r["generated_audio"].shape == (2, 1, 220 * 512) and bool(torch.isfinite(r["generated_audio"]).all())
+
+
+def test_loudness_strategy_against_the_restated_meter():
+    """Row f3, strategy 'loudness' — scale_audio's own default (scripts/generate.py:443-447) —: vaura_audio_loudness against the CPU
+    restatement of ITU-R BS.1770-4 as torchaudio 2.2.1's transforms.Loudness computes it (oracle/post_oracle.py; the dependency is
+    absent: PARITY UNPINNED).  Per clip: the applied gain within 1e-3 relative, the waveform within 1e-4; a quiet clip (below the
+    2e-3 rms floor) and a clip shorter than one gating block are only clamped; the tanh compressor; 44.1 kHz (the codec's rate) and
+    scale_audio's 24 kHz default."""
+    import math
+    from oracle import post_oracle as po
+    from vaura_amd import post
+    for sr, n in ((44100, 112640), (24000, 24000 * 2 + 123)):
+        g = torch.Generator().manual_seed(sr)
+        t = torch.arange(n) / float(sr)
+        clips = [0.3 * torch.sin(2 * math.pi * 440.0 * t) + 0.05 * torch.randn(n, generator=g),
+                 0.8 * torch.sin(2 * math.pi * 90.0 * t) * torch.linspace(0, 1, n),              # bass-heavy, fading in: the gates matter
+                 1e-4 * torch.randn(n, generator=g),                                             # below the energy floor
+                 torch.cat([0.5 * torch.randn(n // 3, generator=g), torch.zeros(n - n // 3)])]   # two thirds silence
+        wav = torch.stack(clips)[:, None, :]
+        for comp in (False, True):
+            out = post.normalize_audio(wav.to(DEV), strategy="loudness", sample_rate=sr, loudness_headroom_db=14, loudness_compressor=comp)
+            gains = out.loudness_gains.cpu()
+            for i, c in enumerate(clips):
+                ref = po.normalize_loudness(c[None], sr, loudness_headroom_db=14, loudness_compressor=comp)
+                if i == 2:
+                    assert float(gains[i]) == 1.0
+                else:
+                    want = 10.0 ** ((-14 - po.loudness_lkfs(c[None], sr)) / 20.0)
+                    assert abs(float(gains[i]) / want - 1.0) < 1e-3, (sr, i, float(gains[i]), want)
+                assert float((out[i].cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(gains[i])), (sr, i, comp)
+    short = wav[:1, :, : sr // 4].to(DEV)                                                        # shorter than one 400 ms block
+    out = post.normalize_audio(short, strategy="loudness", sample_rate=sr)
+    assert float(out.loudness_gains[0]) == 1.0 and torch.equal(out.cpu(), short.cpu().clamp(-1, 1))
+    one = post.scale_audio(wav[0].to(DEV), sample_rate=44100)                                    # the reference's default strategy
+    assert one.shape == (1, wav.shape[-1]) and one.device.type == "cpu" and float(one.abs().max()) <= 1.0
+    with pytest.raises(AssertionError, match="requires sample rate"):
+        post.normalize_audio(wav.to(DEV), strategy="loudness")

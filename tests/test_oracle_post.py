@@ -24,3 +24,30 @@ def test_scale_audio_shape_and_dtype():
     out = post_oracle.scale_audio(wav, "clip", 44100)
     assert out.shape == (1, 64) and out.dtype == torch.float32 and out.device.type == "cpu"
     assert float(out.abs().max()) <= 10 ** (-6 / 20) + 1e-7
+
+
+def test_loudness_restatement_known_answers():
+    """'loudness' strategy (utils/data_utils.py:347-387 -> torchaudio.transforms.Loudness, third-party and absent: PARITY UNPINNED).
+    The restated ITU-R BS.1770-4 meter against the recommendation's own known answer: a 997 Hz sine of amplitude a reads
+    -3.01 + 20 log10(a) LKFS at any sample rate (K-weighting is 0 dB there by construction); gating drops silence; and
+    normalize_loudness lands on -headroom LKFS, leaves quiet / too-short clips alone, and always clamps."""
+    import math
+    from oracle import post_oracle as po
+    for sr in (44100, 48000, 24000):
+        t = torch.arange(sr * 3) / float(sr)
+        lk = po.loudness_lkfs(0.5 * torch.sin(2 * math.pi * 997.0 * t)[None], sr)
+        assert abs(lk - (-3.01 + 20 * math.log10(0.5))) < 0.1, (sr, lk)      # (the bilinear biquads are within 0.04-0.06 dB of 0 dB at 997 Hz)
+    sr = 44100
+    t = torch.arange(sr * 3) / float(sr)
+    tone = 0.25 * torch.sin(2 * math.pi * 997.0 * t)[None]
+    padded = torch.cat([tone, torch.zeros(1, sr * 3)], -1)                      # half silence: the gates must drop it
+    assert abs(po.loudness_lkfs(padded, sr) - po.loudness_lkfs(tone, sr)) < 0.5      # (the blocks straddling the edge pass the relative gate)
+    assert po.loudness_lkfs(padded, sr) > po.loudness_lkfs(tone, sr) - 3.0 + 2.0          # ungated it would read 3 dB lower
+    out = po.normalize_loudness(tone, sr, loudness_headroom_db=14)
+    assert abs(po.loudness_lkfs(out, sr) - (-14.0)) < 0.05
+    quiet = tone * 1e-3                                                          # rms 1.8e-4 < the 2e-3 floor: untouched
+    assert torch.equal(po.normalize_loudness(quiet, sr), quiet)
+    short = tone[:, : sr // 4]                                                    # shorter than one 400 ms block: untouched (then clamped)
+    assert torch.equal(po.normalize_loudness(short, sr), short.clamp(-1, 1))
+    loud = po.normalize_loudness(tone, sr, loudness_headroom_db=-6)              # would exceed full scale: clamped
+    assert float(loud.abs().max()) <= 1.0

@@ -111,6 +111,9 @@ SIGNATURES = {
     "vaura_audio_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
                                         C.c_void_p, C.c_void_p]),
     "vaura_audio_scratch_elems": (C.c_size_t, [C.c_int]),
+    "vaura_audio_loudness": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_int, C.c_float, C.c_void_p,
+                                       C.c_void_p]),
+    "vaura_audio_loudness_scratch_elems": (C.c_size_t, [C.c_int]),
     "vaura_dac_encode": (C.c_int, [C.POINTER(CodecEncoder), C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vaura_dac_encode_workspace_elems": (C.c_size_t, [C.POINTER(CodecEncoder), C.c_int, C.c_int64]),
     "vaura_avclip_forward": (C.c_int, [C.POINTER(Vit), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -2,9 +2,10 @@
 ``save_results`` (/root/reference/scripts/generate.py:392-461, utils/data_utils.py:407-466).
 
 ``normalize_audio`` / ``scale_audio`` keep the reference's names, keywords and return conventions; the arithmetic
-runs in libvaura_hip.so (``vaura_audio_normalize``) on the device tensor the codec produced — there is no CPU
-path.  The 'loudness' strategy needs torchaudio.transforms.Loudness (third-party) and is not built; the mp4 mux
-(PyAV) is host I/O outside this package.
+runs in libvaura_hip.so (``vaura_audio_normalize`` / ``vaura_audio_loudness``) on the device tensor the codec produced — there is no
+CPU path.  The 'loudness' strategy (``scale_audio``'s own default) is ITU-R BS.1770-4 integrated loudness as the reference's dependency
+torchaudio 2.2.1 computes it (``transforms.Loudness``) — third-party and absent here, so it is restated from the published algorithm
+and its parity is UNPINNED, like DAC's; the mp4 mux (PyAV) is host I/O outside this package.
 """
 from __future__ import annotations
 
@@ -22,7 +23,8 @@ def normalize_audio(wav: torch.Tensor, normalize: bool = True, strategy: str = "
                     log_clipping: bool = False, sample_rate: Optional[int] = None, stem_name: Optional[str] = None) -> torch.Tensor:
     """wav (C=1, N) or (B, 1, N) fp32 on a HIP device -> same shape; statistics are per clip (leading dims)."""
     if strategy == "loudness":
-        raise NotImplementedError("'loudness' needs torchaudio.transforms.Loudness (third-party); use clip | peak | rms")
+        assert sample_rate is not None, "Loudness normalization requires sample rate."        # data_utils.py:454
+        return _normalize_loudness(wav, int(sample_rate), float(loudness_headroom_db), bool(loudness_compressor))
     if strategy not in _STRATEGIES:
         raise AssertionError(f"Unexpected strategy: '{strategy}'")
     if not wav.is_cuda:
@@ -39,6 +41,26 @@ def normalize_audio(wav: torch.Tensor, normalize: bool = True, strategy: str = "
                                           L.current_stream()), "vaura_audio_normalize")
     if strategy in ("", "none") :
         assert bool(out.abs().max() < 1)        # data_utils.py:460
+    return out
+
+
+def _normalize_loudness(wav: torch.Tensor, sample_rate: int, loudness_headroom_db: float, loudness_compressor: bool,
+                        energy_floor: float = 2e-3) -> torch.Tensor:
+    """normalize_loudness + _clip_wav (utils/data_utils.py:347-404): gain every clip to -loudness_headroom_db LKFS, optional tanh
+    compressor, clamp to [-1, 1]; a clip below ``energy_floor`` rms or shorter than one 400 ms gating block is only clamped (the
+    reference returns it unchanged from normalize_loudness — its unfold raises on the short one — and then clips)."""
+    if not wav.is_cuda:
+        raise L.VauraHipError("normalize_audio runs on the HIP device that holds the decoded waveform; there is no CPU path")
+    if wav.dim() >= 2 and wav.shape[-2] != 1:
+        raise NotImplementedError("multi-channel audio: the codec is mono (dac_8kbps_wrapper.yaml)")
+    x = wav.to(torch.float32).contiguous()
+    n = x.shape[-1]
+    clips = x.numel() // n
+    out = torch.empty_like(x)
+    scratch = torch.empty(L.lib().vaura_audio_loudness_scratch_elems(clips), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vaura_audio_loudness(L.ptr(x), L.ptr(out), clips, n, sample_rate, loudness_headroom_db, int(loudness_compressor),
+                                         float(energy_floor), L.ptr(scratch), L.current_stream()), "vaura_audio_loudness")
+    out.loudness_gains = scratch[:clips]          # the gains that were applied (tests; 1 = left alone)
     return out
 
 
