@@ -309,3 +309,33 @@ def test_loudness_strategy_against_the_restated_meter():
     assert one.shape == (1, wav.shape[-1]) and one.device.type == "cpu" and float(one.abs().max()) <= 1.0
     with pytest.raises(AssertionError, match="requires sample rate"):
         post.normalize_audio(wav.to(DEV), strategy="loudness")
+
+
+def test_sampler_forward_survives_activations_beyond_the_fp16_plane_range():
+    """The reference HOST driving this sampler plugin (sampler(tgt, memory) per step, vaura_model.py:798-808) gets the same range safety
+    as generate(): a checkpoint whose activations overflow the fp16 planes (norm gains and token projection x 3000) makes forward()
+    switch to the exact-fp32 twin engine — whole prefix recomputed once, later calls served from the twin's cache — and the logits
+    equal the oracle's on that checkpoint."""
+    from oracle.decoder_oracle import DecoderOracle
+    from vaura_amd.sampler import Transformer
+    cfg = synth.tiny_sampler(2)
+    sd = dict(synth.sampler_state_dict(cfg, seed=81))
+    for k in list(sd):
+        if k.endswith("attention_norm.weight") or k.endswith("ffn_norm.weight") or k == "norm.weight":
+            sd[k] = sd[k] * 3000.0
+        if "tok_embeddings" in k and k.endswith("out_proj.weight_g"):
+            sd[k] = sd[k] * 3000.0
+    s = Transformer(**cfg.yaml_params())
+    s.load_state_dict(sd, strict=True)
+    s.audio_tokens_per_video_frame = 7
+    s = s.to(DEV)
+    feats = synth.video_features(2, seed=82)
+    idx = torch.randint(0, 1025, (2, 9, 6), generator=torch.Generator().manual_seed(83))
+    ref = DecoderOracle(sd, cfg.num_layers, cfg.nhead).forward_full(idx, feats)
+    for L_ in (4, 5, 6):                                           # the host grows the prefix call by call
+        lg, _, _ = s(tgt=idx[..., :L_].to(DEV), memory=feats.to(DEV))
+        assert bool(torch.isfinite(lg).all())
+        err = float((lg.cpu() - ref[:, :, :L_]).abs().max())
+        assert err < 3e-5 * max(1.0, float(ref.abs().max())), (L_, err)
+    eng = s.engine()
+    assert eng.wdtype in ("h1", "h2") and eng.range_fallbacks == 1 and eng._forward_on_twin

@@ -495,6 +495,8 @@ class DecoderEngine:
         cap = c.block_size                                   # positions the model supports (scripts/generate.py:221-224)
         if Lq > cap:
             raise L.VauraHipError(f"sequence of {Lq} positions exceeds block_size {cap}")
+        if getattr(self, "_forward_on_twin", False):         # an earlier call overflowed the fp16 planes: this engine's forward() stays on fp32
+            return self._range_twin.forward_cached(idx, feats, tokens_per_frame)
         idx = idx.to(self.dev)
         feats = feats.to(self.dev, torch.float32)
         st = getattr(self, "_fc", None)
@@ -519,7 +521,19 @@ class DecoderEngine:
             self.cached_forward_steps = getattr(self, "cached_forward_steps", 0) + 1
         st["idx"][:, :, n0:Lq] = idx[:, :, n0:Lq]
         st["n"] = Lq
-        self.check_status()                  # the caller consumes these logits on the host side anyway (one synchronisation)
+        try:
+            self.check_status()              # the caller consumes these logits on the host side anyway (one synchronisation)
+        except L.VauraHipError as e:
+            # range safety for the reference host's call pattern too (see generate_codes_checked): non-finite logits = an activation left
+            # the fp16-plane range -> this and every later forward() of the engine runs on the exact-fp32 twin (whole prefix recomputed once)
+            if getattr(e, "status", 0) != 1 or self.wdtype == "f32" or self._twin_sd is None:
+                raise
+            if self._range_twin is None:
+                self._range_twin = DecoderEngine(self.cfg, self._twin_sd, self.dev, wdtype="f32", range_fallback=False)
+            self.range_fallbacks += 1
+            self._forward_on_twin = True
+            self._fc = None
+            return self._range_twin.forward_cached(idx, feats, tokens_per_frame)
         return st["logits"][:, :, :Lq].clone()      # a copy: the cache must survive in-place edits by the caller
 
     # ------------------------------------------------------------------ op-level access (tests)
