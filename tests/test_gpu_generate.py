@@ -895,6 +895,17 @@ def test_range_guard_detects_overflow_and_the_checked_call_reruns_it_in_fp32():
     e2.check_status()                                   # nothing left behind
     # a checkpoint that stays in range never takes the detour
     assert torch.equal(eng.generate_codes_checked(feats, 12, cfg_scale=6.0), eng.generate_codes(feats, 12, cfg_scale=6.0)) and eng.range_fallbacks == 0
+    # LARGE NORM GAINS ALONE do not leave the planes' range: the engine folds a power of two out of every RMSNorm gain into the matrix
+    # that consumes it (engine.fold_gain: exact on both sides), so the planes hold (g 2^-E) * h.  attention_norm gains x 3000 (the residual
+    # stream then grows to ~1e3..1e4 and h * g to ~1e7) decode on the DEFAULT arithmetic, token-exact, without the fp32 detour
+    ga = dict(sd)
+    for k in sd:
+        if k.endswith("attention_norm.weight"):
+            ga[k] = sd[k] * 3000.0
+    e4 = DecoderEngine(cfg, ga, DEV, wdtype="h2")
+    ref4 = go.generate(DecoderOracle(ga, cfg.num_layers, cfg.nhead), feats.cpu(), 12, mode="cached", cfg_scale=6.0)
+    got4 = e4.generate_codes_checked(feats, 12, cfg_scale=6.0).cpu()
+    assert e4.range_fallbacks == 0 and torch.equal(got4, ref4)
 
 
 @pytest.mark.parametrize("precision", ["f16pair", "f16", "f16pair_w8"])

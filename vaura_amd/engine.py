@@ -85,6 +85,15 @@ def h1_lossless(w: torch.Tensor) -> bool:
     return bool((err <= tol).all())
 
 
+def fold_gain(g: torch.Tensor):
+    """(g 2^-E, 2^E) with E = max(0, ceil(log2 max|g|)): the RMSNorm gain as the planes carry it and the factor its consuming matrix
+    takes instead (both exact: powers of two)."""
+    g = g.detach().float()
+    m = float(g.abs().max())
+    e = max(0, math.ceil(math.log2(m))) if m > 0 and math.isfinite(m) else 0
+    return g * (2.0 ** -e), 2.0 ** e
+
+
 def streamed_matrices(sd: Dict[str, torch.Tensor]):
     """The matrices the decode loop streams every step (98 % of the bytes)."""
     from .synth import is_streamed_weight
@@ -164,16 +173,23 @@ class DecoderEngine:
                 w1 = sd[p + "feed_forward.w1.weight"].float()
                 w3 = sd[p + "feed_forward.w3.weight"].float()
                 w13 = torch.stack([w1.view(F // 16, 16, D), w3.view(F // 16, 16, D)], dim=1).reshape(2 * F, D)
-                lw[l].wqkv = L.ptr(self._pack(sd[p + "attention.wqkv.weight"], self.wd))
+                # Norm gains leave the planes (range): rmsnorm's gain g multiplies the residual stream BEFORE it is split into fp16 planes
+                # (the producer's epilogue), so a large gain eats the planes' range.  Fold a power of two out of it: the planes hold
+                # (g 2^-E) * h with max |g 2^-E| <= 1 and the consuming matrix is stored as W 2^E — exact on both sides (its power-of-two
+                # row scales absorb it; W (g * x) == (W 2^E) ((g 2^-E) * x) bit for bit), E = 0 for gains <= 1 (every golden).
+                ga, ea = fold_gain(sd[p + "attention_norm.weight"])
+                gf, ef = fold_gain(sd[p + "ffn_norm.weight"])
+                lw[l].wqkv = L.ptr(self._pack(sd[p + "attention.wqkv.weight"].float() * ea, self.wd))
                 lw[l].wo = L.ptr(self._pack(sd[p + "attention.wo.weight"], self.wd))
-                lw[l].w13 = L.ptr(self._pack(w13, self.wd))
+                lw[l].w13 = L.ptr(self._pack(w13 * ef, self.wd))
                 lw[l].w2 = L.ptr(self._pack(sd[p + "feed_forward.w2.weight"], self.wd))
-                lw[l].attn_norm = L.ptr(self._dev(sd[p + "attention_norm.weight"]))
-                lw[l].ffn_norm = L.ptr(self._dev(sd[p + "ffn_norm.weight"]))
+                lw[l].attn_norm = L.ptr(self._dev(ga))
+                lw[l].ffn_norm = L.ptr(self._dev(gf))
             self.layers = lw
-            heads = torch.cat([sd[f"lm_heads.{k}.weight"].float() for k in range(K)], dim=0)
+            gn, en = fold_gain(sd["norm.weight"])
+            heads = torch.cat([sd[f"lm_heads.{k}.weight"].float() for k in range(K)], dim=0) * en
             self.heads = self._pack(heads, head_wd)
-            self.final_norm = self._dev(sd["norm.weight"])
+            self.final_norm = self._dev(gn)
             self.fc1 = self._pack(sd["cls_embeddings.projection.fc1.weight"], L.W_F32)
             self.fc2 = self._pack(sd["cls_embeddings.projection.fc2.weight"], L.W_F32)
             self.uncond = self._dev(sd["cls_embeddings.uncond_embedding"])
