@@ -115,6 +115,13 @@ typedef struct vaura_decoder {
   int32_t n_cond_tokens;   /* Tv                                                   */
   int32_t prefill_positions; /* > 0: every ws_* buffer holds this many positions' worth of row blocks, so a
                                 prompt is teacher-forced in chunks of that many positions per pass (bf16 path) */
+  int32_t plane_shift;     /* S in [0, 24], pair path only (0 otherwise): the two activation plane sets that have no RMSNorm in front of
+                              them — the attention output (ws_attn_split) and silu(w1 x) * (w3 x) (ws_ffn_split) — are stored times
+                              2^-S, and the caller packed wo and w2 times 2^S (vaura_pack_weight of the scaled matrix: the row scales
+                              are powers of two, so the tiles are the same bits).  Exact in both directions unless a plane value drops
+                              into fp16's subnormals; buys 2^S of head-room before |activation| > 65504 raises
+                              VAURA_STATUS_NONFINITE_LOGITS.  0 = the layout every parity number was taken on */
+  int32_t _pad_plane_shift;
 
   const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
   const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles (VAURA_W_H1 when wdtype is FP8) llama.py:356-361 */

@@ -908,6 +908,81 @@ def test_range_guard_detects_overflow_and_the_checked_call_reruns_it_in_fp32():
     assert e4.range_fallbacks == 0 and torch.equal(got4, ref4)
 
 
+def test_plane_shift_moves_the_fp16_plane_range_up_at_the_same_speed(golden, full_sampler_sd_raw, parity_report):
+    """DecoderEngine(plane_shift=S): every activation plane set is stored times 2^-S, its consuming matrix times 2^S (exact both ways
+    while the lo plane stays out of fp16's subnormals), so the planes end at 65504 * 2^S.
+      * the x3000 checkpoint of the range-guard test (SwiGLU outputs ~1e7), which S = 0 can only decode through the exact-fp32 twin (and
+        S = 8 too: tools/plane_shift_probe.py), decodes on the h2 kernels with S = 12: no status bit, no fallback, tokens equal to the
+        oracle's — greedy and top-k sampled;
+      * a checkpoint in range decodes to the same tokens at S = 4 as at S = 0 in every plane storage, one and two row blocks, with a
+        teacher-forced prompt (the GEMM-tiled prefill stores the same planes), logits within 2e-5 of S = 0's;
+      * full depth: the headline golden (reference generate(), cfg 6 / top-k 250, 16 rows) token for token at S = 4;
+      * S is refused on the exact-fp32 step and outside 0..24."""
+    from vaura_amd import _lib as L
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    cfg = synth.tiny_sampler(2)
+    sd = dict(synth.sampler_state_dict(cfg, seed=81))
+    feats = synth.video_features(2, seed=82).to(DEV)
+    big = dict(sd)
+    for k in sd:
+        if k.endswith("attention_norm.weight") or k.endswith("ffn_norm.weight") or k == "norm.weight":
+            big[k] = sd[k] * 3000.0
+        if "tok_embeddings" in k and k.endswith("out_proj.weight_g"):
+            big[k] = sd[k] * 3000.0
+    dec = DecoderOracle(big, cfg.num_layers, cfg.nhead)
+    e8 = DecoderEngine(cfg, big, DEV, wdtype="h2", plane_shift=12)
+    ref = go.generate(dec, feats.cpu(), 12, mode="cached", cfg_scale=6.0)
+    got = e8.generate_codes_checked(feats, 12, cfg_scale=6.0).cpu()
+    assert e8.range_fallbacks == 0 and torch.equal(got, ref)
+    nz = synth.exp_noise(12 + 9 - 1, 18, 1024, 83)
+    refs = go.generate(dec, feats.cpu(), 12, mode="cached", cfg_scale=6.0, use_sampling=True, top_k=128, noise=nz)
+    gots = e8.generate_codes_checked(feats, 12, cfg_scale=6.0, use_sampling=True, top_k=128, noise=nz).cpu()
+    assert e8.range_fallbacks == 0 and torch.equal(gots, refs)
+    e0 = DecoderEngine(cfg, big, DEV, wdtype="h2", range_fallback=False)     # ... and S = 0 does overflow on it
+    e0.generate_codes(feats, 12, cfg_scale=6.0)
+    with pytest.raises(L.VauraHipError, match="non-finite logits"):
+        e0.check_status()
+    del e8, e0
+    prompt = torch.randint(0, 1024, (10, 9, 40), generator=torch.Generator().manual_seed(5)).to(DEV)
+    idx = torch.randint(0, 1024, (3, 9, 24), generator=torch.Generator().manual_seed(6)).to(DEV)
+    for wd in ("h2", "h1", "fp8"):
+        a = DecoderEngine(cfg, sd, DEV, wdtype=wd)
+        b = DecoderEngine(cfg, sd, DEV, wdtype=wd, plane_shift=4)
+        for B in (2, 10):                                                   # 4 rows; 20 rows = two row blocks per weight pass
+            f = synth.video_features(B, seed=90 + B).to(DEV)
+            nzb = synth.exp_noise(30 + 9 - 1, 9 * B, 1024, 91)
+            kw = dict(cfg_scale=6.0, use_sampling=True, top_k=250, noise=nzb)
+            assert torch.equal(a.generate_codes(f, 30, **kw), b.generate_codes(f, 30, **kw)), (wd, B)
+            assert torch.equal(a.generate_codes(f, 30, cfg_scale=6.0), b.generate_codes(f, 30, cfg_scale=6.0)), (wd, B)
+        f = synth.video_features(10, seed=93).to(DEV)
+        assert torch.equal(a.generate_codes(f, 60, prompt=prompt, cfg_scale=6.0), b.generate_codes(f, 60, prompt=prompt, cfg_scale=6.0)), wd
+        la = a.logits_all_positions(idx, synth.video_features(3, seed=94).to(DEV))
+        lb = b.logits_all_positions(idx, synth.video_features(3, seed=94).to(DEV))
+        err = float((la - lb).abs().max())
+        print(f"{wd}: logits at plane_shift 4 against 0, max-abs {err:.2e}")
+        assert err < 2e-5
+        a.check_status(), b.check_status()
+        del a, b
+    with pytest.raises(L.VauraHipError, match="plane_shift"):
+        DecoderEngine(cfg, sd, DEV, wdtype="f32", plane_shift=4)
+    with pytest.raises(L.VauraHipError, match="plane_shift"):
+        DecoderEngine(cfg, sd, DEV, wdtype="h2", plane_shift=25)
+    torch.cuda.empty_cache()
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV, plane_shift=4)
+    assert eng.wdtype == "h2"
+    gs = golden("full_topk250_cfg6_raw_B2_T220.npz")
+    f8 = synth.video_features(8, seed=int(gs["feat_seed"])).to(DEV)
+    nz8 = torch.cat([synth.exp_noise(228, 18, 1024, int(gs["noise_seed"])), synth.exp_noise(228, 54, 1024, 4321)], dim=1)
+    tok = eng.generate_codes(f8, 220, use_sampling=True, temp=1.0, top_k=int(gs["top_k"]), cfg_scale=float(gs["cfg_scale"]), noise=nz8).cpu()
+    eng.check_status()
+    assert_tokens_equal(parity_report, "full_topk250_cfg6_raw_B2_T220", "h2 plane_shift 4",
+                        "headline golden with every plane set stored x 2^-4 (16x the fp16 range)", tok[:2], _ref(gs, "tokens"),
+                        gs["margins"], gs["threshold_rel_gap"])
+    del eng
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("precision", ["f16pair", "f16", "f16pair_w8"])
 def test_one_launch_residual_units_are_bit_identical_to_two_launches(precision):
     """csrc/dac.hip: a residual unit (7-tap dilated conv -> Snake -> 1 x 1 conv -> + residual) of the last two decoder blocks (C = 192:

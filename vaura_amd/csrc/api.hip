@@ -23,6 +23,7 @@ static int check_decoder(const vaura_decoder* d) {
   if (m.cond_dim + m.tok_dim != m.d_model) return VAURA_ERR_SHAPE;
   if (d->rows != d->batch && d->rows != 2 * d->batch) return VAURA_ERR_ARG;
   if (d->seq_len > d->max_len || d->batch <= 0) return VAURA_ERR_ARG;
+  if (d->plane_shift < 0 || d->plane_shift > 24 || (d->plane_shift && !d->ws_h_split)) return VAURA_ERR_ARG;
   return 0;
 }
 
@@ -64,6 +65,9 @@ static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const
   a.rows = n_pos == 1 ? d->rows : a.R * 16;
   a.N = N; a.eps = d->dims.eps;
   a.k_total = d->dims.d_model;
+  // plane_shift S: the two plane sets without a norm behind them (SwiGLU output, attention output) are stored times 2^-S, their
+  // consumers' matrices (w2, wo) were packed times 2^S by the caller — exact both ways, and 2^S more head-room in the fp16 planes
+  a.out_scale = (outp && outp == d->ws_ffn_split) ? ldexpf(1.f, -d->plane_shift) : 1.f;
   return a;
 }
 
@@ -121,13 +125,14 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // EXPERIMENT (debug flag bit 12): attention + wo as one launch too (csrc/attention.hip attn_wo_kernel; single-round-trip attention
   // only: cache <= 256 positions, 16 heads).  Bit-identical and measured SLOWER than the two launches (13.7 us against 7.05 + 0.7 +
   // 4.8: the loop +3.3 % two planes / +3.8 % one): wo's stream is 1.5 us, nothing a run-ahead could hide pays for the hand-off.
-  const bool attn_wo = mlp_engine && rows <= 16 && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u);
+  const bool attn_wo = mlp_engine && rows <= 16 && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u) &&
+                       d->plane_shift == 0;   // the experiments' own attention epilogues store unscaled planes
   // EXPERIMENT (second flag word, bit 2): that layer's ATTENTION as the launch's fourth phase too (16 heads of 96, single-round-trip
   // attention: cache <= 256, one row block; csrc/mlp_engine.h ATT instances).  Bit-identical, and measured SLOWER than the separate
   // launch (round 5: the loop 204.2 -> 207.8 ms two planes, 163.4 -> 176.4 ms one): the serial chain behind the qkv products — drain,
   // flag, poll, the q / k / v quads' round trip, two barriers of softmax arithmetic — is as long inside the launch as the kernel
   // boundary it replaces, and the K / V rows were already hidden under that chain in the separate kernel.  Off by default.
-  const bool fuse_attn = fuse_qkv && rows <= 16 && H == 16 && hd == 96 && d->max_len <= 256 && d->ws_attn_split && !attn_wo &&
+  const bool fuse_attn = fuse_qkv && rows <= 16 && H == 16 && hd == 96 && d->max_len <= 256 && d->ws_attn_split && !attn_wo && d->plane_shift == 0 &&
                          !(va_debug_flags_get() & 8u) && (va_debug_flags2_get() & 4u);
   bool attn_done = false;                    // layer l's attention was computed by layer l - 1's engine launch
   for (int l = 0; l < m.n_layer; ++l) {
@@ -158,7 +163,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s,
-                             d->ws_sync ? d->ws_sync + 512 : nullptr);      // words 512 .. 767: arrival counts of the range-split attention (the MLP / tail engines use 0 .. 511; the attention + wo experiment uses 512 .. only with caches <= 256, where nothing is split)
+                             d->ws_sync ? d->ws_sync + 512 : nullptr, ldexpf(1.f, -d->plane_shift));      // words 512 .. 767: arrival counts of the range-split attention (the MLP / tail engines use 0 .. 511; the attention + wo experiment uses 512 .. only with caches <= 256, where nothing is split)
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     }

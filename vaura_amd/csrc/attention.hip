@@ -24,7 +24,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     float* __restrict__ vcache,
     float* __restrict__ out,         // packed rows (rows x D)
     uint16_t* __restrict__ outp,     // optional split rows (rows x D)
-    int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host, int prefill_rows16) {
+    int n_head, int max_len, const int32_t* __restrict__ pos_dev, int pos_host, int prefill_rows16,
+    float pscale) {                  // the planes hold out * pscale (a power of two; 1 = the product default: engine plane_shift)
   constexpr int QUADS = HD / 4;          // 24
   constexpr int QPL = QUADS / 8;         // float4 per lane per position = 3
   static_assert(QUADS % 8 == 0, "head_dim must be a multiple of 32");
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
     for (int i = 1; i < 4; ++i) o += reinterpret_cast<const f32x4*>(red + i * HD)[tid];
     if (!prefill) o += reinterpret_cast<const f32x4*>(sv)[tid] * (sc[pos] * inv);
     va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(vrow, (h * HD) / 4 + tid, D), o);
-    if (outp) store_split4(outp, vrow, h * HD + 4 * tid, D, o);
+    if (outp) store_split4(outp, vrow, h * HD + 4 * tid, D, o * pscale);
   }
 }
 
@@ -201,7 +202,8 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
                                                   const float* __restrict__ rope,
                                                   float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ out,
                                                   uint16_t* __restrict__ outp, int n_head, int pos, f32x4* sqkv,
-                                                  f32x4 (*wacc)[HD / 4], float* wm, float* wl, HOOK after_requests = HOOK()) {
+                                                  f32x4 (*wacc)[HD / 4], float* wm, float* wl, float pscale = 1.f,
+                                                  HOOK after_requests = HOOK()) {
   constexpr int QUADS = HD / 4;   // 24
   constexpr int QPL = QUADS / 8;  // 3
   constexpr int NW = ATT1_THREADS / 64;
@@ -351,7 +353,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
     }
     o *= 1.0f / denom;
     va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(row, (h * HD) / 4 + tid, D), o);
-    if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
+    if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o * pscale);
   }
 #ifdef VAURA_STAMPS
   VA_WAIT_VM(0);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
     // argument order = what the dependent chain needs first (the leading 14 dwords are preloaded into SGPRs)
     const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
     const float* __restrict__ qkv2, const float* __restrict__ rope, int n_head, int max_len, int pos_host,
-    float* __restrict__ out, uint16_t* __restrict__ outp) {
+    float* __restrict__ out, uint16_t* __restrict__ outp, float pscale) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];   // rotated q | rotated k | v of the new position | scratch
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -374,11 +376,11 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
   float* kc = kcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
   float* vc = vcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
   switch ((pos + 63) >> 6) {
-    case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
-    default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl); break;
+    case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
   }
 }
 
@@ -449,11 +451,11 @@ __global__ __launch_bounds__(ATT1_THREADS) void attn_wo_kernel(
     hook();                // a row slot without a sequence: no attention, but this workgroup still owns a wo tile and a flag
   } else {
     switch ((pos + 63) >> 6) {
-      case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, hook); break;
-      case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, hook); break;
-      case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, hook); break;
-      case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, hook); break;
-      default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, hook); break;
+      case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, 1.f, hook); break;
+      case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, 1.f, hook); break;
+      case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, 1.f, hook); break;
+      case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, 1.f, hook); break;
+      default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, 1.f, hook); break;
     }
   }
   // publish: threads 0..23 (wave 0) stored this (row, head)'s output and planes (write-through); drained, then the flag
@@ -698,7 +700,7 @@ __device__ __forceinline__ void attention_split_body(const float* __restrict__ q
 // merge of the n_split (<= 8) partials of one (row, head) by thread tid < HD / 4.  FRESH: the partials were written by other workgroups
 // of the SAME launch (write-through): read them past the caches (sc1) — all of them requested before the one wait.
 template <int HD, bool FRESH>
-__device__ __forceinline__ void attention_combine(const float* __restrict__ pp, float* __restrict__ out, uint16_t* __restrict__ outp,
+__device__ __forceinline__ void attention_combine(float pscale, const float* __restrict__ pp, float* __restrict__ out, uint16_t* __restrict__ outp,
                                                   int n_head, int n_split, int h, int row, int tid) {
   float Mz[8], dz[8];
   f32x4 oz[8];
@@ -737,14 +739,14 @@ __device__ __forceinline__ void attention_combine(const float* __restrict__ pp, 
   o *= 1.0f / denom;
   const int D = n_head * HD;
   va_st16(reinterpret_cast<f32x4*>(out) + packed_quad(row, (h * HD) / 4 + tid, D), o);
-  if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o);
+  if (outp) store_split4(outp, row, h * HD + 4 * tid, D, o * pscale);
 }
 
 template <int HD>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
     const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
     const float* __restrict__ qkv2, const float* __restrict__ rope, int n_head, int max_len, int pos_host,
-    float* __restrict__ part, uint32_t* __restrict__ arrivals, float* __restrict__ out, uint16_t* __restrict__ outp) {
+    float* __restrict__ part, uint32_t* __restrict__ arrivals, float* __restrict__ out, uint16_t* __restrict__ outp, float pscale) {
   constexpr int QUADS = HD / 4;
   __shared__ f32x4 sqkv[3 * QUADS + 64];
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
@@ -781,17 +783,17 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_split_kernel(
     }
     __syncthreads();
     if (s_last && threadIdx.x < QUADS)
-      attention_combine<HD, true>(part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD), out, outp, n_head, n_split, h, row, threadIdx.x);
+      attention_combine<HD, true>(pscale, part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD), out, outp, n_head, n_split, h, row, threadIdx.x);
   }
 }
 
 template <int HD>
 __global__ __launch_bounds__(64) void attention_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                               uint16_t* __restrict__ outp, int n_head, int n_split) {
+                                                               uint16_t* __restrict__ outp, int n_head, int n_split, float pscale) {
   constexpr int QUADS = HD / 4;
   const int h = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
   if (tid >= QUADS) return;
-  attention_combine<HD, false>(part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD), out, outp, n_head, n_split, h, row, tid);
+  attention_combine<HD, false>(pscale, part + ((size_t)row * n_head + h) * n_split * ATT_PART_STRIDE(HD), out, outp, n_head, n_split, h, row, tid);
 }
 
 // rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
@@ -840,7 +842,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ kcache,
                                                                 const float* __restrict__ vcache, float* __restrict__ out,
                                                                 uint16_t* __restrict__ outp, int n_head, int max_len, int p0, int n_pos,
-                                                                int rows16) {
+                                                                int rows16, float pscale) {
   static_assert(HD == 96, "24 k-steps of 4");
   constexpr int KS = HD / 4;        // 24 MFMA steps per S^T tile
   constexpr int DT = HD / 16;       // 6 output column tiles
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     const f32x4 v4 = *reinterpret_cast<const f32x4*>(os + qq * APF_STRIDE + 4 * cq);
     const int vrow = (q0 + qq) * rows16 + row;
     reinterpret_cast<f32x4*>(out)[packed_quad(vrow, (h * HD) / 4 + cq, D)] = v4;
-    if (outp) store_split4(outp, vrow, h * HD + 4 * cq, D, v4);
+    if (outp) store_split4(outp, vrow, h * HD + 4 * cq, D, v4 * pscale);
   }
 }
 
@@ -967,7 +969,7 @@ int va_attention_splits(int rows, int n_head, int max_len) {
 
 int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
-                        float* part, int n_split, hipStream_t s, uint32_t* arrivals) {
+                        float* part, int n_split, hipStream_t s, uint32_t* arrivals, float pscale) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
   if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
@@ -975,18 +977,18 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
     // arrivals (rows * n_head zeroed words, e.g. the decoder's ws_sync + 512): the last split to arrive merges; debug flag bit 19: own launch
     if (va_debug_flags_get() & 0x80000u) arrivals = nullptr;
     VA_LAUNCH(attention_split_kernel<96>, dim3(n_head, rows, n_split), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2,
-              rope, n_head, max_len, pos_host, part, arrivals, out, outp);
-    if (!arrivals) VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split);
+              rope, n_head, max_len, pos_host, part, arrivals, out, outp, pscale);
+    if (!arrivals) VA_LAUNCH(attention_combine_kernel<96>, dim3(n_head, rows), dim3(64), 0, s, (const float*)part, out, outp, n_head, n_split, pscale);
     return 0;
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
     VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
-              n_head, max_len, pos_host, out, outp);
+              n_head, max_len, pos_host, out, outp, pscale);
     return 0;
   }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
   VA_LAUNCH(attention_step_kernel<96>, dim3(n_head, rows), dim3(ATT_THREADS), smem, s, qkv, qkv2, rope, kc, vc, out, outp,
-            n_head, max_len, pos_dev, pos_host, 0);
+            n_head, max_len, pos_dev, pos_host, 0, pscale);
   return 0;
 }
 
@@ -1027,13 +1029,13 @@ int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n
   if (!(va_debug_flags & 16u)) {
     VA_LAUNCH(attention_prefill_kernel<96>, dim3(H, d->rows, (n_pos + APF_Q - 1) / APF_Q), dim3(256), 0, s, (const float*)d->ws_qkv,
               (const float*)(d->kcache + layer * kv_layer), (const float*)(d->vcache + layer * kv_layer), d->ws_attn, d->ws_attn_split, H,
-              d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16);
+              d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16, ldexpf(1.f, -d->plane_shift));
     return 0;
   }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + d->max_len + 4);
   VA_LAUNCH(attention_step_kernel<96>, dim3(H, d->rows, n_pos), dim3(ATT_THREADS), smem, s, d->ws_qkv, (const float*)nullptr, d->rope,
             d->kcache + layer * kv_layer, d->vcache + layer * kv_layer, d->ws_attn, d->ws_attn_split, H, d->max_len, nullptr,
-            p0, (d->rows + 15) / 16 * 16);
+            p0, (d->rows + 15) / 16 * 16, ldexpf(1.f, -d->plane_shift));
   return 0;
 }
 

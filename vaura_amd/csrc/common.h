@@ -183,7 +183,7 @@ int va_launch_gemv(const void* w, int wdtype, const float* x, const float* gain,
 int va_attention_splits(int rows, int n_head, int max_len);   // workgroups per (row, head) for this shape
 int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
-                        float* part, int n_split, hipStream_t s, uint32_t* arrivals = nullptr);
+                        float* part, int n_split, hipStream_t s, uint32_t* arrivals = nullptr, float pscale = 1.f);
 struct Gemv3Args;
 unsigned va_debug_flags2_get();  // vaura_set_debug_flags2: the second word
 unsigned va_debug_flags_get();   // vaura_set_debug_flags (gemv3.hip): kernel-variant switches for A/B measurements

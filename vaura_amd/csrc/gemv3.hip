@@ -470,7 +470,7 @@ int vaura_gemv_pair(const void* w, int wdtype, const uint16_t* x_split, const fl
   a.wq = wdtype == VAURA_W_FP8 ? 1 : (wdtype == VAURA_W_H2 ? 2 : 0); a.wscale = nullptr; a.out2 = out_khalf2;
   a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
   a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
-  a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K;
+  a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K; a.out_scale = 1.f;
   if (epilogue == E3_RESID && !residual) return VAURA_ERR_ARG;
   return va_launch_gemv3(a, N, K, epilogue, ss_in != nullptr, as_stream(s));
 }

@@ -51,6 +51,7 @@ struct Gemv3Args {
   int rows, R, N;
   float eps;
   int k_total;            // K of the normalised vector (mean denominator)
+  float out_scale;        // E3_SWIGLU: the planes hold silu(w1 x) * (w3 x) * out_scale (a power of two, 1 by default: vaura_decoder.plane_shift)
 };
 
 __device__ __forceinline__ size_t split_index16(int rb, int plane, int octet, int row16, int C) {
@@ -157,7 +158,7 @@ __device__ __forceinline__ void gemv3_epilogue(const Gemv3Args& a, int rb, int t
       for (int r = 0; r < 4; ++r) o[r] = silu3_f(v[2 * pr][r]) * v[2 * pr + 1][r];
       const int tile = tile0 / 2 + pr;   // tile of the ffn dimension
       if (a.out) va_st16(reinterpret_cast<f32x4*>(a.out) + ((size_t)rb * (a.N / 4) + (size_t)tile * 4) * 16 + lane, o);
-      if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o);
+      if (a.outp) store_split4(a.outp, row, tile * 16 + 4 * q, a.N, o * a.out_scale);
     }
   } else {
 #pragma unroll

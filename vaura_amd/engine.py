@@ -85,12 +85,12 @@ def h1_lossless(w: torch.Tensor) -> bool:
     return bool((err <= tol).all())
 
 
-def fold_gain(g: torch.Tensor):
-    """(g 2^-E, 2^E) with E = max(0, ceil(log2 max|g|)): the RMSNorm gain as the planes carry it and the factor its consuming matrix
-    takes instead (both exact: powers of two)."""
+def fold_gain(g: torch.Tensor, plane_shift: int = 0):
+    """(g 2^-E, 2^E) with E = max(0, ceil(log2 max|g|)) + plane_shift: the RMSNorm gain as the planes carry it and the factor its
+    consuming matrix takes instead (both exact: powers of two)."""
     g = g.detach().float()
     m = float(g.abs().max())
-    e = max(0, math.ceil(math.log2(m))) if m > 0 and math.isfinite(m) else 0
+    e = (max(0, math.ceil(math.log2(m))) if m > 0 and math.isfinite(m) else 0) + int(plane_shift)
     return g * (2.0 ** -e), 2.0 ** e
 
 
@@ -134,7 +134,7 @@ class DecoderEngine:
     _sequence_id = 0
 
     def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
-                 one_launch_mlp: bool = True, range_fallback: bool = True):
+                 one_launch_mlp: bool = True, range_fallback: bool = True, plane_shift: int = 0):
         """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "f32" (``resolve_weight_dtype``).
         one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
         is eligible (1..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
@@ -142,8 +142,16 @@ class DecoderEngine:
         when several processes share this GPU, or when several DecoderEngines of ONE process run on different streams at the same
         time (each launch wants all 256 CUs, one workgroup per CU: two such launches can starve each other until their bounded waits
         give up).  A give-up is reported by ``check_status`` — which callers of ``generate_codes`` / ``run`` must call themselves,
-        ``VAURAModel.generate_tokens`` does."""
+        ``VAURAModel.generate_tokens`` does.
+        plane_shift: S in 0..24 (fp16-plane storages only).  EVERY activation plane set is stored times 2^-S and the matrix that consumes
+        it times 2^S (h planes: through ``fold_gain``; attention output and SwiGLU output: ``vaura_decoder.plane_shift``) — the planes
+        overflow at |activation| = 65504 * 2^S instead of 65504, at the same speed.  The price is at the other end of fp16: the lo
+        plane's absolute resolution is 2^-24 * 2^S (its subnormal step), so S = 0 is what every parity number is quoted on, and a
+        checkpoint KNOWN to carry massive activations is the reason to pass S = 4 .. 8 rather than pay the exact-fp32 twin on every call."""
         self.one_launch_mlp = bool(one_launch_mlp)
+        self.plane_shift = int(plane_shift)
+        if not 0 <= self.plane_shift <= 24:
+            raise L.VauraHipError(f"plane_shift must be in 0..24, got {plane_shift}")
         # Range safety (``generate_codes_checked``): the fp16-plane activation format ends at |x| = 65504; a call that overflows it is
         # DETECTED on the device (sticky status bit) and re-run from its start on a twin engine with weight_dtype="f32" (fp32
         # activations and weights on the exact-fp32 matrix instruction: no range limit, the reference's own arithmetic), built lazily
@@ -157,6 +165,9 @@ class DecoderEngine:
         self.requested_wdtype = wdtype
         wdtype = resolve_weight_dtype(sd, wdtype)
         self.planes = wdtype != "f32"          # activations travel as (hi, lo) fp16 planes; "f32" = the exact-fp32-MFMA step
+        if self.plane_shift and not self.planes:
+            raise L.VauraHipError("plane_shift applies to the fp16-plane storages (h1 | h2 | fp8) only")
+        S, pw = self.plane_shift, 2.0 ** self.plane_shift
         # "fp8": e4m3 + power-of-two row scales for the four per-layer matrices (BASELINE configs[4]); the codebook
         # heads stay one fp16 plane.  The model then IS the one with weights quant.fp8_effective_weight(W): same kernels,
         # same activation arithmetic.
@@ -177,16 +188,16 @@ class DecoderEngine:
                 # (the producer's epilogue), so a large gain eats the planes' range.  Fold a power of two out of it: the planes hold
                 # (g 2^-E) * h with max |g 2^-E| <= 1 and the consuming matrix is stored as W 2^E — exact on both sides (its power-of-two
                 # row scales absorb it; W (g * x) == (W 2^E) ((g 2^-E) * x) bit for bit), E = 0 for gains <= 1 (every golden).
-                ga, ea = fold_gain(sd[p + "attention_norm.weight"])
-                gf, ef = fold_gain(sd[p + "ffn_norm.weight"])
+                ga, ea = fold_gain(sd[p + "attention_norm.weight"], S)
+                gf, ef = fold_gain(sd[p + "ffn_norm.weight"], S)
                 lw[l].wqkv = L.ptr(self._pack(sd[p + "attention.wqkv.weight"].float() * ea, self.wd))
-                lw[l].wo = L.ptr(self._pack(sd[p + "attention.wo.weight"], self.wd))
+                lw[l].wo = L.ptr(self._pack(sd[p + "attention.wo.weight"].float() * pw, self.wd))
                 lw[l].w13 = L.ptr(self._pack(w13 * ef, self.wd))
-                lw[l].w2 = L.ptr(self._pack(sd[p + "feed_forward.w2.weight"], self.wd))
+                lw[l].w2 = L.ptr(self._pack(sd[p + "feed_forward.w2.weight"].float() * pw, self.wd))
                 lw[l].attn_norm = L.ptr(self._dev(ga))
                 lw[l].ffn_norm = L.ptr(self._dev(gf))
             self.layers = lw
-            gn, en = fold_gain(sd["norm.weight"])
+            gn, en = fold_gain(sd["norm.weight"], S)
             heads = torch.cat([sd[f"lm_heads.{k}.weight"].float() for k in range(K)], dim=0) * en
             self.heads = self._pack(heads, head_wd)
             self.final_norm = self._dev(gn)
@@ -285,6 +296,7 @@ class DecoderEngine:
         d.wdtype, d.batch, d.rows, d.max_len = self.wd, batch, rows, max_len
         d.timesteps, d.seq_len, d.n_cond_tokens = timesteps, S, n_cond_tokens
         d.prefill_positions = self._prefill_positions
+        d.plane_shift = self.plane_shift
         d.layers_host = C.cast(self.layers, C.POINTER(L.LayerWeights))
         d.heads, d.final_norm = L.ptr(self.heads), L.ptr(self.final_norm)
         d.tok_emb, d.tok_proj_w, d.tok_proj_b = L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b)
