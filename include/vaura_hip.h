@@ -439,7 +439,8 @@ void vaura_set_debug_flags(unsigned flags);
 /* A second word of the same kind (the first is full).  bit 0: with 17..32 decoder rows the GEMVs walk the two row blocks one after the
  * other (round 4) instead of taking both per weight pass; bit 1: the one-launch MLP refuses more than 16 rows; bit 2 (experiment, measured slower): the next layer's
  * attention as a fourth phase of the one-launch MLP; bits 3, 4: fp8 weights keep round 4's kernels for wo / w2 / never take the
- * one-launch MLP.  0 = the product. */
+ * one-launch MLP; bits 5, 6, 12..15: row f2's linear layers on round 4's kernel / with late fragment reads / column-tile panel width
+ * (tools/README.md).  0 = the product. */
 void vaura_set_debug_flags2(unsigned flags);
 /* Host-side launch counters for tests that must know WHICH kernel instance a call took (read-and-clear; single caller thread):
  * 0 = codec conv launches on the 256-row workgroup instances (conv_pair_kernel<..., 8>, csrc/dac.hip) since the last read.

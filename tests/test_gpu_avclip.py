@@ -65,3 +65,24 @@ def test_plugin_feeds_the_generate_path(golden):
     assert float((feats.cpu() - torch.from_numpy(g["feats"])).abs().max()) < TOL
     same, _ = fe(feats)                      # pre-extracted features pass through
     assert same is feats
+
+
+def test_lds_dma_linear_layers_are_bit_identical_to_the_register_staged_ones(avclip_engine):
+    """csrc/dac.hip linear_dma_kernel (operands by LDS-DMA in whole cache lines, fragments read early, per-wave epilogue; the default
+    since round 5) against round 4's register-staged linear_pair_kernel (second debug word, bit 5), its late-read instance (bit 6)
+    and round 4's tile order (bits 12..15 = 15: no column panels): the same products summed in the same order, so the features must be
+    BIT-identical — 2 clips x 2 segments, a ragged last row tile (1 x 1: 1569 rows = 12 tiles + 33) and 12 segments (147 row tiles)."""
+    from vaura_amd import _lib as L
+    lib = L.lib()
+    try:
+        for B, S in ((2, 2), (1, 1), (3, 4)):
+            frames = synth.video_frames(B, S, seed=31 + B).to(DEV)
+            outs = []
+            for f2 in (0, 32, 64, 15 << 12):
+                lib.vaura_set_debug_flags2(f2)
+                outs.append(avclip_engine.forward(frames).clone())
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[0]).all()
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (B, S)
+    finally:
+        lib.vaura_set_debug_flags2(0)

@@ -14,6 +14,8 @@
 #   plain-stores                        write-through output stores (product) against ordinary ones (build --plain-stores), alternating
 #   codec-abl [tags ..]                 codec decode (mfma_driver codec 8, precisions 1 and 4) on experiment builds `python -m vaura_amd.csrc.build --tag T -DVA_CONV_ABL=n`
 #                                       (timing ablations of conv_pair_kernel, csrc/dac.hip) next to the product library
+#   linear-abl [tags ..]                extractor forward (mfma_driver avclip 8) on experiment builds `python -m vaura_amd.csrc.build --tag T -DVA_LIN_ABL=n`
+#                                       (timing ablations of linear_pair_kernel, csrc/dac.hip) next to the product library
 #   codec-pmc                           SQ wait / issue / LDS counters of the codec kernels (mfma_driver codec 8 under rocprofv3 --pmc, four passes), per kernel
 #   codec-layers                        per-dispatch durations of one codec decode (kernel trace of mfma_driver codec 8)
 #   avclip-stats                        per-kernel averages of one extractor forward (mfma_driver avclip 8 under rocprofv3 --stats)
@@ -82,6 +84,11 @@ codec-abl)
   for rep in 1 2; do for t in "" ${@:-_cabl1 _cabl2 _cabl4 _cabl3}; do for pr in 1 4; do
     echo "lib$t precision $pr: $(timeout 120 /tmp/mfma_driver vaura_amd/csrc/libvaura_hip$t.so codec 8 $pr 5 2>&1 | grep -o 'last decode [0-9.]* ms')" | tee -a $OUT/codec_abl.log
   done; done; done ;;
+linear-abl)
+  mfma_driver
+  for rep in 1 2; do for t in "" ${@:-_labl1 _labl2 _labl4 _labl8}; do
+    echo "lib$t: $(timeout 120 /tmp/mfma_driver vaura_amd/csrc/libvaura_hip$t.so avclip 8 1 3 2>&1 | grep -o 'last forward [0-9.]* ms')" | tee -a $OUT/linear_abl.log
+  done; done ;;
 codec-pmc)
   mfma_driver; cd /tmp && export TMPDIR=/tmp
   i=0

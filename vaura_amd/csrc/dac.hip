@@ -1332,6 +1332,11 @@ static int launch_conv_unit(const vaura_conv& c7, const vaura_conv& c1, const fl
 // an XCD-aware tile order: workgroup id % 8 is the XCD, and an XCD walks "its" row tiles with the column tiles fastest,
 // so an activation tile is fetched into one L2 only and reused there by every column tile.
 #define LBN 192
+// VA_LIN_ABL: timing ablations for tools/experiment.sh linear-abl (WRONG RESULTS; product build = 0): 1 no global loads inside the
+// k loop, 2 no fragment reads / matrix instructions, 4 no LDS staging stores, 8 no global traffic in the epilogue
+#ifndef VA_LIN_ABL
+#define VA_LIN_ABL 0
+#endif
 // MW = wave rows: 2 -> 128 x 192 tile, 256 threads, two workgroups per CU; 4 -> 256 x 192 tile, 512 threads, one per CU
 template <int MW>
 __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void linear_pair_kernel(ConvPArgs a, int mtiles, int ntiles) {
@@ -1382,10 +1387,11 @@ __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void linear_pair_kernel(
   const int g = lane >> 4, r16 = lane & 15;
   load_regs(0);
   for (int kt = 0; kt < nk; ++kt) {
-    store_lds();
+    if constexpr (VA_LIN_ABL & 4) { if (a.Cin == 12345) store_lds(); } else store_lds();
     __syncthreads();
-    if (kt + 1 < nk) load_regs(kt + 1);
+    if (kt + 1 < nk && !(VA_LIN_ABL & 1)) load_regs(kt + 1);
     f16x8 xh[4], xl[4];
+    if constexpr (!(VA_LIN_ABL & 2)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       xh[j] = __builtin_bit_cast(f16x8, Xs(2 * g, wm * 64 + j * 16 + r16));
@@ -1401,6 +1407,7 @@ __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void linear_pair_kernel(
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[i][j], 0, 0, 0);
       }
+    }
     }
     __syncthreads();
   }
@@ -1423,7 +1430,7 @@ __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void linear_pair_kernel(
     for (int it = 0; it < 16 * MW * OCT / NTH; ++it) {
       const int u = tid + NTH * it, lr = u / OCT, oc = u - lr * OCT;
       const int jr = j0 + (lr >> 4) * 64 + j * 16 + (lr & 15);
-      if (jr < a.Lin) {
+      if (jr < a.Lin && (!(VA_LIN_ABL & 8) || stage[lr * SP + oc * 8] == 12345.678f)) {
         const int co = n0 + oc * 8;
         const size_t orow = obase + (size_t)(jr + a.oshift0);
         const size_t o = orow * a.Cout + co;
@@ -1452,6 +1459,228 @@ __global__ __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) void linear_pair_kernel(
   }
 }
 
+// The same tile, wave layout, products and summation order (bit-identical outputs) with the operands brought in by LDS-DMA: no
+// staging registers, no ds_write, NST stages of 40 KB in flight (2: two workgroups share a CU, the next chunk flies during this one's
+// matrix instructions; 3: one workgroup, two chunks ahead), ONE barrier per chunk.
+// A DMA piece (one global_load_lds_dwordx4: lane l's 16 bytes land at slot l of 1 KB) is 8 ROWS x the whole 128-byte chunk of each
+// (8 lanes = one cache line; the first cut fetched a fragment per piece — 16 rows x every other quad, 64 requests per instruction —
+// and was bound by the address path: 52 ms against 45).  What makes the fragment reads conflict-free on such an image: a block of 32
+// rows (two 16-row tiles) is four pieces; piece p holds rows p, p + 4, p + 8, p + 12 of each tile at k = 4 tile + 2 ((r >> 2) & 1) +
+// ((r >> 3) & 1), and stores a row's 8 quads ROTATED by s(p) = {0, 1, 4, 5}: quad q at position (q + s(p)) mod 8.  A ds_read_b128
+// is served in groups of 16 lanes holding 16 different rows with two neighbouring octets g (MI355X_MICROARCH.md, LDS): their slots
+// mod 16 are 8 (r >> 3 & 1) + (2 g + plane + s(r & 3)) mod 8 — sixteen different values.  The epilogue writes from the accumulators: a lane holds 4 consecutive output columns of one row (16 bytes
+// of the fp32 tensor); for the pair-layout copy the lanes g, g ^ 1 of a row swap halves (v_permlane16_swap) and write the octet's hi
+// and lo quad — no LDS staging, no barriers.  Measured by ablation on round 4's kernel (tools/experiment.sh linear-abl, 35 ms of
+// linears): global loads through registers 7 ms, the staging stores 8 ms, the staged epilogue 9 ms, matrix instructions 12 ms —
+// nothing overlapped well.
+// EARLY (two stages, the product): a chunk's fragments are all read into registers at the head of its step and a second barrier
+// frees its stage at once for chunk kt + 2 — a DMA piece then has two steps of matrix instructions to land instead of one, in the
+// same 80 KB.  Whole extractor forwards, 8 clips (round 4's kernel 44.2 ms): late reads 43.2, EARLY 42.0.
+// MW = wave rows, NWN = waves along the 192 columns; only <2, 2> (128 x 192, four waves of 64 x 96, two workgroups per CU) is
+// instantiated.  Measured and dropped (DESIGN_HISTORY.md, round 5): <NST 3, 2, 2> one workgroup of four waves 50.3 ms; <2, MW 4, 2>
+// 256 x 192 on eight waves (43 % less traffic from beyond L2) 43.6; <3 | 4, 2, NWN 4> eight waves of 64 x 48 with three / four
+// stages 45.2 / 45.4; the accumulators stored without the LDS turn-around 41.7 (no better: what the epilogue costs is its bytes).
+template <int NST, int MW = 2, int NWN = 2, bool EARLY = false>
+__global__ __launch_bounds__(64 * MW * NWN, (NST == 2 && MW * NWN == 4) ? 2 : 1) void linear_dma_kernel(ConvPArgs a, int mtiles, int ntiles, int panel) {
+  static_assert(!EARLY || NST == 2, "EARLY is the two-stage schedule");
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  constexpr int LBM_ = 64 * MW, NWV = NWN * MW, NI = 12 / NWN, WC = NI * 16, XF = (LBM_ / 16) * 2, WF = (LBN / 16) * 2, PPW = (XF + WF) / NWV, STB = (XF + WF) * 1024;
+  static_assert((XF + WF) % NWV == 0, "the same number of pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lind_lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wv % NWN, wm = wv / NWN;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  // Tile order inside an XCD: column tiles in PANELS of `panel` (a divisor of ntiles), all of the XCD's row tiles per panel, the
+  // panel's column tiles fastest.  With panel = ntiles (round 4's order) every group of workgroups in flight streams the WHOLE weight
+  // matrix through a 4 MB L2 (7 - 9 MB for 768 -> 2304 / 3072): measured 1.45 / 2.0 GB fetched from beyond L2 per launch for 0.16 GB
+  // of operands.  A panel of 4 column tiles (2.4 MB at K = 768) stays resident; the activations are then fetched once per panel.
+  const int rows_x = (mtiles + 7) >> 3, per_panel = rows_x * panel;
+  const int pn = local / per_panel, lp = local - pn * per_panel;
+  const int nt = pn * panel + lp % panel, mt = (lp / panel) * 8 + xcd;
+  if (mt >= mtiles) return;
+  const int b = blockIdx.y;
+  const int j0 = mt * LBM_, n0 = nt * LBN;
+  const int cq = a.Cin / 4;                 // 16-B quads per row (C/8 octets x 2 planes)
+  const int nk = a.Cin / BK;
+  const int g = lane >> 4, r16 = lane & 15;
+
+  // this wave's PPW pieces of a stage: piece P < XF = activation rows (32-row block P / 4, piece P % 4 of it), else weight rows.
+  // Rows past the end re-read the last one (their outputs are not stored).
+  const unsigned char* src[PPW];
+  {
+    const int k = lane >> 3, kk = k & 3;
+    const int rr = (k >> 2) * 16 + 4 * (kk >> 1) + 8 * (kk & 1);        // row of the block, before + p
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int P = wv * PPW + j, pp = P & 3;
+      const int q = ((lane & 7) - (pp + (pp >> 1) * 2)) & 7;            // s(p) = {0, 1, 4, 5}
+      if (P < XF) {
+        const int row = min(j0 + (P >> 2) * 32 + rr + pp, a.Lin - 1);
+        src[j] = reinterpret_cast<const unsigned char*>(a.in) + (((size_t)b * a.Lin + row) * cq + q) * 16;
+      } else {
+        src[j] = reinterpret_cast<const unsigned char*>(a.w) + ((size_t)(n0 + ((P - XF) >> 2) * 32 + rr + pp) * cq + q) * 16;
+      }
+    }
+  }
+  auto issue = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int p = wv * PPW + j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[j],
+                                       (__attribute__((address_space(3))) void*)(lind_lds + stage * STB + p * 1024), 16, 0, 0);
+      src[j] += 128;                        // the next 32-channel chunk of the same rows
+    }
+  };
+  // fragment (16-row tile m of the stage's rows, plane pl) as lane (g, r16) reads it
+  int foff[2];
+  {
+    const int pp = r16 & 3, sp = pp + (pp >> 1) * 2, kq = (((r16 >> 3) & 1) + 2 * ((r16 >> 2) & 1)) * 8;
+    foff[0] = pp * 1024 + (kq + ((2 * g + sp) & 7)) * 16;
+    foff[1] = pp * 1024 + (kq + ((2 * g + 1 + sp) & 7)) * 16;
+  }
+  auto xfrag = [&](int stage, int m, int pl) -> f16x8 {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lind_lds + stage * STB + (m >> 1) * 4096 + (m & 1) * 512 + foff[pl]));
+  };
+  auto wfrag = [&](int stage, int n, int pl) -> f16x8 {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lind_lds + stage * STB + XF * 1024 + (n >> 1) * 4096 + (n & 1) * 512 + foff[pl]));
+  };
+
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (EARLY) {
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int st = kt & 1;
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // chunk kt + 1 may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      f16x8 xh[4], xl[4], wh[NI], wl[NI];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[j] = xfrag(st, wm * 4 + j, 0);
+        xl[j] = xfrag(st, wm * 4 + j, 1);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        wh[i] = wfrag(st, wn * NI + i, 0);
+        wl[i] = wfrag(st, wn * NI + i, 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // every wave holds its fragments: the stage is free
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk && !(VA_LIN_ABL & 1)) issue(st);
+      if constexpr (!(VA_LIN_ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  } else {
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nk) issue(st);
+  int st0 = 0;                              // stage of chunk kt
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's pieces of chunk kt have landed (chunks issued after it may still fly: none with two stages); the barrier publishes
+    // every wave's pieces and says that every wave is done reading chunk kt - 1, whose stage takes chunk kt + NST - 1
+    {
+      const int ahead = min(NST - 2, nk - 1 - kt);      // chunks issued after chunk kt
+      if (NST >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else if (NST >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk && !(VA_LIN_ABL & 1)) issue(st0 == 0 ? NST - 1 : st0 - 1);
+    if constexpr (!(VA_LIN_ABL & 2)) {
+      f16x8 xh[4], xl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[j] = xfrag(st0, wm * 4 + j, 0);
+        xl[j] = xfrag(st0, wm * 4 + j, 1);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const f16x8 wh = wfrag(st0, wn * NI + i, 0);
+        const f16x8 wl = wfrag(st0, wn * NI + i, 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    st0 = st0 == NST - 1 ? 0 : st0 + 1;
+  }
+  }
+
+  // ---- epilogue: acc[i][j][r] = out[row j0 + wm 64 + 16 j + r16][column n0 + wn WC + 16 i + 4 g + r].  Stored straight from the
+  // accumulators a wave instruction covers 16 rows x 64 bytes with NEIGHBOURING LANES IN DIFFERENT ROWS — 64 separate 16-byte
+  // requests; that cut (no LDS, no barriers) cost as much as round 4's staged one (10 of 34 ms: tools/experiment.sh linear-abl).
+  // Here every wave turns its own 32 x WC slab around through a private piece of the (now idle) stages — no workgroup barrier —
+  // and reads it back with consecutive lanes on consecutive 16 bytes of a row: residual loads and both stores in whole lines.
+  constexpr int SPW = WC + 4, QPR = WC / 4;      // padded slab row (floats; stride = 4 mod 8 banks: conflict-free b128 stores), quads per row
+  static_assert(NWV * 32 * SPW * 4 <= NST * STB && (32 * QPR) % 64 == 0, "a 32-row slab per wave inside the stages");
+  float* slab = reinterpret_cast<float*>(lind_lds) + wv * (32 * SPW);
+  if constexpr (!EARLY) __syncthreads();         // the last chunk's fragment reads of the slower waves (EARLY: behind its second barrier)
+  const size_t obase = (size_t)b * a.Lout;
+  f32x4 bias4[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wn * WC + i * 16 + 4 * g);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<f32x4*>(slab + (jj * 16 + r16) * SPW + i * 16 + 4 * g) = acc[i][2 * half + jj] + bias4[i];
+#pragma unroll
+    for (int it = 0; it < 32 * QPR / 64; ++it) {
+      const int Q = it * 64 + lane, row = Q / QPR, cq = Q - row * QPR;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SPW + cq * 4);
+      const int jr = j0 + wm * 64 + half * 32 + row;
+      const bool live = jr < a.Lin && (!(VA_LIN_ABL & 8) || v[0] == 12345.678f);
+      const size_t orow = obase + (size_t)(min(jr, a.Lin - 1) + a.oshift0);
+      const int co = n0 + wn * WC + cq * 4;
+      if (a.res && live) v = *reinterpret_cast<const f32x4*>(a.res + orow * a.Cout + co) + v;
+      if (a.out_raw && live) *reinterpret_cast<f32x4*>(a.out_raw + orow * a.Cout + co) = v;
+      if (a.out_act) {
+        f16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = a.act == 1 ? gelu_erf_f(v[r]) : v[r];
+          hi[r] = (_Float16)x;
+          lo[r] = (_Float16)(x - (float)hi[r]);
+        }
+        // lanes l (even: columns 0-3 of the octet) and l ^ 1 (columns 4-7) trade halves: the even one writes the hi quad, the odd one the lo
+        const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+        const bool odd = lane & 1;
+        const uint32_t s0 = odd ? h2[0] : l2[0], s1 = odd ? h2[1] : l2[1];
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s0, VA_DPP_XOR1, 0xf, 0xf, true);
+        const uint32_t t1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s1, VA_DPP_XOR1, 0xf, 0xf, true);
+        if (live) {
+          u32x4* dst = reinterpret_cast<u32x4*>(a.out_act) + (orow * (size_t)(a.Cout >> 3) + (size_t)(co >> 3)) * 2 + (odd ? 1 : 0);
+          *dst = odd ? u32x4{t0, t1, l2[0], l2[1]} : u32x4{h2[0], h2[1], t0, t1};
+        }
+      }
+    }
+  }
+}
+
 // Plain linear layer on the pair GEMM (row f2, vit.hip): out[b][row + oshift][:] = act( in[b][row][:] . W^T + bias (+ res) ).
 // in: pair layout (B, Lin, Cin); w: pair layout (Cout, Cin); out rows live in sequences of Lout rows per b.
 int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bias, const float* res, float* out_raw,
@@ -1472,7 +1701,27 @@ int va_launch_linear_pair(const uint16_t* in, const uint16_t* w, const float* bi
       VA_LAUNCH(linear_pair_kernel<4>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(512), 0, s, p, mtiles, ntiles);
     } else {
       const int mtiles = (Lin + 127) / 128;
-      VA_LAUNCH(linear_pair_kernel<2>, dim3((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B), dim3(256), 0, s, p, mtiles, ntiles);
+#ifndef VA_LIN_F2
+#define VA_LIN_F2 0u       // experiment builds: instance bits forced on (tools/experiment.sh linear-abl drives a C++ program without flag control)
+#endif
+      const unsigned f2 = va_debug_flags2_get() | VA_LIN_F2;
+      // column-tile panel (see linear_dma_kernel): 4 tiles while a tile of the weights is <= 1 MB (K <= 1280), else the whole width;
+      // second flag word bits 12..15 override (1 .. 15 tiles; must divide ntiles)
+      int panel = (Cin <= 1280 && ntiles % 4 == 0) ? 4 : ntiles;
+      if (((f2 >> 12) & 15u) && ntiles % (int)((f2 >> 12) & 15u) == 0) panel = (int)((f2 >> 12) & 15u);
+      if (((f2 >> 12) & 15u) == 15u) panel = ntiles;
+      const dim3 grid((unsigned)(((mtiles + 7) / 8) * 8 * ntiles), B);
+      if (f2 & 32u) {                      // second flag word, bit 5: round 4's register-staged kernel
+        VA_LAUNCH(linear_pair_kernel<2>, grid, dim3(256), 0, s, p, mtiles, ntiles);
+      } else if (f2 & 64u) {               // bit 6: LDS-DMA with the fragments read next to their matrix instructions (one barrier per chunk)
+        static unsigned long long big2 = 0;
+        if (va_big_lds_once(reinterpret_cast<const void*>(linear_dma_kernel<2, 2, 2, false>), 2 * 40 * 1024, &big2)) return VAURA_ERR_STATE;
+        VA_LAUNCH((linear_dma_kernel<2, 2, 2, false>), grid, dim3(256), 2 * 40 * 1024, s, p, mtiles, ntiles, panel);
+      } else {
+        static unsigned long long bige = 0;
+        if (va_big_lds_once(reinterpret_cast<const void*>(linear_dma_kernel<2, 2, 2, true>), 2 * 40 * 1024, &bige)) return VAURA_ERR_STATE;
+        VA_LAUNCH((linear_dma_kernel<2, 2, 2, true>), grid, dim3(256), 2 * 40 * 1024, s, p, mtiles, ntiles, panel);
+      }
     }
     return 0;
   }
