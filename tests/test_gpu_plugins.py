@@ -339,3 +339,14 @@ def test_sampler_forward_survives_activations_beyond_the_fp16_plane_range():
         assert err < 3e-5 * max(1.0, float(ref.abs().max())), (L_, err)
     eng = s.engine()
     assert eng.wdtype in ("h1", "h2") and eng.range_fallbacks == 1 and eng._forward_on_twin
+    # ... and with `plane_shift: 12` in the sampler's params the same host calls stay on the fp16-plane kernels (no detour at all)
+    s2 = Transformer(**cfg.yaml_params(), plane_shift=12)
+    s2.load_state_dict(sd, strict=True)
+    s2.audio_tokens_per_video_frame = 7
+    s2 = s2.to(DEV)
+    for L_ in (4, 5, 6):
+        lg, _, _ = s2(tgt=idx[..., :L_].to(DEV), memory=feats.to(DEV))
+        err = float((lg.cpu() - ref[:, :, :L_]).abs().max())
+        assert bool(torch.isfinite(lg).all()) and err < 3e-5 * max(1.0, float(ref.abs().max())), (L_, err)
+    e2 = s2.engine()
+    assert e2.plane_shift == 12 and e2.range_fallbacks == 0 and not e2._forward_on_twin

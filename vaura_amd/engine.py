@@ -159,6 +159,7 @@ class DecoderEngine:
         self._twin_sd = sd if range_fallback else None
         self._range_twin: Optional["DecoderEngine"] = None
         self.range_fallbacks = 0             # calls re-run on the exact-fp32 twin so far
+        self._forward_on_twin = False        # forward_cached moved to the twin for good (the host's per-step calls)
         _require_cuda(device)
         self.cfg = cfg
         self.dev = torch.device(device)
@@ -523,7 +524,7 @@ class DecoderEngine:
         cap = c.block_size                                   # positions the model supports (scripts/generate.py:221-224)
         if Lq > cap:
             raise L.VauraHipError(f"sequence of {Lq} positions exceeds block_size {cap}")
-        if getattr(self, "_forward_on_twin", False):         # an earlier call overflowed the fp16 planes: this engine's forward() stays on fp32
+        if self._forward_on_twin:         # an earlier call overflowed the fp16 planes: this engine's forward() stays on fp32
             return self._range_twin.forward_cached(idx, feats, tokens_per_frame)
         idx = idx.to(self.dev)
         feats = feats.to(self.dev, torch.float32)
