@@ -1648,15 +1648,27 @@ __global__ __launch_bounds__(64 * MW * NWN, (NST == 2 && MW * NWN == 4) ? 2 : 1)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
         *reinterpret_cast<f32x4*>(slab + (jj * 16 + r16) * SPW + i * 16 + 4 * g) = acc[i][2 * half + jj] + bias4[i];
+    // the residual quads of the whole half, requested before the first store: `res` may be `out_raw` (x += ...), so the compiler must
+    // keep every load behind the stores in front of it — one memory round trip per iteration if they are written where they are used
+    constexpr int NIT = 32 * QPR / 64;
+    f32x4 rq[NIT];
+    if (a.res && !(VA_LIN_ABL & 8)) {
 #pragma unroll
-    for (int it = 0; it < 32 * QPR / 64; ++it) {
+      for (int it = 0; it < NIT; ++it) {
+        const int Q = it * 64 + lane, row = Q / QPR, cq = Q - row * QPR;
+        const int jr = min(j0 + wm * 64 + half * 32 + row, a.Lin - 1);
+        rq[it] = *reinterpret_cast<const f32x4*>(a.res + (obase + (size_t)(jr + a.oshift0)) * a.Cout + n0 + wn * WC + cq * 4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int Q = it * 64 + lane, row = Q / QPR, cq = Q - row * QPR;
       f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SPW + cq * 4);
       const int jr = j0 + wm * 64 + half * 32 + row;
       const bool live = jr < a.Lin && (!(VA_LIN_ABL & 8) || v[0] == 12345.678f);
       const size_t orow = obase + (size_t)(min(jr, a.Lin - 1) + a.oshift0);
       const int co = n0 + wn * WC + cq * 4;
-      if (a.res && live) v = *reinterpret_cast<const f32x4*>(a.res + orow * a.Cout + co) + v;
+      if (a.res && !(VA_LIN_ABL & 8)) v = rq[it] + v;
       if (a.out_raw && live) *reinterpret_cast<f32x4*>(a.out_raw + orow * a.Cout + co) = v;
       if (a.out_act) {
         f16x4 hi, lo;
