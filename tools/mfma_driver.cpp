@@ -171,6 +171,29 @@ int main(int argc, char** argv) {
       const int rc = decode(&c, codes, clips, T, wav, st);
       if (rc) { fprintf(stderr, "vaura_dac_decode: %d\n", rc); return 3; }
     }
+    if (const char* so = getenv("MFMA_STAMPS")) {
+      // <lib> = the diagnostic build (python -m vaura_amd.csrc.build --stamps): ONE more decode with the conv kernels' in-kernel
+      // s_memrealtime stamps collected (csrc/common.h; wave 0 of every workgroup, every wave with PMC_STAMP_ALL_WAVES) -> file
+      auto set_d = (int (*)(unsigned long long*))dlsym(lib, "vaura_stamps_set_dac");
+      if (!set_d) { fprintf(stderr, "%s is not a stamps build\n", argv[1]); return 1; }
+      CK(hipStreamSynchronize(st));
+      const size_t cap = 1500000;
+      unsigned long long* buf; CK(hipMalloc(&buf, (8 + cap * 16) * 8)); CK(hipMemset(buf, 0, (8 + cap * 16) * 8));
+      unsigned long long hdr[3] = {0, cap, getenv("PMC_STAMP_ALL_WAVES") ? 1ull : 0ull};
+      CK(hipMemcpy(buf, hdr, sizeof hdr, hipMemcpyHostToDevice));
+      if (set_d(buf)) return 3;
+      if (decode(&c, codes, clips, T, wav, st)) return 3;
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> host(8 + cap * 16);
+      CK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
+      const size_t n = std::min<size_t>(host[0], cap);
+      FILE* f = fopen(so, "wb");
+      if (!f) { perror(so); return 1; }
+      fwrite(host.data() + 8, 128, n, f);
+      fclose(f);
+      printf("stamps: %zu records -> %s\n", n, so);
+      if (set_d(nullptr)) return 3;
+    }
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
     CK(hipEventElapsedTime(&ms, e0, e1));

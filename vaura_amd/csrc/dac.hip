@@ -446,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
 #pragma unroll
     for (int j = 0; j < MJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);                       // (diagnostic build, tools/mfma_driver MFMA_STAMPS) wave start
   load_w(0);
   load_x(0);
   store_w(0);
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
     }
   }
   __syncthreads();
+  VA_STAMP(stamps, 1);                       // first tiles staged
   const int g = lane >> 4, r16 = lane & 15;
   int kt = 0;
   for (int c = 0; c < kc; ++c) {
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
     }
   }
 
+  VA_STAMP(stamps, 2);                       // main loop done
   // ---- epilogue through LDS: the MFMA layout gives a lane 4 channels of one row (16-byte pieces, 64-byte runs per
   // row: half cache lines for the fp32 stream, 8-byte pieces for the pair stream); staging the tile lets every thread
   // own a whole octet of a row, so residual reads and both output streams move 32 contiguous bytes per thread and
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
         }
       }
       __syncthreads();
+      if (p == 0) VA_STAMP(stamps, 3);         // pass 0: Snake image + 1 x 1 weights in LDS
       f32x4 acc2[NI][2];
 #pragma unroll
       for (int i = 0; i < NI; ++i)
@@ -590,6 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
           }
       }
       __syncthreads();                          // every wave has read the image: the fp32 tile may overwrite it
+      if (p == 0) VA_STAMP(stamps, 4);         // pass 0: 1 x 1 products done
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -599,11 +605,14 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
         }
       __syncthreads();
       conv_tile_store<BN_, SP, false, 64>(a, stage, b, ph, j0 + p * 64, n0, tid);
+      if (p == 0) VA_STAMP(stamps, 5);         // pass 0: tile stored
     };
     pass(std::integral_constant<int, 0>{});
     pass(std::integral_constant<int, 1>{});
     pass(std::integral_constant<int, 2>{});
     pass(std::integral_constant<int, 3>{});
+    VA_STAMP(stamps, 6);
+    VA_STAMP_FLUSH(stamps, 21);
     return;
   }
   float* stage = reinterpret_cast<float*>(smem);
@@ -621,8 +630,12 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvPArgs a) {
       }
     }
     __syncthreads();
+    if (h == 0) VA_STAMP(stamps, 4);          // first 128-row pass staged
     conv_tile_store<BN_, SP>(a, stage, b, ph, j0 + h * BM, n0, tid);
+    if (h == 0) VA_STAMP(stamps, 5);
   }
+  VA_STAMP(stamps, 6);
+  VA_STAMP_FLUSH(stamps, 20);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -713,6 +726,8 @@ __global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
 #pragma unroll
     for (int j = 0; j < RB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  VA_STAMP_DECL(stamps);
+  VA_STAMP(stamps, 0);                       // (diagnostic build, tools/mfma_driver MFMA_STAMPS) wave start
   load_w(0);
   load_x(0);
   store_w(0);
@@ -723,6 +738,7 @@ __global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
     tab[C_ + ch] = 1.0f / (al + 1e-9f);
   }
   __syncthreads();
+  VA_STAMP(stamps, 1);                       // first tiles staged
   int kt = 0;
   for (int c = 0; c < KC; ++c) {
     for (int t = 0; t < NT; ++t, ++kt) {
@@ -773,6 +789,7 @@ __global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const int qd = tid + 256 * i; W2s(buf, qd & 7, qd >> 3) = w2reg[i]; }
   };
+  VA_STAMP(stamps, 2);                       // main loop done
   load_w2(0, 0);      // (in flight under the Snake arithmetic below; the main loop ended with a barrier: its LDS is free)
 
   // ---- first conv's epilogue in registers: + bias, Snake(alpha_mid), (hi, lo) split -> the second conv's B fragments
@@ -798,6 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
     }
   });
 
+  VA_STAMP(stamps, 3);                       // Snake + split in registers done
   // ---- second conv: column tiles of 96 output channels, k = the C channels held in registers
   float* stage = reinterpret_cast<float*>(smem + W2_ELEMS);
   constexpr int WPP = 4 / RB;                 // waves that own a 64-row pass (1 or 2)
@@ -835,6 +853,7 @@ __global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
       if (c2 + 1 < KC) store_w2(buf ^ 1);
       __syncthreads();
     });
+    if (nt == 0) VA_STAMP(stamps, 4);        // first column tile: 1 x 1 products done
     // 64 rows at a time through the fp32 tile (owned by wave p with 256 rows, by waves 2 p and 2 p + 1 with 128)
 #pragma unroll
     for (int p = 0; p < BMT / 64; ++p) {
@@ -851,8 +870,11 @@ __global__ __launch_bounds__(256, 2) void conv_unit_kernel(ConvPArgs a) {
       __syncthreads();
       conv_tile_store<BN, SP, false, 64>(a, stage, b, 0, j0 + p * 64, nt * BN, tid);
     }
+    if (nt == 0) VA_STAMP(stamps, 5);        // first column tile stored
     if (nt + 1 < C_ / BN) __syncthreads();      // ... before the next column tile's passes reuse it
   }
+  VA_STAMP(stamps, 6);
+  VA_STAMP_FLUSH(stamps, 22);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1692,6 +1714,8 @@ __global__ __launch_bounds__(64 * MW * NWN, (NST == 2 && MW * NWN == 4) ? 2 : 1)
     }
   }
 }
+
+VA_STAMP_SETTER(vaura_stamps_set_dac)
 
 // Plain linear layer on the pair GEMM (row f2, vit.hip): out[b][row + oshift][:] = act( in[b][row][:] . W^T + bias (+ res) ).
 // in: pair layout (B, Lin, Cin); w: pair layout (Cout, Cin); out rows live in sequences of Lout rows per b.
