@@ -741,6 +741,32 @@ def test_reference_shipped_defaults_top_k128_cfg6_h2_B8_matches_reference(golden
     torch.cuda.empty_cache()
 
 
+def test_reference_default_batch16_32_rows_full_depth_matches_reference(golden, full_sampler_sd_raw, parity_report):
+    """The reference's default BATCH too (configs/generate_vgg.yaml:41 batch_size 16 -> 32 decoder rows under cfg 6: two row blocks per
+    weight pass in every GEMV and in the one-launch MLP, 512-workgroup attention), at full depth on the default storage: clips 0-1 of
+    B=16 must equal, token for token, what the reference's own generate() produced for them — sampled with the shipped defaults
+    (top-k 128), sampled with top-k 250 (the headline golden) and greedy under cfg 6.  STRICT."""
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV)
+    assert eng.wdtype == "h2"
+    for name, seed2 in (("full_topk128_cfg6_raw_B2_T220", 4322), ("full_topk250_cfg6_raw_B2_T220", 4321)):
+        g = golden(name + ".npz")
+        feats = synth.video_features(16, seed=int(g["feat_seed"])).to(DEV)
+        nz = torch.cat([synth.exp_noise(228, 18, 1024, int(g["noise_seed"])), synth.exp_noise(228, 9 * 14, 1024, seed2)], dim=1)
+        tok = eng.generate_codes(feats, 220, use_sampling=True, temp=1.0, top_k=int(g["top_k"]), cfg_scale=float(g["cfg_scale"]), noise=nz).cpu()
+        eng.check_status()
+        assert eng.rows == 32
+        assert_tokens_equal(parity_report, name, "h2", f"cfg 6 / top-k {int(g['top_k'])} sampled, clips 0-1 of B=16 (32 rows: the reference's default batch)",
+                            tok[:2], _ref(g, "tokens"), g["margins"], g["threshold_rel_gap"])
+    gg = golden("full_greedy_cfg6_raw_B2_T220.npz")
+    feats = synth.video_features(16, seed=int(gg["feat_seed"])).to(DEV)
+    tokg = eng.generate_codes(feats, 220, cfg_scale=float(gg["cfg_scale"])).cpu()
+    eng.check_status()
+    assert_tokens_equal(parity_report, "full_greedy_cfg6_raw_B2_T220", "h2", "greedy cfg 6, clips 0-1 of B=16 (32 rows)", tokg[:2],
+                        _ref(gg, "tokens"), gg["margins"])
+    del eng
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("wdtype", ["auto", "f32"])
 def test_later_chunk_of_the_sliding_window_caller_full_depth_matches_reference(golden, full_sampler_sd_raw, parity_report, wdtype):
     """Row f1 at its REAL shape and depth (scripts/generate.py:344-357, a later chunk): prompt Tp = 166 encoded frames, max_new_tokens 221
