@@ -271,8 +271,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     const __amdgpu_buffer_rsrc_t q1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.out), 0, 16 * 3 * DM * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t q2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.out2), 0, 16 * 3 * DM * 4, 0x00020000);
     const int qoff = (int)(packed_quad(att_row, (which * DM + att_h * HD + cq * 4) >> 2, 3 * DM) * 16);
-    f32x4 gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q1, qoff, 0, 16 /* sc1 */));
-    const f32x4 gx2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q2, qoff, 0, 16 /* sc1 */));
+    constexpr int QAUX = 16;     // sc1: past L1, served by L2 (MLPE_ATT_LOCAL: the producers' plain stores left the lines in THIS XCD's L2)
+    f32x4 gx = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q1, qoff, 0, QAUX));
+    const f32x4 gx2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q2, qoff, 0, QAUX));
     const f32x4 gcs = *reinterpret_cast<const f32x4*>(e.att_rope + ((size_t)att_pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
     float* kc = e.att_kc + ((size_t)att_row * 16 + att_h) * (size_t)e.att_max_len * HD;
     float* vc = e.att_vc + ((size_t)att_row * 16 + att_h) * (size_t)e.att_max_len * HD;
@@ -755,7 +756,15 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       // tile) — the slices, products and 4-wave reduction of gemv3_kernel<6, 4, 3, E3_STORE, true, 1, 0, 1, 2> — waves 4 .. 7 only
       // pass the barriers (and finish tiles: any wave can run an epilogue)
       constexpr int G = FP8 ? 6 : 3, NWQ = FP8 ? 4 : NW, GF = 3, TQ = 3, KQ = 1536, KGQ = KQ / 32;
-      const int ks = bid & 1, tile0q = (bid >> 1) * TQ, kgo = ks * G * NWQ;
+      // EXPERIMENT build -DMLPE_ATT_LOCAL (ATT instances): the qkv work items of head h on the XCD of h's attention workgroups (XCD =
+      // workgroup id % 8 = h % 8): item s 64 + 4 h + sub goes to workgroup (h % 8) + 8 ((h / 8) 12 + 4 s + sub), so that the hand-off
+      // of the q / k / v quads stays inside one L2 (consumer loads sc0 instead of sc1)
+#ifdef MLPE_ATT_LOCAL
+      const int qid = ATT ? (((bid >> 3) % 12) >> 2) * 64 + 4 * ((bid & 7) + 8 * ((bid >> 3) / 12)) + (((bid >> 3) % 12) & 3) : bid;
+#else
+      const int qid = bid;
+#endif
+      const int ks = qid & 1, tile0q = (qid >> 1) * TQ, kgo = ks * G * NWQ;
       const bool actq = wid < NWQ;                     // this wave multiplies in the qkv phase
       const int w3 = (wid + bid) % NWQ;
       const int mq = lane & 15;
@@ -904,6 +913,11 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         sacc *= wsq;
         const f32x4 v = sacc * rinvq;
         if (ks > 0) aq.out = aq.out2;
+#ifdef MLPE_ATT_LOCAL
+        if constexpr (ATT) {     // plain store: the line stays in this XCD's L2, where the head's attention workgroups read it (sc1 loads)
+          reinterpret_cast<f32x4*>(aq.out)[((size_t)rq * (aq.N / 4) + (size_t)(tile0q + tq) * 4) * 16 + lane] = v;
+        } else
+#endif
         gemv3_epilogue<1, E3_STORE>(aq, rq, tile0q + tq, lane, &v, nullptr);
       }
       if constexpr (ATT) {
@@ -918,7 +932,11 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
             while (__hip_atomic_load(arrive + 21, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag ||
                    __hip_atomic_load(arrive + 22, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != ltag)
               __builtin_amdgcn_s_sleep(1);
-            if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 512 + bid), "v"(epoch) : "memory");
+#ifdef MLPE_ATT_LOCAL
+            if (lane == 0) asm volatile("global_store_dword %0, %1, off" ::"v"(e.flags + 512 + qid), "v"(epoch) : "memory");
+#else
+            if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 512 + qid), "v"(epoch) : "memory");
+#endif
           }
           att_request();
         }
