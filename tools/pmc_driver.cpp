@@ -253,6 +253,9 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, st));
         CK(hipStreamSynchronize(st));
         float t; CK(hipEventElapsedTime(&t, e0, e1));
+        int32_t sw = 0;                        // sticky status word (include/vaura_hip.h): a hand-off that gave up stops every later one from waiting
+        CK(hipMemcpy(&sw, d.state + 4, sizeof sw, hipMemcpyDeviceToHost));
+        if (sw) { fprintf(stderr, "STATUS WORD 0x%x after a loop of flags %u:%u: the timing of this run is INVALID\n", sw, variants[v], variants2[v]); return 5; }
         if (r >= 0) { ms[v].push_back(t); host_ms[v].push_back(std::chrono::duration<float, std::milli>(h1 - h0).count()); }
       }
     static const char* kinds[8] = {"embed", "qkv", "attn", "wo", "w13", "w2", "heads", "sample"};
