@@ -47,7 +47,7 @@ def full_sampler_sd_raw():
 @pytest.fixture(scope="session")
 def parity_report():
     """ONE report per pytest session of every token / logit comparison against a reference golden (tests/parity_helpers.py);
-    written when the session ends to gpurun_out/r05_parity.json (the only directory a GPU box hands back; the copy that is judged
+    written when the session ends to gpurun_out/r06_parity.json (the only directory a GPU box hands back; the copy that is judged
     lives under profiles/)."""
     from parity_helpers import ParityReport
     rep = ParityReport()
@@ -58,4 +58,4 @@ def parity_report():
         # a partial session (-k ...) must not overwrite the record of a whole one: the headline golden is the marker
         whole = any(e.get("golden") == "full_topk250_cfg6_raw_B2_T220" and e.get("storage") == "h2" for e in rep.entries) and \
             any(e.get("golden") == "full_c4_greedy_B1_T880" for e in rep.entries)
-        rep.write(os.path.join(REPO, "gpurun_out", "r05_parity.json" if whole else "r05_parity_partial.json"))
+        rep.write(os.path.join(REPO, "gpurun_out", "r06_parity.json" if whole else "r06_parity_partial.json"))

@@ -3,7 +3,7 @@
 Token parity against a reference golden is STRICT (`assert_tokens_equal`): `torch.equal`, no exception.  The one golden that holds
 a step whose reference margin is inside fp32 summation-order noise (configs[3], step 578, margin 5.5e-6) goes through
 `assert_tokens_or_recorded_near_tie`, and what happened there is written down per storage.  Every comparison is recorded in the
-session's `ParityReport` (conftest.py `parity_report`), which the session writes ONCE to gpurun_out/r05_parity.json."""
+session's `ParityReport` (conftest.py `parity_report`), which the session writes ONCE to gpurun_out/r06_parity.json."""
 import json
 import os
 
