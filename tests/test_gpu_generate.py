@@ -499,13 +499,12 @@ def test_dac_encode_matches_oracle():
 
 
 @pytest.mark.parametrize("precision,tol", [("f32", 2e-5), ("f16pair", 2e-5), ("f16", 2e-3)])
-@pytest.mark.parametrize("name,full", [("codec_hf.npz", False), ("codec_hf_full.npz", True)])
-def test_dac_decode_directly_against_the_hf_fixtures(golden, name, full, precision, tol):
+def test_dac_decode_directly_against_the_hf_fixture(golden, precision, tol, name="codec_hf_full.npz", full=True):
     """`vaura_dac_decode` against waveforms an INDEPENDENT implementation of DAC-44k produced (transformers' `DacModel`, weights
     folded from the same synthetic DAC-1.0.0-keyed state dict: tests/golden/make_golden.py codec / codec_full), with no hop through
     oracle/dac_oracle.py.  Not the reference's own dependency (descript-audio-codec 1.0.0 is absent offline: a16 stays
     parity-unpinned), but it removes the oracle from between the HIP codec and the only external vectors this image can make.
-    Reduced width (decoder_dim from the fixture) and the 44.1 kHz model's full width."""
+    The 44.1 kHz model's full width (the HIP kernels' tile shapes are built for it; the reduced-width fixture is the CPU suite's)."""
     g = golden(name)
     ccfg = synth.FULL_CODEC if full else synth.CodecCfg(decoder_dim=int(g["decoder_dim"]), decoder_rates=(8, 8, 4, 2))
     sd = synth.codec_state_dict(ccfg, seed=int(g["codec_seed"]))
