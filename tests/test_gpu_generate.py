@@ -1227,10 +1227,10 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     f12 = synth.video_features(2 * clips, seed=104).to(DEV)
     out = {}
     try:
-        # the default (w1||w3 -> w2 -> next layer's qkv in one launch) | + attention and wo in one launch (experiment) | qkv separate |
-        # the three-phase tail experiment | every GEMV and the attention their own launches
-        # ... | (round 5, experiment) the default WITH the next layer's attention as the launch's fourth phase (second flag word, bit 2)
-        for flags in (0, 0x1000, 0x2, 8, 4, (0, 4)):
+        # the default (w1||w3 -> w2 -> next layer's qkv in one launch) | qkv separate | every GEMV and the attention their own launches.
+        # (The three measured-negative engines — attention + wo, the layer tail, the attention as a fourth phase — left the product
+        # library in round 6: experiment builds only, `tools/experiment.sh engines`; their bit-identity records are in DESIGN_HISTORY.md.)
+        for flags in (0, 0x2, 4):
             f1, f2 = flags if isinstance(flags, tuple) else (flags, 0)
             L.lib().vaura_set_debug_flags(f1)
             L.lib().vaura_set_debug_flags2(f2)
@@ -1246,7 +1246,7 @@ def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
         eng._free_graph()
     torch.cuda.synchronize()
     assert torch.isfinite(out[4][0]).all()
-    for flags in (0, 0x1000, 0x2, 8, (0, 4)):
+    for flags in (0, 0x2):
         assert torch.equal(out[flags][0], out[4][0]), (flags, float((out[flags][0] - out[4][0]).abs().max()))
         for i in (1, 2, 3):
             assert torch.equal(out[flags][i], out[4][i]), (flags, i)

@@ -9,6 +9,9 @@
 #                                       ALLWAVES=1: every wave records — perturbs heavily)
 #   lib-ab [tags ..]                    whole 228-step loops on experiment builds (`python -m vaura_amd.csrc.build --tag T -DX=..` -> libvaura_hip_T.so) next to the
 #                                       product library, two rounds, both storages
+#   engines [rounds]                    the three measured-negative engines (attention + wo: flag 4096; the layer tail: flag 8; the attention as a fourth
+#                                       phase of the one-launch MLP: 0:4), which live in experiment builds only since round 6: builds
+#                                       libvaura_hip_engines.so (-DVAURA_EXPERIMENT_ENGINES=1) and times whole loops per flag set on it
 #   graph-steps                         decode steps per graph launch (debug flag bits 24..27): 1 / 4 / 12, alternating
 #   chains                              the batch as 2 / 4 independent decode chains on separate streams against one chain of all rows
 #   plain-stores                        write-through output stores (product) against ordinary ones (build --plain-stores), alternating
@@ -57,6 +60,13 @@ stamps)
     python3 tools/engine_stamps.py $OUT/st_${w}_$f.bin | tee $OUT/stamps_${w}_f$f.txt
     rm -f $OUT/st_${w}_$f.bin
   done; done ;;
+engines)
+  pmc_driver
+  python3 -m vaura_amd.csrc.build --tag engines -DVAURA_EXPERIMENT_ENGINES=1 || exit 1
+  for w in h2 h1; do
+    echo "== weights $w (libvaura_hip_engines.so)"
+    timeout 600 /tmp/pmc_driver vaura_amd/csrc/libvaura_hip_engines.so --time ${1:-3} --flags 0,4096,8,0:4 --weights $w 2>&1 | grep "flags\|host enqueue" | tee -a $OUT/engines.log
+  done ;;
 lib-ab)
   pmc_driver
   for w in h2 h1; do for rep in 1 2; do for t in "" "$@"; do

@@ -122,18 +122,18 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
   // ... and the NEXT layer's qkv GEMV as a third phase of that launch
   const bool fuse_qkv = mlp_engine && qkv2 && !(va_debug_flags_get() & 0x2u);   // debug flag bit 1: qkv stays its own launch
   bool qkv_done = false;                     // layer l's qkv partials were written by layer l - 1's engine launch
-  // EXPERIMENT (debug flag bit 12): attention + wo as one launch too (csrc/attention.hip attn_wo_kernel; single-round-trip attention
-  // only: cache <= 256 positions, 16 heads).  Bit-identical and measured SLOWER than the two launches (13.7 us against 7.05 + 0.7 +
-  // 4.8: the loop +3.3 % two planes / +3.8 % one): wo's stream is 1.5 us, nothing a run-ahead could hide pays for the hand-off.
+  // EXPERIMENT builds only (-DVAURA_EXPERIMENT_ENGINES; DESIGN_HISTORY.md rounds 4-5, all bit-identical and measured slower or no
+  // faster): debug flag bit 12 = attention + wo as one launch, bit 3 = the whole layer tail as one launch, second flag word bit 2 = the
+  // next layer's attention as a fourth phase of the one-launch MLP.  The product library compiles none of them.
+#ifdef VAURA_EXPERIMENT_ENGINES
   const bool attn_wo = mlp_engine && rows <= 16 && H == 16 && d->max_len <= 256 && (va_debug_flags_get() & 0x1000u) && !(va_debug_flags_get() & 8u) &&
                        d->plane_shift == 0;   // the experiments' own attention epilogues store unscaled planes
-  // EXPERIMENT (second flag word, bit 2): that layer's ATTENTION as the launch's fourth phase too (16 heads of 96, single-round-trip
-  // attention: cache <= 256, one row block; csrc/mlp_engine.h ATT instances).  Bit-identical, and measured SLOWER than the separate
-  // launch (round 5: the loop 204.2 -> 207.8 ms two planes, 163.4 -> 176.4 ms one): the serial chain behind the qkv products — drain,
-  // flag, poll, the q / k / v quads' round trip, two barriers of softmax arithmetic — is as long inside the launch as the kernel
-  // boundary it replaces, and the K / V rows were already hidden under that chain in the separate kernel.  Off by default.
   const bool fuse_attn = fuse_qkv && rows <= 16 && H == 16 && hd == 96 && d->max_len <= 256 && d->ws_attn_split && !attn_wo && d->plane_shift == 0 &&
                          !(va_debug_flags_get() & 8u) && (va_debug_flags2_get() & 4u);
+  const bool tail_engine = mlp_engine && rows <= 16 && (va_debug_flags_get() & 8u);
+#else
+  constexpr bool attn_wo = false, fuse_attn = false;
+#endif
   bool attn_done = false;                    // layer l's attention was computed by layer l - 1's engine launch
   for (int l = 0; l < m.n_layer; ++l) {
     const vaura_layer_weights& L = d->layers_host[l];
@@ -147,17 +147,19 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
       if (rc) return rc;
     }
     qkv_done = false;
+#ifdef VAURA_EXPERIMENT_ENGINES
     const Gemv3Args awo0 = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
+#endif
     if (attn_done) {
       attn_done = false;                     // (computed by the previous layer's one-launch MLP)
+#ifdef VAURA_EXPERIMENT_ENGINES
     } else if (attn_wo) {
-      // attention + wo as ONE launch (csrc/attention.hip attn_wo_kernel): wo's weights stream under the attention, the attention's
-      // planes are handed over inside the launch; booked under the attention kind by the per-launch profiler
       PROF_B(VAURA_K_ATTN);
       rc = va_launch_attn_wo(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn, d->ws_attn_split,
                              rows, H, d->max_len, d->state, awo0, d->ws_sync + 512, l, s);
       PROF_A(VAURA_K_ATTN);
       if (rc) return rc;
+#endif
     } else {
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
     rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
@@ -168,11 +170,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
     if (rc) return rc;
     }
     const Gemv3Args awo = g3(L.wo, d->ws_attn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, L.ffn_norm, d->ws_ss, d, D);
-    if (mlp_engine && rows <= 16 && (va_debug_flags_get() & 8u)) {
-      // EXPERIMENT (debug flag bit 3): the whole layer TAIL as one launch — wo + residual -> hand-off -> w1||w3 + SwiGLU -> hand-off
-      // -> w2 + residual (csrc/mlp_engine.h tail_engine_kernel).  Bit-identical, and measured no faster than wo + the two-phase
-      // engine (two planes -0.5 %, one plane +1.5 % on the loop): the first hand-off costs what wo's kernel boundary costs, and
-      // w1||w3's stream is HBM-bound wherever it starts.  The default stays wo as its own launch.
+#ifdef VAURA_EXPERIMENT_ENGINES
+    if (tail_engine) {
       PROF_B(VAURA_K_W13);
       rc = va_launch_tail_engine(awo, g3(L.w13, d->ws_h_split, d->ws_ss, nullptr, nullptr, d->ws_ffn_split, nullptr, nullptr, d, F),
                                  g3(L.w2, d->ws_ffn_split, nullptr, d->ws_h, d->ws_h, d->ws_h_split, next_attn_gain, d->ws_ss, d, D),
@@ -181,6 +180,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
       if (rc) return rc;
       continue;
     }
+#endif
     if (!attn_wo) {
       PROF_B(VAURA_K_WO);    // h += Wo.attn ; emit split(h * ffn_norm) + ss               llama.py:259, 279
       rc = va_launch_gemv3(awo, D, D, E3_RESID, false, s);

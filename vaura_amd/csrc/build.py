@@ -12,6 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["gemv.hip", "gemv3.hip", "attention.hip", "step.hip", "api.hip", "dac.hip", "post.hip", "vit.hip"]
 HEADERS = ["common.h", "gemv_kernel.h", "gemv3_kernel.h", "mlp_engine.h", os.path.join("..", "..", "include", "vaura_hip.h")]
+# csrc/experiments/*.h (the measured-negative engines of rounds 4-5) are compiled only with -DVAURA_EXPERIMENT_ENGINES=1:
+#   python -m vaura_amd.csrc.build --tag engines -DVAURA_EXPERIMENT_ENGINES=1   -> libvaura_hip_engines.so (never loaded by the package)
 LIB = os.path.join(HERE, "libvaura_hip.so")
 # diagnostic build (--stamps): the same sources with -DVAURA_STAMPS (in-kernel s_memrealtime stamps, common.h); never loaded by the
 # package, only by tools/pmc_driver --stamps

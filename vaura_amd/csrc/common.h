@@ -201,6 +201,7 @@ struct VaEngineAttention {     // the next layer's attention as a fourth phase o
 };
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq_next, uint32_t* flags, int32_t* state, int layer,
                          hipStream_t s, const VaEngineAttention* att = nullptr);
+// experiment builds only (-DVAURA_EXPERIMENT_ENGINES: csrc/experiments/)
 int va_launch_attn_wo(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out, uint16_t* outp,
                       int rows, int n_head, int max_len, const int32_t* state, const Gemv3Args& awo, uint32_t* flags, int layer, hipStream_t s);
 int va_launch_tail_engine(const Gemv3Args& awo, const Gemv3Args& a13, const Gemv3Args& a2, uint32_t* flags, int32_t* state, int layer,

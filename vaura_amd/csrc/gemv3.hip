@@ -286,11 +286,16 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
     if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 2>(e, s) : launch_mlp_engine_t<0, true, 2>(e, s);
     return a13.wq == 2 ? launch_mlp_engine_t<2, false, 2>(e, s) : launch_mlp_engine_t<0, false, 2>(e, s);
   }
+#ifdef VAURA_EXPERIMENT_ENGINES
   if (att) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 1, true>(e, s) : launch_mlp_engine_t<0, true, 1, true>(e, s);
+#else
+  if (att) return VAURA_ERR_STATE;       // the attention phase exists in experiment builds only (DESIGN_HISTORY.md round 5)
+#endif
   if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true>(e, s) : launch_mlp_engine_t<0, true>(e, s);
   return a13.wq == 2 ? launch_mlp_engine_t<2, false>(e, s) : launch_mlp_engine_t<0, false>(e, s);
 }
 
+#ifdef VAURA_EXPERIMENT_ENGINES
 template <int WT>
 static int launch_tail_engine_t(const TailEngineArgs& e, hipStream_t s) {
   using SH = MlpEngineShape<WT>;
@@ -317,6 +322,7 @@ int va_launch_tail_engine(const Gemv3Args& awo, const Gemv3Args& a13, const Gemv
   e.abl = (int)((va_debug_flags >> 28) & 15u);
   return a13.wq == 2 ? launch_tail_engine_t<2>(e, s) : launch_tail_engine_t<0>(e, s);
 }
+#endif
 
 // ---------------------------------------------------------------------------- fp16-plane weight ingress
 // power-of-two row scale 2^E with amax / 2^E in [2^13, 2^14): both planes of a weight of ordinary size are normal fp16 numbers
