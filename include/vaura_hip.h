@@ -55,10 +55,14 @@ typedef enum vaura_status {
  *   VAURA_W_H1  one fp16 plane + row scales, 2 bytes per weight: lossless for checkpoints whose weights fit 11 significand
  *               bits (bf16-representable ones: 8)
  *   VAURA_W_FP8 (BASELINE configs[4]; no reference counterpart): OCP e4m3 with one power-of-two scale per output row, for the
- *               four per-layer matrices; heads stay VAURA_W_H1
+ *               four per-layer matrices; heads stay VAURA_W_H1.  Multiplied against BOTH activation planes: exactly the H1
+ *               arithmetic on the dequantised checkpoint (tested as such)
+ *   VAURA_W_FP8H (round 6, configs[4]'s measured configuration): the SAME packed bytes as VAURA_W_FP8, multiplied against the hi
+ *               activation plane only (11-bit activations under 4-bit-significand weights): half the plane bytes through every CU,
+ *               half the matrix instructions; tolerance against VAURA_W_FP8 / H1 reported by the tests and bench.py, not bit parity
  *   VAURA_W_F32 / VAURA_W_BF16: fp32 / bf16 MFMA tiles of the exact-fp32-MFMA GEMVs (gemv_kernel.h): the conditioning MLP, and
  *               the decode step when the split workspaces are NULL (an exact, slower cross-check)                        */
-typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1, VAURA_W_FP8 = 2, VAURA_W_H1 = 3, VAURA_W_H2 = 4 } vaura_wdtype;
+typedef enum vaura_wdtype { VAURA_W_F32 = 0, VAURA_W_BF16 = 1, VAURA_W_FP8 = 2, VAURA_W_H1 = 3, VAURA_W_H2 = 4, VAURA_W_FP8H = 5 } vaura_wdtype;
 
 /* ---- model geometry: configs/modules/samplers/llama_9cbs.yaml:3-17 + sampler/llama.py:308-361 */
 typedef struct vaura_dims {

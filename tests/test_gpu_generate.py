@@ -714,6 +714,45 @@ def test_configs4_per_gpu_shape_fp8_weights_and_mx8_codec(full_sampler_sd):
     assert torch.isfinite(wav_mx8).all() and rms <= 0.25 * sig, (rms, sig)
 
 
+def test_fp8h_hi_plane_activations_tolerance_against_fp8_and_bf16(full_sampler_sd):
+    """Round 6, configs[4]'s measured storage "fp8h": the fp8 matrices multiplied against the HI activation plane only (11-bit
+    activations; csrc/gemv3_kernel.h WT = 3) — a narrower arithmetic than "fp8" (which is the one-plane engine on the dequantised
+    checkpoint, token-exact against the oracle there), so its tolerance is REPORTED, as configs[4] demands ("tol vs bf16 reported"),
+    and bounded loosely.  Full depth, configs[4]'s per-GPU shape (16 clips, cfg 6 -> 32 rows): (1) teacher-forced logits of "fp8h"
+    against "fp8" (same weights: what the dropped lo plane costs) and against "h1" (the bf16 model: what fp8 weights cost — the
+    dominant term by two orders of magnitude); (2) greedy cfg-6 token agreement with "fp8" over 220 frames; (3) in range, status clean."""
+    cfg = synth.FULL_SAMPLER
+    B = 16
+    feats = synth.video_features(B, seed=15).to(DEV)
+    out = {}
+    for wd in ("fp8h", "fp8", "h1"):
+        eng = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype=wd)
+        tok = eng.generate_codes(feats, 220, cfg_scale=6.0).cpu()
+        eng.check_status()
+        if wd == "fp8h":
+            assert eng.rows == 32 and int(tok.min()) >= 0 and int(tok.max()) < 1024
+            idx = tok[:2, :, :40].contiguous().to(DEV)
+        lg = eng.logits_all_positions(idx, feats[:2]).cpu()
+        out[wd] = (tok, lg)
+        del eng
+        torch.cuda.empty_cache()
+    def rel(a, b):
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    r_h8 = rel(out["fp8h"][1], out["fp8"][1])
+    r_h16 = rel(out["fp8h"][1], out["h1"][1])
+    r_816 = rel(out["fp8"][1], out["h1"][1])
+    mx = float((out["fp8h"][1] - out["fp8"][1]).abs().max())
+    top1 = float((out["fp8h"][1].argmax(-1) == out["fp8"][1].argmax(-1)).float().mean())
+    agree = float((out["fp8h"][0] == out["fp8"][0]).float().mean())
+    steps = torch.arange(220)[None, :] + 1 + torch.arange(9)[:, None]
+    first = [int(steps[out["fp8h"][0][b] != out["fp8"][0][b]].min()) if not torch.equal(out["fp8h"][0][b], out["fp8"][0][b]) else 229 for b in range(B)]
+    print(f"fp8h vs fp8 (same weights, hi activation plane only): logits rel-RMS {r_h8:.3e}, max abs {mx:.3e}, top-1 agreement {top1:.4f}; "
+          f"greedy cfg-6 tokens over 220 frames: agreement {agree:.4f}, clips identical {sum(f == 229 for f in first)}/{B}, earliest "
+          f"first difference at step {min(first)}; vs the bf16 model: fp8h {r_h16:.3e}, fp8 {r_816:.3e}")
+    assert r_h8 < 0.02 * r_816 + 2e-3 and r_h16 < 1.05 * r_816 + 1e-3      # the lo plane is noise under the fp8 weights' own error
+    assert top1 > 0.97
+
+
 def test_configs4_full_depth_first_frames_against_the_oracle_on_the_dequantised_checkpoint(full_sampler_sd):
     """The full-depth fp8 claim against the ORACLE, not only HIP-vs-HIP: configs[4]'s per-GPU shape (16 clips, cfg 6 -> 32 rows,
     24 layers, e4m3 weights) greedy, against the CPU oracle run on the dequantised checkpoint (`quant.fp8_effective_state_dict`:
@@ -797,7 +836,7 @@ def test_headline_configuration_h2_cfg6_topk250_B8_matches_reference(golden, ful
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("wdtype", ["h2", "h1", "fp8"])
+@pytest.mark.parametrize("wdtype", ["h2", "h1", "fp8", "fp8h"])
 def test_two_row_blocks_per_weight_pass_are_bit_identical_to_the_walk(wdtype):
     """17..32 decoder rows (the reference's default batch 16 under CFG, configs/generate_vgg.yaml:41 + :27; BASELINE configs[4]): every
     GEMV takes BOTH row blocks per weight fragment (gemv3_kernel / gemv3h_kernel RBK = 2: second accumulator set, one reduction
@@ -1204,7 +1243,7 @@ def test_heavy_tailed_checkpoint_rows_against_live_oracle(wdtype):
 
 
 @pytest.mark.parametrize("clips", [6, 3, 16, 10])
-@pytest.mark.parametrize("wdtype", ["h2", "h1", "fp8"])
+@pytest.mark.parametrize("wdtype", ["h2", "h1", "fp8", "fp8h"])
 def test_one_launch_mlp_is_bit_identical_to_two_launches(wdtype, clips):
     """csrc/mlp_engine.h, the default where eligible: the MLP of a layer (w1||w3 + SwiGLU -> w2 + residual) as ONE launch with an
     in-launch hand-off, w2's weights requested ahead of it (debug flag bit 2: every GEMV its own launch; bit 3: the experimental

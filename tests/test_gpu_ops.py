@@ -116,14 +116,17 @@ SPLIT_GEMV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("wdtype", [L.W_H1, L.W_H2, L.W_FP8])
+@pytest.mark.parametrize("wdtype", [L.W_H1, L.W_H2, L.W_FP8, L.W_FP8H])
 @pytest.mark.parametrize("K,N,epi,norm,rows", SPLIT_GEMV_CASES)
 def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
     """vaura_gemv_pair: activations as (hi, lo) fp16 planes (22 significand bits), weights as one fp16 plane (a
     bf16-representable matrix: held exactly), two planes (an fp32 matrix: 22 bits) or fp8, fused RMSNorm via partial sums of
     squares, optional split / sum-of-squares outputs for the next kernel.  Checked against the fp64 product on the matrix the
     storage HOLDS (engine.h_effective_weight / quant.fp8_effective_weight) and, for two planes, also on the fp32 matrix itself:
-    the tolerance there is what 22-bit operands cost (2^-22 per product, averaged over K)."""
+    the tolerance there is what 22-bit operands cost (2^-22 per product, averaged over K).  VAURA_W_FP8H (round 6): the fp8 matrix
+    against the HI activation plane only — the reference is the fp64 product of the fp16-ROUNDED activation (x * gain) with the
+    dequantised matrix, at the same 3e-6 (the decode instances: fewer than 16 row blocks; a prompt-sized GEMM of that storage
+    multiplies both planes)."""
     from vaura_amd import quant
     from vaura_amd.engine import h_effective_weight
     g = torch.Generator().manual_seed(K + N + epi + rows + 1)
@@ -139,7 +142,8 @@ def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
         w = torch.stack([w[:F_].view(F_ // 16, 16, K), w[F_:].view(F_ // 16, 16, K)], dim=1).reshape(N, K)
     if wdtype == L.W_H1:
         w = synth.to_bf16_exact(w)
-    w_eff = quant.fp8_effective_weight(w) if wdtype == L.W_FP8 else h_effective_weight(w, 1 if wdtype == L.W_H1 else 2)
+    w_eff = quant.fp8_effective_weight(w) if wdtype in (L.W_FP8, L.W_FP8H) else h_effective_weight(w, 1 if wdtype == L.W_H1 else 2)
+    hi_only = wdtype == L.W_FP8H and (rows + 15) // 16 < 16
     if wdtype == L.W_H1:
         assert torch.equal(w_eff, w)          # one plane holds a bf16-representable matrix exactly
     # the producer's side of the fused norm: x*gain travels as planes, sum(x^2) as per-tile partials
@@ -147,6 +151,9 @@ def test_split_row_gemv_variants(K, N, epi, norm, rows, wdtype):
     xs, ss = ops.split_rows(ops.pack_rows(xd), rows, K, gain.to(DEV) if norm else None, want_ss=norm)
     x64 = x.double()
     xn = x64 if gain is None else (x64 * gain.double()) * torch.rsqrt(torch.mean(x64 * x64, dim=-1, keepdim=True) + eps)
+    if hi_only:      # the plane the consumer reads: fp16(x * gain) as the producer wrote it; rinv multiplies the sum afterwards
+        xg = (x if gain is None else x * gain).half().double()
+        xn = xg if gain is None else xg * torch.rsqrt(torch.mean(x64 * x64, dim=-1, keepdim=True) + eps)
     y = xn @ w_eff.double().t()
     if epi == L.EPI_SWIGLU:
         yv = y.view(rows, N // 32, 2, 16)

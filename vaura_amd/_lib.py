@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvaura_hip.so")
 
-W_F32, W_BF16, W_FP8, W_H1, W_H2 = 0, 1, 2, 3, 4
+W_F32, W_BF16, W_FP8, W_H1, W_H2, W_FP8H = 0, 1, 2, 3, 4, 5
 EPI_STORE, EPI_RESID, EPI_SWIGLU, EPI_GELU, EPI_LOGITS = 0, 1, 2, 3, 4
 KERNEL_KINDS = ("embed", "qkv", "attn", "wo", "w13", "w2", "heads", "sample")
 

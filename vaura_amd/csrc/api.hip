@@ -57,7 +57,8 @@ static Gemv3Args g3(const void* W, const uint16_t* xp, const float* ss_in, const
   Gemv3Args a;
   // VAURA_W_FP8: the four per-layer matrices are fp8; the codebook heads (final logits) stay one fp16 plane.
   // VAURA_W_H2: (hi, lo) fp16 planes — the A operands as loaded
-  a.wq = d->wdtype == VAURA_W_H2 ? 2 : ((d->wdtype == VAURA_W_FP8 && W != d->heads) ? 1 : 0);
+  // VAURA_W_FP8H: those fp8 matrices multiplied against the hi activation plane only (wq 3; the heads keep both planes)
+  a.wq = d->wdtype == VAURA_W_H2 ? 2 : ((va_is_fp8(d->wdtype) && W != d->heads) ? (d->wdtype == VAURA_W_FP8H ? 3 : 1) : 0);
   a.wscale = nullptr; a.out2 = nullptr;
   a.W = W; a.XP = xp; a.ss_in = ss_in; a.n_ss_in = d->dims.d_model / 16; a.res = res; a.out = out; a.outp = outp;
   a.gain_out = gain_out; a.ss_out = ss_out;
@@ -235,7 +236,7 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
 
 static int enqueue_step(const vaura_decoder* d, const vaura_sampling* sp, int sample, hipStream_t s) {
   // H1 / H2 / FP8: the pair path; F32 / BF16 tiles: the exact-fp32-MFMA GEMVs (gemv_kernel.h)
-  if (d->wdtype == VAURA_W_H1 || d->wdtype == VAURA_W_H2 || d->wdtype == VAURA_W_FP8) return enqueue_step_bf16(d, sp, sample, s);
+  if (d->wdtype == VAURA_W_H1 || d->wdtype == VAURA_W_H2 || va_is_fp8(d->wdtype)) return enqueue_step_bf16(d, sp, sample, s);
   if (d->wdtype != VAURA_W_F32 && d->wdtype != VAURA_W_BF16) return VAURA_ERR_DTYPE;
   const vaura_dims& m = d->dims;
   const int D = m.d_model, F = m.ffn_dim, H = m.n_head, hd = D / H;

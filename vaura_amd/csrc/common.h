@@ -185,6 +185,7 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
                         float* part, int n_split, hipStream_t s, uint32_t* arrivals = nullptr, float pscale = 1.f);
 struct Gemv3Args;
+static inline bool va_is_fp8(int wdtype) { return wdtype == VAURA_W_FP8 || wdtype == VAURA_W_FP8H; }   // e4m3 tile pairs (both activation arithmetics)
 unsigned va_debug_flags2_get();  // vaura_set_debug_flags2: the second word
 unsigned va_debug_flags_get();   // vaura_set_debug_flags (gemv3.hip): kernel-variant switches for A/B measurements
 int va_pack_weight_fp8(const float* src, void* dst, int64_t N, int64_t K, hipStream_t s);

@@ -117,14 +117,14 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, float* __restric
 extern "C" {
 
 size_t vaura_packed_weight_bytes(int64_t N, int64_t K, int wdtype) {
-  if (wdtype == VAURA_W_FP8) return (size_t)N * (size_t)K + (size_t)N * sizeof(float);   // tile pairs + row scales
+  if (va_is_fp8(wdtype)) return (size_t)N * (size_t)K + (size_t)N * sizeof(float);   // tile pairs + row scales
   if (wdtype == VAURA_W_H1 || wdtype == VAURA_W_H2) return (size_t)N * (size_t)K * (wdtype == VAURA_W_H1 ? 2 : 4) + (size_t)N * sizeof(float);
   return (size_t)N * (size_t)K * (wdtype == VAURA_W_BF16 ? 2 : 4);
 }
 
 int vaura_pack_weight(const float* src, void* dst, int64_t N, int64_t K, int wdtype, vaura_stream_t s) {
   if (!src || !dst || N <= 0 || K <= 0 || (N % 16) || (K % 32)) return VAURA_ERR_ARG;
-  if (wdtype == VAURA_W_FP8) return va_pack_weight_fp8(src, dst, N, K, as_stream(s));
+  if (va_is_fp8(wdtype)) return va_pack_weight_fp8(src, dst, N, K, as_stream(s));
   if (wdtype == VAURA_W_H1 || wdtype == VAURA_W_H2) return va_pack_weight_h(src, dst, N, K, wdtype == VAURA_W_H1 ? 1 : 2, as_stream(s));
   const int64_t total = (N / 16) * (K / 32) * 64;
   const unsigned blocks = (unsigned)((total + 255) / 256);

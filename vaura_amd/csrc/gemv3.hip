@@ -59,15 +59,15 @@ static int dispatch3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue,
   // two weight planes are 8 bytes per lane and k-group: two-tile workgroups take weights and planes in three batches (two in
   // flight) like the K = 4096 instances their four, so that the slice a wave holds fits the register file without spills
   constexpr int XB2 = WT == 2 ? 3 : 1, XB4 = 4;
-  if constexpr (WT == 1) {   // fp8 tile pairs (round 5): with 17..32 rows the residual GEMVs on the row-split pair kernel too — one workgroup
+  if constexpr (WT == 1 || WT == 3) {   // fp8 tile pairs (round 5; 3 = against the hi activation plane only, round 6): with 17..32 rows the residual GEMVs on the row-split pair kernel too — one workgroup
     // per tile takes in BOTH row blocks' planes (524 KB at K = 4096 next to 65 KB of weights): 217.5 -> 214.7 ms on the 32-row loop;
     // at 16 rows the one-workgroup-per-tile kernels stay (162.3 against 164.8 ms).  Second flag word, bit 3: never (the A/B)
     if (a.R >= 2 && !norm && !(va_debug_flags & 1u) && !(va_debug_flags2 & 8u) && tiles % 8 == 0 && epilogue == E3_RESID) {
-      if (K == 1536) return launch3h<1, 3, E3_RESID, 1, 2, 8, true>(a, tiles, s);
-      if (K == 4096) return launch3h<1, 8, E3_RESID, 1, 2, 8, true>(a, tiles, s);
+      if (K == 1536) return launch3h<WT, 3, E3_RESID, 1, 2, 8, true>(a, tiles, s);
+      if (K == 4096) return launch3h<WT, 8, E3_RESID, 1, 2, 8, true>(a, tiles, s);
     }
   }
-  if constexpr (WT != 1) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
+  if constexpr (WT != 1 && WT != 3) {   // narrow outputs without a fused norm (wo, w2): two workgroups per tile, 8 rows each
     if (!norm && !(va_debug_flags & 1u) && tiles % 8 == 0 && (epilogue == E3_RESID || epilogue == E3_STORE)) {
       if (K == 1536 && epilogue == E3_RESID) return launch3h<WT, 3, E3_RESID, 1, 2, 8, true>(a, tiles, s);
       if (K == 1536 && epilogue == E3_STORE) return launch3h<WT, 3, E3_STORE, 1>(a, tiles, s);
@@ -100,7 +100,7 @@ static int launch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_
   const bool pf2 = !(va_debug_flags & 0x10000u) && (K / 32) % 2 == 0;     // bit 16: one weight k-group in flight
   const int gy = big ? gy8 : gy4;
   const dim3 grid((unsigned)(gx * gy)), block(G3M_NW * 64);
-  if (a.wq == 1) {
+  if (a.wq == 1 || a.wq == 3) {      // (a prompt pass of the hi-plane-only fp8 storage multiplies both planes: the exact fp8 arithmetic)
     if (big) VA_LAUNCH((gemm3_kernel<EPI, NORM, 1, 8>), grid, block, 0, s, a, (int)K, gx, gy, remap);
     else VA_LAUNCH((gemm3_kernel<EPI, NORM, 1>), grid, block, 0, s, a, (int)K, gx, gy, remap);
   } else if (a.wq == 2) {
@@ -181,7 +181,7 @@ static int launch_gemm4(const Gemv3Args& a, int64_t tiles, int64_t K, hipStream_
 
 // many row blocks (a prompt being teacher-forced): GEMM tiling instead of the register-resident GEMV loop
 static int dispatch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, int epilogue, bool norm, hipStream_t s) {
-  if (a.wq != 1 && !(va_debug_flags & 0x20000u)) {     // debug flag bit 17: the register-staged gemm3_kernel for every storage
+  if (a.wq != 1 && a.wq != 3 && !(va_debug_flags & 0x20000u)) {     // debug flag bit 17: the register-staged gemm3_kernel for every storage
     if (epilogue == E3_STORE && norm) return launch_gemm4<E3_STORE, true>(a, tiles, K, s);
     if (epilogue == E3_STORE && !norm) return launch_gemm4<E3_STORE, false>(a, tiles, K, s);
     if (epilogue == E3_RESID && !norm) return launch_gemm4<E3_RESID, false>(a, tiles, K, s);
@@ -199,7 +199,7 @@ static int dispatch_gemm3(const Gemv3Args& a, int64_t tiles, int64_t K, int epil
 
 // bytes of one weight element by storage (a.wq): one fp16 plane 2, fp8 1, two fp16 planes 4; float scale[N] follows the tiles
 static const float* weight_scales(const Gemv3Args& a, int64_t n_weight_rows, int64_t K) {
-  const size_t per = a.wq == 1 ? 1 : (a.wq == 2 ? 4 : 2);
+  const size_t per = (a.wq == 1 || a.wq == 3) ? 1 : (a.wq == 2 ? 4 : 2);
   return reinterpret_cast<const float*>(static_cast<const char*>(a.W) + (size_t)n_weight_rows * (size_t)K * per);
 }
 
@@ -212,6 +212,7 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   if (a.out2) {   // the caller asked for two K-half partials (decode qkv): fused norm, K = 1536 only
     if (K != 1536 || epilogue != E3_STORE || !norm || a.R >= 16) return VAURA_ERR_SHAPE;
     if (a.wq == 1) return launch3<1, 6, 4, 3, E3_STORE, true, 1, 2, true>(a, tiles, s);   // fp8 tile pairs hold two k-groups per lane: 4 waves x 6 groups per K half
+    if (a.wq == 3) return launch3<3, 6, 4, 3, E3_STORE, true, 1, 2, true>(a, tiles, s);
     if (a.wq == 2) return launch3<2, 3, 8, 3, E3_STORE, true, 1, 2, true, 3>(a, tiles, s);
     return launch3<0, 3, 8, 3, E3_STORE, true, 1, 2, true>(a, tiles, s);
   }
@@ -219,6 +220,7 @@ int va_launch_gemv3(const Gemv3Args& a0, int64_t n_weight_rows, int64_t K, int e
   // step of a large batch (R = 2..15 row blocks) keeps the weight-stationary GEMV loop and its N/(16 T) workgroups
   if (a.R >= 16 && (K == 1536 || K == 4096) && tiles % (G3M_NW * G3M_T) == 0) return dispatch_gemm3(a, tiles, K, epilogue, norm, s);
   if (a.wq == 1) return dispatch3<1>(a, tiles, K, epilogue, norm, s);
+  if (a.wq == 3) return dispatch3<3>(a, tiles, K, epilogue, norm, s);
   if (a.wq == 2) return dispatch3<2>(a, tiles, K, epilogue, norm, s);
   return dispatch3<0>(a, tiles, K, epilogue, norm, s);
 }
@@ -232,7 +234,7 @@ bool va_mlp_engine_eligible(const vaura_decoder* d) {
   if (!d->ws_sync || !d->state || d->rows < 1 || d->rows > 32) return false;
   if (d->rows > 16 && (va_debug_flags2 & 2u)) return false;          // second flag word, bit 1: 17..32 rows keep the separate launches
   // fp8 tile pairs (round 5): the two-row-block instances only (17..32 rows: configs[4]'s per-GPU shape); second flag word, bit 4: no
-  if (d->wdtype == VAURA_W_FP8) { if (d->rows <= 16 || (va_debug_flags2 & 16u)) return false; }
+  if (va_is_fp8(d->wdtype)) { if (d->rows <= 16 || (va_debug_flags2 & 16u)) return false; }
   else if (d->wdtype != VAURA_W_H1 && d->wdtype != VAURA_W_H2) return false;
   if (d->dims.d_model != 1536 || d->dims.ffn_dim != 4096) return false;
   static int cus[64] = {};
@@ -275,7 +277,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
     e.p3.wscale = weight_scales(*aq, 3 * 1536, 1536);
   }
   if (!a13.W || !a13.XP || !a2.W || !a2.XP || !flags || !state || a13.R < 1 || a13.R > 2 || a2.R != a13.R) return VAURA_ERR_ARG;
-  if (a13.wq != a2.wq || a13.wq < 0 || a13.wq > 2 || (a13.wq == 1 && (a13.R != 2 || att)) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 ||
+  if (a13.wq != a2.wq || a13.wq < 0 || a13.wq > 3 || ((a13.wq == 1 || a13.wq == 3) && (a13.R != 2 || att)) || a13.N != 4096 || a2.N != 1536 || a13.k_total != 1536 ||
       a13.n_ss_in != 96) return VAURA_ERR_SHAPE;
   e.p1.wscale = weight_scales(a13, 2 * 4096, 1536);
   e.p2.wscale = weight_scales(a2, 1536, 4096);
@@ -283,6 +285,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
   if (a13.R == 2) {       // 17..32 decoder rows: both row blocks per weight fragment
     if (a13.wq == 1) return aq ? launch_mlp_engine_t<1, true, 2>(e, s) : launch_mlp_engine_t<1, false, 2>(e, s);
+    if (a13.wq == 3) return aq ? launch_mlp_engine_t<3, true, 2>(e, s) : launch_mlp_engine_t<3, false, 2>(e, s);
     if (aq) return a13.wq == 2 ? launch_mlp_engine_t<2, true, 2>(e, s) : launch_mlp_engine_t<0, true, 2>(e, s);
     return a13.wq == 2 ? launch_mlp_engine_t<2, false, 2>(e, s) : launch_mlp_engine_t<0, false, 2>(e, s);
   }
@@ -471,9 +474,9 @@ int vaura_gemv_pair(const void* w, int wdtype, const uint16_t* x_split, const fl
                     float* out_khalf2, uint16_t* out_split, const float* gain_out, float* ss_out, int64_t rows, int64_t N, int64_t K, int epilogue,
                     float eps, vaura_stream_t s) {
   if (!w || !x_split || rows <= 0) return VAURA_ERR_ARG;
-  if (wdtype != VAURA_W_H1 && wdtype != VAURA_W_FP8 && wdtype != VAURA_W_H2) return VAURA_ERR_DTYPE;
+  if (wdtype != VAURA_W_H1 && !va_is_fp8(wdtype) && wdtype != VAURA_W_H2) return VAURA_ERR_DTYPE;
   Gemv3Args a;
-  a.wq = wdtype == VAURA_W_FP8 ? 1 : (wdtype == VAURA_W_H2 ? 2 : 0); a.wscale = nullptr; a.out2 = out_khalf2;
+  a.wq = wdtype == VAURA_W_FP8H ? 3 : (wdtype == VAURA_W_FP8 ? 1 : (wdtype == VAURA_W_H2 ? 2 : 0)); a.wscale = nullptr; a.out2 = out_khalf2;
   a.W = w; a.XP = x_split; a.ss_in = ss_in; a.n_ss_in = n_ss_in; a.res = residual; a.out = out; a.outp = out_split;
   a.gain_out = gain_out; a.ss_out = ss_out; a.rows = (int)rows; a.R = (int)((rows + 15) / 16);
   a.N = (int)(epilogue == E3_SWIGLU ? N / 2 : N); a.eps = eps; a.k_total = (int)K; a.out_scale = 1.f;

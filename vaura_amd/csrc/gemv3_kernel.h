@@ -31,6 +31,16 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define VA_NPL 2   // activation planes
+// WT = storage tag of the kernels below: 0 one fp16 weight plane, 1 fp8 tile pairs, 2 (hi, lo) fp16 weight planes — all against BOTH
+// activation planes — and 3 (round 6, BASELINE configs[4]): fp8 tile pairs against the HI activation plane ONLY.  With 4-bit-significand
+// weights the lo plane (bits 12..22 of an activation) is far below the weights' own rounding, but it was half of what every CU takes
+// in: at 32 rows a phase-2 workgroup of the one-launch MLP read 524 KB of planes next to 65 KB of weights.  The planes keep their
+// layout (producers still write both); a WT = 3 consumer skips the lo plane's loads and products.
+template <int WT>
+struct WTag {
+  static constexpr bool FP8 = WT == 1 || WT == 3, F32 = WT == 2;
+  static constexpr int XPL = WT == 3 ? 1 : VA_NPL;        // activation planes a consumer loads and multiplies
+};
 
 enum { E3_STORE = 0, E3_RESID = 1, E3_SWIGLU = 2, E3_LOGITS = 4 };
 
@@ -111,9 +121,12 @@ __device__ __forceinline__ f16x8 fp8x8_to_f16(uint32_t a, uint32_t b) {
 // 2^-22 term wlo.xlo is dropped).  The accumulators are added smallest first, once, in the epilogue.
 template <int WT>
 __device__ __forceinline__ void mfma_group(const f16x8* wf /* 1 or 2 planes */, const u32x4* x2, f32x4* acc) {
-  const f16x8 x0 = __builtin_bit_cast(f16x8, x2[0]), x1 = __builtin_bit_cast(f16x8, x2[1]);
+  const f16x8 x0 = __builtin_bit_cast(f16x8, x2[0]);
   acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], x0, acc[0], 0, 0, 0);
-  acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], x1, acc[1], 0, 0, 0);
+  if constexpr (WT != 3) {      // WT = 3: the hi plane only (x2 has ONE element)
+    const f16x8 x1 = __builtin_bit_cast(f16x8, x2[1]);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0], x1, acc[1], 0, 0, 0);
+  }
   if constexpr (WT == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1], x0, acc[1], 0, 0, 0);
 }
 template <int WT>
@@ -214,7 +227,8 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   VA_STAMP(stamps, 0);                       // wave start
   a.W = Wq;
   a.XP = XPq;
-  constexpr bool FP8 = WT == 1, F32 = WT == 2;
+  constexpr bool FP8 = WTag<WT>::FP8, F32 = WTag<WT>::F32;
+  constexpr int XPL = WTag<WT>::XPL;
   static_assert(!FP8 || (G % 2 == 0 && (G / XB) % 2 == 0), "fp8 tile pairs hold two k-groups per lane");
   static_assert(KS == 1 || EPI == E3_STORE, "K-split partials are summed by the consumer: plain stores only");
   static_assert(!FP8 || (G * NW) % 2 == 0, "fp8 tile pairs: a K part must start on an even k-group");
@@ -286,13 +300,13 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
   // activation planes of the current batch of k-groups; the first batch of the NEXT row block is requested as soon as
   // the last MFMA of this one has been issued, so its round trip runs under the reduction / barrier / epilogue
   constexpr int NXB = XB > 1 ? 2 : 1;   // with several batches two are in flight (double buffer)
-  u32x4 xb[RBK][NXB][GB][VA_NPL];
+  u32x4 xb[RBK][NXB][GB][XPL];
   auto load_x1 = [&](int r, int rb, int b) {
     const int xl16 = rb * 16 + m < a.rows ? lane16 : 0x7ffffff0;      // (a row block past the last one: every lane out of range -> zeros)
 #pragma unroll
     for (int g = 0; g < GB; ++g)
 #pragma unroll
-      for (int p = 0; p < VA_NPL; ++p)
+      for (int p = 0; p < XPL; ++p)
         xb[r][b % NXB][g][p] = (ABL & 2) ? u32x4{(uint32_t)lane, 1u, 2u, 3u}
                                       : __builtin_amdgcn_raw_buffer_load_b128(
                                             xrs, xl16, (int)(((rb * VA_NPL + p) * (K / 8) * 16 + (kgo + w * G + b * GB + g) * 64) * 16), 0);
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3_kernel(const void* __restrict__
         for (int p = 0; p < NACC; ++p) acc[r][t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (first) {
       VA_STAMP(stamps, 1);                   // every request of the first batch issued
-      VA_WAIT_VM(GB * VA_NPL + (SS_DIRECT ? NSS : (NORM ? SSN : 0)));
+      VA_WAIT_VM(GB * XPL + (SS_DIRECT ? NSS : (NORM ? SSN : 0)));
       VA_STAMP(stamps, 2);                   // the weight tiles (HBM) have landed
       VA_WAIT_VM(0);
       VA_STAMP(stamps, 3);                   // the activation planes / partial sums (written by the previous kernel) have landed
@@ -508,9 +522,10 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   // WT = 1 (round 5): fp8 tile pairs.  One 1-KiB fragment holds BOTH k-groups of a pair (lane (n, k-octet): 8 bytes of the even
   // k-group, 8 of the odd one), so the A operand of lane (la, s, q) is an 8-byte load of half s of that fragment, widened to fp16 in
   // registers: the same products in the same order as the one-plane instance on the dequantised matrix.
-  static_assert(WT == 0 || WT == 1 || WT == 2, "one or two fp16 weight planes, or fp8 tile pairs");
+  static_assert(WT >= 0 && WT <= 3, "one or two fp16 weight planes, or fp8 tile pairs (3: against the hi activation plane only)");
   static_assert(EPI == E3_RESID || EPI == E3_STORE, "independent output tiles only");
-  constexpr bool F32 = WT == 2, FP8 = WT == 1;
+  constexpr bool F32 = WTag<WT>::F32, FP8 = WTag<WT>::FP8;
+  constexpr int XPL = WTag<WT>::XPL;
   constexpr int WH = F32 ? 2 : 1;
   constexpr int NACC = 2;
   constexpr int K = 64 * G2 * NW;
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
   const int voffx = (sb * 64 + q * 16 + la + 8 * h) * 16;   // batch row la + 8 h of the block (out of range below when it does not exist)
 
   u32x4 wb[NB][GB][2][WH];
-  u32x4 xb[RBK][NB][GB][VA_NPL];
+  u32x4 xb[RBK][NB][GB][XPL];
   f32x4 wsc = f32x4{1.f, 1.f, 1.f, 1.f};
   auto load_w = [&](int b) {
 #pragma unroll
@@ -567,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
 #pragma unroll
       for (int g = 0; g < GB; ++g)
 #pragma unroll
-        for (int p = 0; p < VA_NPL; ++p)
+        for (int p = 0; p < XPL; ++p)
           xb[r][b % NB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, rb * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0,
                                                                       ((rb * VA_NPL + p) * (K / 8) * 16 + (w * G2 + b * GB + g) * 128) * 16, 0);
     }
@@ -597,7 +612,7 @@ __global__ __launch_bounds__(NW * 64) void gemv3h_kernel(const void* __restrict_
         for (int p = 0; p < NACC; ++p) acc[r][nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (rb == 0) {
       VA_STAMP(stamps, 1);
-      VA_WAIT_VM(GB * VA_NPL + 2);           // wave 0 also holds the residual / gain requests
+      VA_WAIT_VM(GB * XPL + 2);           // wave 0 also holds the residual / gain requests
       VA_STAMP(stamps, 2);
       VA_WAIT_VM(0);
       VA_STAMP(stamps, 3);

@@ -96,8 +96,8 @@ struct MlpEngineShape {
   static constexpr int G2 = 8;                         // k-group pairs per wave in phase 2 (K = 4096)
   // WT = 1 (fp8 tile pairs, round 5; two row blocks only): ONE 1-KiB fragment holds both k-groups of a pair, so the whole w2 slice of
   // a wave (8 fragments) waits in LDS
-  static constexpr int PL = WT == 1 ? 8 : (RBK == 2 ? (WT == 2 ? 3 : 6) : (WT == 2 ? 4 : 8));   // pairs per wave whose weights wait in LDS (the rest in registers)
-  static constexpr int NF = WT == 1 ? PL : 2 * PL * WH;   // 1-KiB fragments of ring per wave
+  static constexpr int PL = (WT == 1 || WT == 3) ? 8 : (RBK == 2 ? (WT == 2 ? 3 : 6) : (WT == 2 ? 4 : 8));   // pairs per wave whose weights wait in LDS (the rest in registers)
+  static constexpr int NF = (WT == 1 || WT == 3) ? PL : 2 * PL * WH;   // 1-KiB fragments of ring per wave
   static constexpr int WAVE_RING = NF * 1024;          // bytes of ring per wave: 16 KB (12 KB with two row blocks, 8 KB fp8)
   static constexpr int RED = RBK * MLPE_NW * 3 * 64 * 16;    // reduction tiles (every phase; the qkv phase has three tiles per wave)
   static constexpr int LDS = MLPE_NW * WAVE_RING + RED + 128;     // + the arrival / hand-shake words
@@ -162,7 +162,8 @@ template <int WT, bool QKV, int RBK = 1, bool ATT = false>
 __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __restrict__ W13q, const uint16_t* __restrict__ XPq,
                                                                   const void* __restrict__ W2q, MlpEngineArgs e) {
   using SH = MlpEngineShape<WT, RBK>;
-  constexpr bool F32 = WT == 2, FP8 = WT == 1;
+  constexpr bool F32 = WTag<WT>::F32, FP8 = WTag<WT>::FP8;
+  constexpr int XPL = WTag<WT>::XPL;
   static_assert(!FP8 || (RBK == 2 && !ATT), "fp8 tile pairs: the two-row-block instances only (configs[4]'s shape)");
   constexpr int WH = SH::WH, NW = MLPE_NW, NACC = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char mlpe_lds[];
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       }
     };
     constexpr int NXB = XB > 1 ? 2 : 1;
-    u32x4 xb[RBK][NXB][GB][VA_NPL];
+    u32x4 xb[RBK][NXB][GB][XPL];
     auto load_x = [&](int b) {
 #pragma unroll
       for (int r = 0; r < RBK; ++r) {
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
         for (int g = 0; g < GB; ++g)
 #pragma unroll
-          for (int p = 0; p < VA_NPL; ++p)
+          for (int p = 0; p < XPL; ++p)
             xb[r][b % NXB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xl16, (int)(((r * VA_NPL + p) * (K / 8) * 16 + (w * G + b * GB + g) * 64) * 16), 0);
       }
     };
@@ -634,14 +635,14 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // ---- the planes of this workgroup's 8 rows (of every row block) over its wave's K slice: every load sc1 (the producers stored
     //      write-through).  Two row blocks: the second block's last four pairs are requested into the registers the first block's
     //      first four release (all 32 fragments at once do not fit next to the weights).
-    u32x4 xb[RBK][G2][VA_NPL];
+    u32x4 xb[RBK][G2][XPL];
     auto load_xr = [&](auto rc, auto j0c, auto j1c) {
       constexpr int r = decltype(rc)::value, j0 = decltype(j0c)::value, j1 = decltype(j1c)::value;
       const int vx = r * 16 + la + 8 * h < a.rows ? voffx : 0x7ffffff0;
 #pragma unroll
       for (int j = j0; j < j1; ++j)
 #pragma unroll
-        for (int p = 0; p < VA_NPL; ++p)
+        for (int p = 0; p < XPL; ++p)
           xb[r][j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, ((r * VA_NPL + p) * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -833,14 +834,14 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       asm volatile("" ::: "memory");
       const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aq.XP), 0, aq.R * VA_NPL * (KQ / 8) * 256, 0x00020000);
       const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.ss_in), 0, RBK * 96 * 16 * 4, 0x00020000);
-      u32x4 xq[RBK][G][VA_NPL];
+      u32x4 xq[RBK][G][XPL];
 #pragma unroll
       for (int r = 0; r < RBK; ++r) {
         const int xl16 = (actq && r * 16 + mq < aq.rows) ? lane16 : 0x7ffffff0;
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-          for (int p = 0; p < VA_NPL; ++p)
+          for (int p = 0; p < XPL; ++p)
             xq[r][g][p] = __builtin_amdgcn_raw_buffer_load_b128(hrs, xl16, (int)(((r * VA_NPL + p) * (KQ / 8) * 16 + (kgo + w3 * G + g) * 64) * 16), 16 /* sc1 */);
       }
       constexpr int NSSQ = KQ / 64;

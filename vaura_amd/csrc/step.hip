@@ -77,7 +77,7 @@ int va_launch_embed(const vaura_decoder* d, int pos_host, int n_pos, hipStream_t
   const vaura_dims& m = d->dims;
   const int D = m.cond_dim + m.tok_dim;
   if (!d->tok_table || (D % 256)) return VAURA_ERR_SHAPE;
-  const bool split = d->wdtype == VAURA_W_H1 || d->wdtype == VAURA_W_H2 || d->wdtype == VAURA_W_FP8;   // pair path (api.hip enqueue_step)
+  const bool split = d->wdtype == VAURA_W_H1 || d->wdtype == VAURA_W_H2 || va_is_fp8(d->wdtype);   // pair path (api.hip enqueue_step)
   if (split && (!d->ws_h_split || !d->ws_ss || !d->first_norm)) return VAURA_ERR_ARG;
   VA_LAUNCH(embed_kernel, dim3(d->rows, D / 256, n_pos), dim3(64), 0, s, d->seq, d->state, d->cond_proj, d->empty_video,
             d->tok_table, d->ws_h, split ? d->ws_h_split : nullptr, d->first_norm, d->ws_ss, d->batch, m.n_codebooks,
