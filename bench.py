@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 8 for c2, 4 for c4)")
     ap.add_argument("--cfg-scale", type=float, default=None)
     ap.add_argument("--top-k", type=int, default=250)
-    ap.add_argument("--weights", choices=["auto", "h1", "h2", "fp8", "f32"], default="auto",
+    ap.add_argument("--weights", choices=["auto", "h1", "h2", "fp8", "fp8h", "f32"], default="auto",
                     help="storage of the streamed matrices (vaura_amd.engine.resolve_weight_dtype); auto = the plugin default: two fp16 "
                          "planes (h2) for the un-rounded checkpoint")
     ap.add_argument("--checkpoint", choices=["raw", "bf16repr"], default="raw",
@@ -259,7 +259,7 @@ def main():
     eng = DecoderEngine(cfg, sd, dev, wdtype=args.weights, one_launch_mlp=one_launch)
     storage = eng.wdtype                     # what "auto" resolved to
     if args.codec is None:
-        args.codec = "f16pair_w8" if storage == "fp8" else "f16pair"
+        args.codec = "f16pair_w8" if storage in ("fp8", "fp8h") else "f16pair"
     codec = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision=args.codec)
     feats_cpu = synth.video_features(B, TV, cfg.cond_in, seed=0, first_clip=first)
     feats = feats_cpu.to(dev)
@@ -329,7 +329,7 @@ def main():
 
     tokens = world * B * K_CB * T_FRAMES * args.steps
     rows = 2 * B if args.cfg_scale > 1 else B
-    wbytes = {"h1": 2, "h2": 4, "f32": 4, "fp8": 1}[storage]
+    wbytes = {"h1": 2, "h2": 4, "f32": 4, "fp8": 1, "fp8h": 1}[storage]
     out = {
         "metric": f"audio codec tokens/sec (whole node), {'10.24' if long_ctx else '2.56'} s clips",
         "value": round(tokens / elapsed, 1), "unit": "codec tokens/s", "n_gpus": world, "steps": args.steps,
@@ -338,8 +338,8 @@ def main():
         # the arithmetic type the path computes in: exact products of (hi, lo) fp16 operand PAIRS (22 significand bits per operand, the
         # wlo*xlo term dropped) accumulated in fp32; `--weights f32` is bit-for-bit fp32 products on the fp32 MFMA (value_f32_exact below)
         "dtype": {"h2": "f16x2-split(22b)/f32-acc", "h1": "f16x2-split(22b act, 11b w)/f32-acc", "fp8": "fp8-w,f16x2-act/f32-acc",
-                  "f32": "f32"}[storage], "data": "synthetic",
-        "config": {"workload": (f"configs[{3 if long_ctx else (4 if storage == 'fp8' and args.codec == 'mx8' else 1)}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
+                  "fp8h": "fp8-w,f16-act/f32-acc", "f32": "f32"}[storage], "data": "synthetic",
+        "config": {"workload": (f"configs[{3 if long_ctx else (4 if storage in ('fp8', 'fp8h') and args.codec == 'mx8' else 1)}]: batch={B}/GPU x {'10.24' if long_ctx else '2.56'} s clips (T={T_FRAMES}, 9 codebooks, Tv={TV} AVCLIP-shaped features), "
                                 f"top-k {args.top_k}, temp 1.0, cfg_scale {args.cfg_scale} (decoder rows={rows}), 24-layer "
                                 "1536-d decoder + DAC-44k decode to waveform"),
                    "global_batch": B * world, "parallelism": f"clip-parallel x{world}, one final all_gather",
@@ -347,7 +347,9 @@ def main():
                                 "h1": "one fp16 plane + power-of-two row scales: lossless for this (bf16-representable) checkpoint, 2 bytes per weight",
                                 "f32": "fp32 tiles on the exact-fp32-MFMA GEMVs (cross-check path)",
                                 "fp8": "fp8 e4m3 + power-of-two row scales for the per-layer matrices and the codec's conv weights, "
-                                       "one-plane heads (a different model: not the headline configuration)"}[storage]
+                                       "one-plane heads (a different model: not the headline configuration)",
+                                "fp8h": "fp8 e4m3 + power-of-two row scales for the per-layer matrices and the codec's conv weights, one-plane heads; "
+                                        "the fp8 matrices multiply the HI fp16 activation plane only (11-bit activations: tolerance reported, configs[4])"}[storage]
                                + f" (requested: {args.weights}; checkpoint: {args.checkpoint})"
                                + "; activations as (hi, lo) fp16 planes between kernels, fp32 accumulate / residual stream / KV cache; codec: "
                                + {"f32": "fp32 MFMA", "f16pair": "activations and weights on (hi, lo) fp16 pairs, fp32 accumulate",
