@@ -101,12 +101,17 @@ typedef struct vaura_sampling {
   uint64_t clip_base;     /* global index of clip 0 (keeps draws invariant to batch sharding) */
   int32_t input_is_probs; /* 1: the input rows already are probabilities (utils/utils.py sample_top_k / sample_top_p / multinomial
                              take probs): no temperature, no softmax, no CFG mix.  0 in the decode loop                       */
-  int32_t _pad;
+  float   tie_eps;        /* near-tie detector (round 6), 0 = off: RELATIVE bound on the error of a logit as the plane storages deliver it
+                             (x the row's largest |logit|, x (2 cfg_scale - 1) through the CFG mix).  A used decision whose own margin is
+                             inside twice that bound — greedy: top-1 - top-2 of the mixed logits; sampled: the runner-up of argmax(p / q),
+                             and the top-k threshold where it could change the draw — is counted in state[6] (state[7] = first such
+                             step + 1) and raises VAURA_STATUS_NEAR_TIE.  The token chosen is never changed by the detector           */
 } vaura_sampling;
 
 /* ---- everything one decode step touches.  All buffers are owned by the caller (torch tensors). */
 #define VAURA_STATUS_NONFINITE_LOGITS 1
 #define VAURA_STATUS_HANDOFF_TIMEOUT 2    /* a consumer of the one-launch MLP (csrc/mlp_engine.h) gave up waiting for its producers */
+#define VAURA_STATUS_NEAR_TIE 4           /* informational: >= 1 used decision of the sampler was inside the arithmetic's noise (vaura_sampling.tie_eps) */
 
 typedef struct vaura_decoder {
   vaura_dims dims;
@@ -150,7 +155,8 @@ typedef struct vaura_decoder {
                                 nothing rewinds it.  A hand-off epoch is (state[3] sequence id, state[5], layer): rewinding [0]
                                 inside a sequence is safe; a NEW sequence, a state buffer that starts from zero again, or another
                                 decoder instance in the same process must come with a new sequence id in [3] (10 bits are
-                                used) — the arrival words of the hand-offs live in LDS and outlive launches.  [6..7] spare */
+                                used) — the arrival words of the hand-offs live in LDS and outlive launches.  [6] = near-tie decisions counted
+                                since the caller last zeroed it, [7] = step index + 1 of the first of them (vaura_sampling.tie_eps) */
   const float* noise;        /* optional (n_steps, B*K, vocab) Exp(1) draws; NULL -> Philox */
 
   float* ws_h;               /* packed rows (rows x d_model) residual stream        */

@@ -34,7 +34,7 @@ class LayerWeights(C.Structure):
 class Sampling(C.Structure):
     _fields_ = [("use_sampling", C.c_int32), ("temp", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
                 ("cfg_scale", C.c_float), ("seed", C.c_uint64), ("clip_base", C.c_uint64), ("input_is_probs", C.c_int32),
-                ("_pad", C.c_int32)]
+                ("tie_eps", C.c_float)]
 
 
 class Decoder(C.Structure):

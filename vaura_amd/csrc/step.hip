@@ -119,6 +119,7 @@ struct SampleArgs {
   int B, K, V, T, S;
   int use_sampling, top_k, probs_in;
   float temp, top_p, cfg_scale;
+  float tie_eps;         // near-tie detector (vaura_sampling.tie_eps): relative bound on a logit's error, 0 = off
   uint64_t seed, clip_base;
   long long step_host;
 };
@@ -184,10 +185,25 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
 
   const f32x4 lc = *reinterpret_cast<const f32x4*>(a.logits + ((size_t)b * a.K + k) * V + 4 * tid);
   float x[4] = {lc[0], lc[1], lc[2], lc[3]};
+  // near-tie detector: magnitude of the rows this decision is made from (both branches, before the mix)
+  float amax = fmaxf(fmaxf(fabsf(lc[0]), fabsf(lc[1])), fmaxf(fabsf(lc[2]), fabsf(lc[3])));
   if (a.cfg_scale > 1.0f) {  // models/vaura_model.py:810-813
     const f32x4 lu = *reinterpret_cast<const f32x4*>(a.logits + ((size_t)(a.B + b) * a.K + k) * V + 4 * tid);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(lu[0]), fabsf(lu[1])), fmaxf(fabsf(lu[2]), fabsf(lu[3]))));
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = lu[j] + (x[j] - lu[j]) * a.cfg_scale;
+  }
+  // Near-tie detector (round 6).  The plane storages carry 22-bit operands where the reference computes fp32: a logit reaches the
+  // sampler with an error of at most ~tie_eps x (the row's largest |logit|), and the CFG mix s lc - (s - 1) lu multiplies that by up
+  // to 2 s - 1.  A decision whose own margin is inside twice that bound could have gone the other way in the reference's arithmetic
+  // (or in ANY fp32 summation order: the reference's logits themselves move by ~3e-6 with the prefix length it re-feeds).  Such
+  // decisions are COUNTED (state[6]; state[7] = first such step + 1) and raise the sticky VAURA_STATUS_NEAR_TIE bit; the token chosen
+  // is never changed here.  What the host does with it is policy (engine.py near_tie: report | rerun on the exact-fp32 twin).
+  bool near_tie = false;
+  float tie_delta = 0.f;       // absolute bound on a mixed logit's error
+  if (a.tie_eps > 0.f && !a.probs_in) {
+    const float scale = block_max(amax, sv);
+    tie_delta = a.tie_eps * scale * (a.cfg_scale > 1.0f ? 2.f * a.cfg_scale - 1.f : 1.f);
   }
   // Range guard of the fp16-plane activation format (gemv3_kernel.h split2): an activation beyond fp16's 65504 becomes inf in its
   // hi plane, inf - inf = NaN in the lo plane, and from there NaN in the residual stream of that row for the rest of the clip —
@@ -211,6 +227,13 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     float rv; int ri;
     block_argmax(bv, bi, sv, si, rv, ri);
     token = ri;
+    if (tie_delta > 0.f) {     // runner-up of the mixed logits: the argmax could flip when top-1 - top-2 < 2 delta
+      float second = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (4 * tid + j != ri) second = fmaxf(second, x[j]);
+      second = block_max(second, sv);
+      near_tie = (rv - second) < 2.f * tie_delta;
+    }
   } else {
     // softmax(logits / temp) — or the input rows themselves when they already are probabilities (utils/utils.py:139-196)
     float p[4];
@@ -339,7 +362,16 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
       float rv; int ri;
       block_argmax(bv, bi, sv, si, rv, ri);
       token = sidx[ri];
+      if (tie_delta > 0.f) {   // the draw: argmax of p / q — a probability moves by a factor exp(+-delta / temp), the runner-up wins inside twice that
+        float second = -1.f;   // (the nucleus cut itself is not screened: no shipped config samples with top-p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * tid + j != ri) second = fmaxf(second, (ps[j] / den2) / q[j]);
+        second = block_max(second, sv);
+        near_tie = (rv - second) < rv * (2.f * tie_delta / a.temp);
+      }
     } else {
+      const float p_raw[4] = {p[0], p[1], p[2], p[3]};   // probabilities before the top-k mask (near-tie detector)
+      float thr_keep = 0.f, den_keep = 1.f;
       if (a.top_k > 0) {
         // utils/utils.py:172-176 — threshold = k-th largest probability (bitwise binary search on the
         // IEEE bits: probabilities are >= 0 so integer order == float order), keep p >= threshold.
@@ -379,9 +411,11 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
           need = (int)s_sel[1];
         }
         const float thrf = __builtin_bit_cast(float, thr);
+        thr_keep = thrf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[j] = p[j] * (p[j] >= thrf ? 1.0f : 0.0f);
         const float den2 = block_sum((p[0] + p[1]) + (p[2] + p[3]), sv);
+        den_keep = den2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[j] = p[j] / den2;
       }
@@ -394,6 +428,32 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
       float rv; int ri;
       block_argmax(bv, bi, sv, si, rv, ri);
       token = ri;
+      if (tie_delta > 0.f) {
+        // (1) the draw argmax(p / q): a probability moves by a factor exp(+-delta / temp) (the common normalisation cancels), so the
+        //     runner-up wins when its ratio is within twice that of the winner's.  (2) the top-k threshold (keep p >= k-th largest):
+        //     membership matters only through the draw — a candidate whose probability is within the band BELOW the threshold and whose
+        //     ratio would have reached the winner's had it been kept, or a winner within the band ABOVE the threshold while such a
+        //     candidate exists (it could have been the one left out).
+        const float band = 2.f * tie_delta / a.temp;
+        float second = -1.f, cand = -1.f;
+        int nbelow = 0, wedge = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * tid + j;
+          if (i != ri) second = fmaxf(second, p[j] / q[j]);
+          if (thr_keep > 0.f) {
+            if (p_raw[j] < thr_keep && p_raw[j] >= thr_keep * (1.f - band)) { ++nbelow; cand = fmaxf(cand, (p_raw[j] / den_keep) / q[j]); }
+            if (i == ri && p_raw[j] <= thr_keep * (1.f + band)) wedge = 1;
+          }
+        }
+        second = block_max(second, sv);
+        near_tie = (rv - second) < rv * band;
+        if (thr_keep > 0.f) {      // (block-uniform)
+          cand = block_max(cand, sv);
+          const int nb = block_count(nbelow, si), nw = block_count(wedge, si);
+          if (cand >= rv * (1.f - band) || (nb > 0 && nw > 0)) near_tie = true;
+        }
+      }
     }
   }
 
@@ -406,7 +466,16 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
       const int tok = (t >= 0 && t < a.T) ? token : V;
       if (offset < a.S) {   // a step past the end of the sequence (refused by vaura_generate_loop) must not write
         int32_t* slot = a.seq + ((size_t)b * a.K + k) * a.S + offset;
-        if (*slot == -1) *slot = tok;
+        if (*slot == -1) {
+          *slot = tok;
+          // near-tie detector: only decisions that are USED count (a valid pattern slot that was still unknown)
+          if (near_tie && t >= 0 && t < a.T && a.state_rw) {
+            __hip_atomic_fetch_or(&a.state_rw[4], VAURA_STATUS_NEAR_TIE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&a.state_rw[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int expect = 0;
+            (void)__hip_atomic_compare_exchange_strong(&a.state_rw[7], &expect, (int)step + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
     if (a.state_rw) {
@@ -435,6 +504,7 @@ int va_launch_sample(const float* logits, int B, int K, int vocab, const vaura_s
   a.use_sampling = sp->use_sampling; a.top_k = sp->top_k; a.temp = sp->temp; a.top_p = sp->top_p;
   a.cfg_scale = sp->input_is_probs ? 1.0f : sp->cfg_scale; a.seed = sp->seed; a.clip_base = sp->clip_base; a.step_host = step_host;
   a.probs_in = sp->input_is_probs;
+  a.tie_eps = sp->tie_eps > 0.f ? sp->tie_eps : 0.f;
   VA_LAUNCH(sample_kernel, dim3(K, B), dim3(SMP_THREADS), 0, s, a.logits, a.state, a);
   return 0;
 }

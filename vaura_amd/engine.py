@@ -13,6 +13,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -134,11 +135,22 @@ def _require_cuda(dev: torch.device):
     L.lib()
 
 
+# Near-tie detector (csrc/step.hip sample_kernel, include/vaura_hip.h vaura_sampling.tie_eps): relative bound on the error of a logit the
+# plane storages deliver against the reference's fp32 (x the row's largest |logit|, x (2 cfg - 1) through the CFG mix).  Calibrated on
+# the reference's own goldens (tests/test_gpu_generate.py::test_near_tie_detector_...): it flags the two literal near-ties the goldens
+# hold (configs[3] step 578: margin 5.5e-6; the later chunk's step 175: 3.8e-6) and nothing in the headline golden.
+NEAR_TIE_EPS = 1.2e-6
+
+
 class DecoderEngine:
-    _sequence_id = 0
+    # hand-off epochs carry 10 bits of this counter (csrc/common.h va_handoff_epoch) and the arrival words of the in-launch hand-offs live
+    # in LDS, which outlives processes: start every process somewhere else, so that two processes taking turns on one GPU do not
+    # produce identical tag sequences
+    _sequence_id = (os.getpid() * 0x9E37 + int.from_bytes(os.urandom(2), "little")) & 0x3FF
 
     def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
-                 one_launch_mlp: bool = True, range_fallback: bool = True, plane_shift: int = 0):
+                 one_launch_mlp: bool = True, range_fallback: bool = True, plane_shift: int = 0,
+                 near_tie: str = "report", near_tie_eps: Optional[float] = None):
         """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "fp8h" | "f32" (``resolve_weight_dtype``).
         one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
         is eligible (1..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
@@ -153,6 +165,16 @@ class DecoderEngine:
         plane's absolute resolution is 2^-24 * 2^S (its subnormal step), so S = 0 is what every parity number is quoted on, and a
         checkpoint KNOWN to carry massive activations is the reason to pass S = 4 .. 8 rather than pay the exact-fp32 twin on every call."""
         self.one_launch_mlp = bool(one_launch_mlp)
+        self.handoff_fallbacks = 0           # calls re-run on the separate launches after an in-launch hand-off gave up (GPU shared)
+        # near-tie detector: "off" | "report" (count decisions inside the arithmetic's noise: ``near_ties`` / ``last_near_ties``) |
+        # "rerun" (``generate_codes_checked`` re-runs a flagged call on the exact-fp32 twin, like an overflow)
+        if near_tie not in ("off", "report", "rerun"):
+            raise L.VauraHipError(f"near_tie must be off | report | rerun, got {near_tie!r}")
+        self.near_tie = near_tie
+        self.near_tie_eps = float(NEAR_TIE_EPS if near_tie_eps is None else near_tie_eps)
+        self.near_ties = 0                   # decisions flagged so far (all calls)
+        self.last_near_ties = (0, None)      # (count, first flagged step) of the last checked call
+        self.near_tie_reruns = 0
         self.plane_shift = int(plane_shift)
         if not 0 <= self.plane_shift <= 24:
             raise L.VauraHipError(f"plane_shift must be in 0..24, got {plane_shift}")
@@ -179,6 +201,10 @@ class DecoderEngine:
         self.wd = {"f32": L.W_F32, "h1": L.W_H1, "h2": L.W_H2, "fp8": L.W_FP8, "fp8h": L.W_FP8H}[wdtype]
         head_wd = L.W_H1 if wdtype in ("fp8", "fp8h") else self.wd
         self.wdtype = wdtype
+        # lossy storages (fp8 / fp8h; one plane FORCED on a checkpoint it cannot hold) are a different model than the state dict: their
+        # exact-fp32 twin must hold the numbers the storage holds, or a call that falls back would be decoded by another model than
+        # the other calls of the same job.  Resolved lazily in _twin().
+        self._twin_lossy_cached: Optional[bool] = None
         self.lib = L.lib()
         D, F, K = cfg.d_model, cfg.ffn_dim, cfg.num_codebooks
         with torch.cuda.device(self.dev):
@@ -363,8 +389,9 @@ class DecoderEngine:
         if use_sampling and temp > 0.0 and not top_p > 0.0 and int(top_k) > self.cfg.d_codebook:
             # the reference's sample_top_k is torch.topk(probs, k) (utils/utils.py:172): k beyond the codebook raises there too
             raise L.VauraHipError(f"top_k = {top_k} exceeds the codebook size {self.cfg.d_codebook} (the reference's torch.topk raises as well)")
+        tie = self.near_tie_eps if (self.near_tie != "off" and self.planes) else 0.0      # the exact-fp32 engine IS the reference's arithmetic
         return L.Sampling(int(bool(use_sampling)), float(temp), int(top_k), float(top_p),
-                          float(cfg_scale if self.rows == 2 * self.batch else 1.0), int(seed), int(clip_base))
+                          float(cfg_scale if self.rows == 2 * self.batch else 1.0), int(seed), int(clip_base), 0, float(tie))
 
     def start_sequence(self, prompt: Optional[torch.Tensor]):
         """codes = -1 everywhere but the prompt -> pattern sequence on device; returns Tp."""
@@ -413,12 +440,40 @@ class DecoderEngine:
         except Exception:
             pass
 
+    @property
+    def _twin_lossy(self) -> bool:
+        if self._twin_lossy_cached is None:
+            self._twin_lossy_cached = self.wdtype in ("fp8", "fp8h") or (
+                self.wdtype == "h1" and self.requested_wdtype != "auto" and self._twin_sd is not None and
+                not all(h1_lossless(self._twin_sd[k]) for k in streamed_matrices(self._twin_sd)))
+        return self._twin_lossy_cached
+
+    def _twin(self) -> "DecoderEngine":
+        """The exact-fp32 engine of the SAME model: fp32 tiles of what this engine's storage holds (the state dict itself for the
+        lossless storages; the dequantised matrices for fp8 / a forced single plane).  Built on first use: ~2.7 GB of weights."""
+        if self._range_twin is None:
+            sd = self._twin_sd
+            if self._twin_lossy:
+                from . import quant
+                if self.wdtype in ("fp8", "fp8h"):
+                    sd = quant.fp8_effective_state_dict(sd)
+                else:
+                    from .synth import is_streamed_weight
+                    sd = {k: (h_effective_weight(v, 1) if is_streamed_weight(k) else v) for k, v in sd.items()}
+            try:
+                self._range_twin = DecoderEngine(self.cfg, sd, self.dev, wdtype="f32", range_fallback=False, near_tie="off")
+            except torch.cuda.OutOfMemoryError as e:
+                raise L.VauraHipError("the exact-fp32 twin engine (2.7 GB of fp32 tiles + its K/V cache) does not fit next to this engine: "
+                                      f"{e}") from e
+        return self._range_twin
+
     def _reset_state(self):
         """position / arrivals / step back to 0; state[3] carries a sequence id (reserved for in-launch hand-off epochs)."""
         self._fc = None                       # position 0 again: a cached forward() prefix no longer matches the K/V cache
         DecoderEngine._sequence_id = (DecoderEngine._sequence_id + 1) & 0x3FF      # 10 bits enter the hand-off epoch (csrc/common.h)
-        self.state[:4].zero_()                               # two tiny device fills: no host-device synchronisation
+        self.state[:4].zero_()                               # tiny device fills: no host-device synchronisation
         self.state[3:4].fill_(DecoderEngine._sequence_id)    # state[4] (status bits) is sticky until check_status() reads it
+        self.state[6:8].zero_()                              # near-tie count / first flagged step of THIS sequence
 
     def check_status(self):
         """Read AND clear the sticky device status word (one host-device synchronisation; ``VAURAModel.generate`` folds it into
@@ -428,10 +483,17 @@ class DecoderEngine:
         tokens AND an optimistic time).  ``generate_codes`` / ``run`` are asynchronous and do NOT call this: whoever drives them
         directly (bench.py, tools/, tests) must call it after synchronising — ``VAURAModel.generate_tokens``, ``forward_cached`` and
         ``logits_all_positions`` do."""
-        st = int(self.state[4].item()) | self._carried_status
+        words = self.state.tolist()                       # ONE transfer: status word + the near-tie counters
+        st = int(words[4]) | self._carried_status
         self._carried_status = 0
         if st:
             self.state[4:5].zero_()
+        self.last_near_ties = (0, None)
+        if st & 4:                                        # informational (csrc/step.hip near-tie detector): never an error
+            self.last_near_ties = (int(words[6]), int(words[7]) - 1 if words[7] else None)
+            self.near_ties += int(words[6])
+            self.state[6:8].zero_()
+            st &= ~4
         msgs = []
         if st & 2:
             msgs.append(
@@ -501,17 +563,27 @@ class DecoderEngine:
                 warnings.warn("vaura_amd: the one-launch MLP's in-launch hand-off timed out (GPU shared?); this engine now uses the "
                               "separate launches (slower by 5-7 %, same results)")
                 self.one_launch_mlp = False
-                self.handoff_fallbacks = getattr(self, "handoff_fallbacks", 0) + 1
+                self.handoff_fallbacks += 1
                 if self.dec is not None:
                     self.dec.ws_sync = 0
                 self._free_graph()
                 return self.generate_codes_checked(feats, max_new_tokens, **kw)
             if st != 1 or self.wdtype == "f32" or self._twin_sd is None:       # nothing wider to fall back to
                 raise
-            if self._range_twin is None:
-                self._range_twin = DecoderEngine(self.cfg, self._twin_sd, self.dev, wdtype="f32", range_fallback=False)
+            if self.range_fallbacks == 0:
+                import warnings
+                warnings.warn("vaura_amd: an activation left the fp16-plane range (non-finite logits at the sampler); this call is re-run "
+                              "on the exact-fp32 twin engine (1.5 x slower, ~2.7 GB more)"
+                              + (" — built from the DEQUANTISED matrices this lossy storage holds" if self._twin_lossy else "")
+                              + ".  A checkpoint that does this on every call wants plane_shift=4..8 or weight_dtype='f32'")
             self.range_fallbacks += 1
-            codes = self._range_twin.generate_codes(feats, max_new_tokens, **kw)
+            codes = self._twin().generate_codes(feats, max_new_tokens, **kw)
+            self._range_twin.check_status()
+            return codes
+        if self.near_tie == "rerun" and self.last_near_ties[0] > 0 and self.wdtype != "f32" and self._twin_sd is not None:
+            # >= 1 used decision of this call was inside the plane arithmetic's noise: the same call on the exact-fp32 twin, same noise
+            self.near_tie_reruns += 1
+            codes = self._twin().generate_codes(feats, max_new_tokens, **kw)
             self._range_twin.check_status()
         return codes
 
@@ -552,21 +624,19 @@ class DecoderEngine:
             L.check(self.lib.vaura_decode_step(C.byref(self.dec), C.byref(sp), 1, stream), "vaura_decode_step")
             st["logits"][:, :, p] = self.ws_logits.view(Bs, K, -1)
             self.cached_forward_steps = getattr(self, "cached_forward_steps", 0) + 1
-        st["idx"][:, :, n0:Lq] = idx[:, :, n0:Lq]
-        st["n"] = Lq
         try:
             self.check_status()              # the caller consumes these logits on the host side anyway (one synchronisation)
+            st["idx"][:, :, n0:Lq] = idx[:, :, n0:Lq]       # committed only once the status word is clean: a caller that
+            st["n"] = Lq                                     # catches the error and goes on must not be served the invalid prefix
         except L.VauraHipError as e:
+            self._fc = None
             # range safety for the reference host's call pattern too (see generate_codes_checked): non-finite logits = an activation left
             # the fp16-plane range -> this and every later forward() of the engine runs on the exact-fp32 twin (whole prefix recomputed once)
             if getattr(e, "status", 0) != 1 or self.wdtype == "f32" or self._twin_sd is None:
                 raise
-            if self._range_twin is None:
-                self._range_twin = DecoderEngine(self.cfg, self._twin_sd, self.dev, wdtype="f32", range_fallback=False)
             self.range_fallbacks += 1
             self._forward_on_twin = True
-            self._fc = None
-            return self._range_twin.forward_cached(idx, feats, tokens_per_frame)
+            return self._twin().forward_cached(idx, feats, tokens_per_frame)
         return st["logits"][:, :, :Lq].clone()      # a copy: the cache must survive in-place edits by the caller
 
     # ------------------------------------------------------------------ op-level access (tests)
