@@ -1477,3 +1477,90 @@ def test_reference_op_vectors_on_the_trained_like_tiny_checkpoint(golden, wdtype
     assert err < 3e-5 * scale, (err, scale)
     cp = eng.cond_projection().cpu()
     assert float((cp - torch.from_numpy(g["cond_proj"])).abs().max()) < 1e-5 * max(1.0, float(np.abs(g["cond_proj"]).max()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 6: the near-tie detector (csrc/step.hip sample_kernel; vaura_sampling.tie_eps; DecoderEngine(near_tie=...)).
+def test_near_tie_detector_flags_the_goldens_literal_ties_and_nothing_else(golden, full_sampler_sd_raw, parity_report):
+    """The plane storages carry 22-bit operands; a decision whose own margin is inside twice the bound on a logit's error
+    (engine.NEAR_TIE_EPS x the row's largest |logit| x (2 cfg - 1)) could have gone the other way in the reference's arithmetic.  The
+    sampler COUNTS such used decisions (status bit 4, state[6..7]); it never changes a token.  On the reference's own goldens at full
+    depth, default storage: (1) the headline arithmetic's golden (cfg 6, top-k 250 sampled, the reference's noise, B=2: 4 104
+    decisions) and the greedy cfg-6 golden (min margin 9.9e-5): NOTHING flagged, tokens strict; (2) the later chunk's greedy run, which
+    holds ONE literal tie (clip 1, sequence step 175 = pass 8 of the chunk: 3.8e-6): exactly that step is the first flagged; (3) with
+    near_tie="rerun" the flagged call is run again on the exact-fp32 twin (same noise) and still equals the reference; (4) "off": the
+    same tokens as "report", nothing counted."""
+    g = golden("full_topk250_cfg6_raw_B2_T220.npz")
+    eng = DecoderEngine(synth.FULL_SAMPLER, full_sampler_sd_raw, DEV)
+    assert eng.wdtype == "h2" and eng.near_tie == "report"
+    feats = synth.video_features(2, seed=int(g["feat_seed"])).to(DEV)
+    nz = synth.exp_noise(228, 18, 1024, int(g["noise_seed"]))
+    tok = eng.generate_codes_checked(feats, 220, use_sampling=True, temp=1.0, top_k=250, cfg_scale=6.0, noise=nz).cpu()
+    assert eng.last_near_ties == (0, None), eng.last_near_ties
+    assert_tokens_equal(parity_report, "full_topk250_cfg6_raw_B2_T220", "h2", "near-tie detector on (report): cfg 6 / top-k 250 sampled, B=2; 0 flagged", tok,
+                        _ref(g, "tokens"), g["margins"], g["threshold_rel_gap"], near_tie_flagged=0)
+    gg = golden("full_greedy_cfg6_raw_B2_T220.npz")
+    tokg = eng.generate_codes_checked(synth.video_features(2, seed=int(gg["feat_seed"])).to(DEV), 220, cfg_scale=6.0).cpu()
+    assert eng.last_near_ties == (0, None), eng.last_near_ties
+    assert torch.equal(tokg, _ref(gg, "tokens"))
+    gc = golden("full_chunk_greedy_cfg6_raw_B2_Tp166_T221.npz")
+    fc = synth.video_features(2, seed=int(gc["feat_seed"])).to(DEV)
+    prompt = torch.from_numpy(gc["prompt"].astype(np.int64)).to(DEV)
+    tokc = eng.generate_codes_checked(fc, 221, prompt=prompt, cfg_scale=float(gc["cfg_scale"])).cpu()
+    n, first = eng.last_near_ties
+    assert n >= 1 and first == 175 - 167, (n, first)             # pass index: the chunk's first sampled pass fills sequence step 167
+    assert eng.near_tie_reruns == 0 and eng.range_fallbacks == 0
+    refc = _ref(gc, "tokens")
+    e = assert_tokens_or_recorded_near_tie(parity_report, "full_chunk_greedy_cfg6_raw_B2_Tp166_T221", "h2",
+                                           f"near-tie detector on (report): later chunk, greedy cfg 6, B=2; {n} flagged, first at pass {first} = step 175",
+                                           tokc, refc, gc["margins"], 2e-5, first_step=167, near_tie_flagged=n)
+    assert e["tokens_equal"] or e["first_diff_step"] == 175, e
+    # policy "off": nothing counted, same tokens
+    eng.near_tie = "off"
+    eng._free_graph()
+    tok_off = eng.generate_codes_checked(fc, 221, prompt=prompt, cfg_scale=float(gc["cfg_scale"])).cpu()
+    assert eng.last_near_ties == (0, None) and torch.equal(tok_off, tokc)
+    # policy "rerun": the flagged call again on the exact-fp32 twin
+    eng.near_tie = "rerun"
+    eng._free_graph()
+    tok_rr = eng.generate_codes_checked(fc, 221, prompt=prompt, cfg_scale=float(gc["cfg_scale"])).cpu()
+    assert eng.near_tie_reruns == 1 and eng._range_twin is not None and eng._range_twin.wdtype == "f32"
+    e = assert_tokens_or_recorded_near_tie(parity_report, "full_chunk_greedy_cfg6_raw_B2_Tp166_T221", "h2 -> f32 (near_tie='rerun')",
+                                           "later chunk, greedy cfg 6, B=2: flagged call re-run on the exact-fp32 twin", tok_rr, refc, gc["margins"], 2e-5,
+                                           first_step=167)
+    assert e["tokens_equal"] or e["first_diff_step"] == 175, e
+    del eng
+    torch.cuda.empty_cache()
+
+
+def test_near_tie_detector_flags_configs3_step_578(golden, parity_report):
+    """configs[3]'s golden (B=1, greedy, cfg 1, T=880) holds ONE step inside fp32 summation-order noise (step 578: reference margin
+    5.5e-6; the next smallest of its 7 920 decisions is 6.2e-5): the detector flags exactly one decision, at step index 577."""
+    g = golden("full_c4_greedy_B1_T880.npz")
+    cfg = synth.SamplerCfg(block_size_audio=int(g["block_size_audio"]))
+    sd = synth.sampler_state_dict(cfg, seed=int(g["weight_seed"]), round_bf16=True)
+    eng = DecoderEngine(cfg, sd, DEV, wdtype="h2")
+    feats = synth.video_features(1, tokens=128, seed=int(g["feat_seed"])).to(DEV)
+    tok = eng.generate_codes_checked(feats, 880).cpu()
+    assert eng.last_near_ties == (1, 577), eng.last_near_ties
+    e = assert_tokens_or_recorded_near_tie(parity_report, "full_c4_greedy_B1_T880", "h2", "near-tie detector on (report): configs[3] B=1; 1 flagged, at step 578",
+                                           tok, _ref(g, "tokens"), g["margins"], 2e-5, near_tie_flagged=1)
+    assert e["tokens_equal"] or e["first_diff_step"] == 578, e
+    del eng
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(cfg_scale=6.0), dict(cfg_scale=6.0, use_sampling=True, top_k=250, seed=3),
+                                dict(use_sampling=True, top_k=40, temp=0.8, seed=4), dict(use_sampling=True, top_p=0.7, seed=5),
+                                dict(use_sampling=True, seed=6)])
+def test_near_tie_detector_never_changes_a_token(tiny_sampler_sd, kw):
+    """Whatever the bound — off, the default, or an absurdly wide one that flags nearly every decision — the tokens are the same."""
+    cfg = synth.tiny_sampler(2)
+    feats = synth.video_features(5, seed=21).to(DEV)
+    out, flagged = [], []
+    for mode, eps in (("off", None), ("report", None), ("report", 1e-2)):
+        eng = DecoderEngine(cfg, tiny_sampler_sd, DEV, wdtype="h2", near_tie=mode, near_tie_eps=eps)
+        out.append(eng.generate_codes_checked(feats, 24, **kw).cpu())
+        flagged.append(eng.last_near_ties[0])
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+    assert flagged[0] == 0 and flagged[2] > flagged[1] and flagged[2] > 50, flagged

@@ -137,9 +137,10 @@ def _require_cuda(dev: torch.device):
 
 # Near-tie detector (csrc/step.hip sample_kernel, include/vaura_hip.h vaura_sampling.tie_eps): relative bound on the error of a logit the
 # plane storages deliver against the reference's fp32 (x the row's largest |logit|, x (2 cfg - 1) through the CFG mix).  Calibrated on
-# the reference's own goldens (tests/test_gpu_generate.py::test_near_tie_detector_...): it flags the two literal near-ties the goldens
-# hold (configs[3] step 578: margin 5.5e-6; the later chunk's step 175: 3.8e-6) and nothing in the headline golden.
-NEAR_TIE_EPS = 1.2e-6
+# the reference's own goldens (tools/near_tie_sweep.py -> profiles/r06_near_tie_sweep.txt; tests/test_gpu_generate.py::test_near_tie_*):
+# bounds in [1.2e-6, 2e-6) flag the two literal near-ties the goldens hold (configs[3] step 578: margin 5.5e-6; the later chunk's step
+# 175: 3.8e-6) and nothing else in any golden run (4 104 sampled + 4 104 greedy cfg-6 decisions, 7 920 + 1 134 greedy ones).
+NEAR_TIE_EPS = 1.5e-6
 
 
 class DecoderEngine:
