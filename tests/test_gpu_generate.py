@@ -1563,4 +1563,4 @@ def test_near_tie_detector_never_changes_a_token(tiny_sampler_sd, kw):
         out.append(eng.generate_codes_checked(feats, 24, **kw).cpu())
         flagged.append(eng.last_near_ties[0])
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
-    assert flagged[0] == 0 and flagged[2] > flagged[1] and flagged[2] > 50, flagged
+    assert flagged[0] == 0 and flagged[2] > flagged[1] and flagged[2] >= 20, flagged
