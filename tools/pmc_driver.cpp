@@ -39,6 +39,14 @@ __global__ void fill_f16(_Float16* p, size_t n, int planes, uint32_t seed) {
     p[i] = (_Float16)((lo ? 2.0f : 4096.0f) * ((float)(h & 0xffff) / 32768.0f - 1.0f));
   }
 }
+// fp8 e4m3 tile pairs: any byte but the two NaN codes (0x7f, 0xff); exponents capped so that 1536-deep sums stay far from fp16's range
+__global__ void fill_fp8(uint8_t* p, size_t n, uint32_t seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (uint8_t)((h & 0x80u) | ((h >> 8) & 0x3fu));      // |v| < 2
+  }
+}
 __global__ void fill_const(float* p, size_t n, float v) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -47,12 +55,19 @@ __global__ void fill_i32(int32_t* p, size_t n, int32_t v) {
 }
 
 static uint32_t g_seed = 1;
+static const char* wname(int wd) { return wd == VAURA_W_H2 ? "h2" : (wd == VAURA_W_FP8 ? "fp8" : (wd == VAURA_W_FP8H ? "fp8h" : "h1")); }
 static float* dev_f32(size_t n, float scale, float offset = 0.f) {
   float* p; CK(hipMalloc(&p, n * 4));
   fill_f32<<<1024, 256>>>(p, n, scale, offset, g_seed++);
   return p;
 }
 static void* dev_weight(size_t N, size_t K, int wd) {   // N x K fp16 plane(s) in MFMA-tile order + float scale[N] (2^-17: weights of +-0.03)
+  if (wd == VAURA_W_FP8 || wd == VAURA_W_FP8H) {        // fp8 tile pairs + float scale[N] (2^-6: weights of +-0.03)
+    char* p; CK(hipMalloc(&p, N * K + N * 4));
+    fill_fp8<<<1024, 256>>>((uint8_t*)p, N * K, g_seed++);
+    fill_const<<<64, 256>>>((float*)(p + N * K), N, 0.015625f);
+    return p;
+  }
   const int planes = wd == VAURA_W_H2 ? 2 : 1;
   char* p; CK(hipMalloc(&p, N * K * 2 * planes + N * 4));
   fill_f16<<<1024, 256>>>((_Float16*)p, N * K * planes, planes, g_seed++);
@@ -78,7 +93,8 @@ int main(int argc, char** argv) {
         variants2.push_back(colon && *colon == ':' ? (unsigned)strtoul(colon + 1, nullptr, 0) : 0u);
       }
     }
-    if (!strcmp(argv[i], "--weights")) wd = (!strcmp(argv[i + 1], "h2") || !strcmp(argv[i + 1], "f32")) ? VAURA_W_H2 : VAURA_W_H1;   // h1 | h2
+    if (!strcmp(argv[i], "--weights")) wd = !strcmp(argv[i + 1], "fp8h") ? VAURA_W_FP8H : (!strcmp(argv[i + 1], "fp8") ? VAURA_W_FP8 :
+                                             ((!strcmp(argv[i + 1], "h2") || !strcmp(argv[i + 1], "f32")) ? VAURA_W_H2 : VAURA_W_H1));   // h1 | h2 | fp8 | fp8h
     else if (!strcmp(argv[i], "--steps")) steps = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
@@ -105,7 +121,7 @@ int main(int argc, char** argv) {
     lw[l].attn_norm = dev_f32(D, 0.2f, 1.0f); lw[l].ffn_norm = dev_f32(D, 0.2f, 1.0f);
   }
   d.layers_host = lw.data();
-  d.heads = dev_weight((size_t)K * V, D, wd);
+  d.heads = dev_weight((size_t)K * V, D, (wd == VAURA_W_FP8 || wd == VAURA_W_FP8H) ? VAURA_W_H1 : wd);     // fp8 storages keep one-plane heads
   d.final_norm = dev_f32(D, 0.2f, 1.0f);
   d.tok_emb = dev_f32((size_t)K * (V + 1) * 8, 1.f); d.tok_proj_w = dev_f32((size_t)K * 1024 * 8, 0.3f); d.tok_proj_b = dev_f32((size_t)K * 1024, 0.02f);
   d.tok_table = dev_f32((size_t)K * (V + 1) * 1024, 0.5f);
@@ -158,7 +174,7 @@ int main(int argc, char** argv) {
     if (!f) { perror(stamps_out); return 1; }
     fwrite(host.data() + 8, 128, n, f);
     fclose(f);
-    printf("stamps: %zu records of %d steps at position %d (rows %d, weights %s) -> %s\n", n, steps, pos0, rows, wd == VAURA_W_H2 ? "h2" : "h1", stamps_out);
+    printf("stamps: %zu records of %d steps at position %d (rows %d, weights %s) -> %s\n", n, steps, pos0, rows, wname(wd), stamps_out);
     return 0;
   }
   if (chains > 1) {
@@ -271,7 +287,7 @@ int main(int argc, char** argv) {
       const int rc = prof(&d, &sp, n, 0xFF, tot, cnt, st);
       if (rc) { fprintf(stderr, "profile_loop: %d\n", rc); return 3; }
       printf("flags %u:%u weights %s rows %d: loop of %d steps median %.3f ms min %.3f ms (%.1f us/step) |", variants[v], variants2[v],
-             wd == VAURA_W_H2 ? "h2" : "h1", rows, n, ms[v][ms[v].size() / 2], ms[v][0], 1e3 * ms[v][ms[v].size() / 2] / n);
+             wname(wd), rows, n, ms[v][ms[v].size() / 2], ms[v][0], 1e3 * ms[v][ms[v].size() / 2] / n);
       for (int k = 0; k < 8; ++k) printf(" %s %.2f", kinds[k], 1e3 * tot[k] / (cnt[k] ? cnt[k] : 1));
       printf("\n");
     }
@@ -288,6 +304,6 @@ int main(int argc, char** argv) {
   CK(hipStreamSynchronize(st));
   int32_t st1[4];
   CK(hipMemcpy(st1, d.state, sizeof st1, hipMemcpyDeviceToHost));
-  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wd == VAURA_W_H2 ? "h2" : "h1", rows, pos0, st1[0] - 1);
+  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wname(wd), rows, pos0, st1[0] - 1);
   return st1[0] == pos0 + steps ? 0 : 4;
 }
