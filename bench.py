@@ -294,6 +294,13 @@ def cpu_baseline(sd, feats_cpu, cfg_scale, n_clips, top_k, quick=False):
     return out
 
 
+def launch_command(n: int, argv, port: int):
+    """The child command of `python bench.py --gpus n` from a plain shell: one rank per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1 (the container hostname may not resolve), this script's own argv passed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
 def self_launch(n: int, argv) -> int:
     """Run this script as `n` ranks under torch.distributed.run (child processes) and return their exit status."""
     import socket
@@ -308,9 +315,7 @@ def self_launch(n: int, argv) -> int:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *argv]
-    return subprocess.run(cmd, env=env).returncode
+    return subprocess.run(launch_command(n, argv, port), env=env).returncode
 
 
 def main():

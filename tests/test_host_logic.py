@@ -172,6 +172,61 @@ def test_two_ranks_on_one_device_uuid_are_refused():
         vdist.assert_distinct_devices([{"rank": 0, "device": "cuda:0"}, {"rank": 1, "device": "cuda:0"}])
 
 
+def test_isolated_ranks_are_told_apart_by_their_pci_address():
+    """Per-rank HIP_VISIBLE_DEVICES isolation: every rank sees ITS gpu as cuda:0 and some runtimes report one uuid (or none) for all
+    devices — host + PCI address then decides (vaura_amd.dist.ranks_seen records it); two ranks on one address are still refused."""
+    from vaura_amd import dist as vdist
+    iso = [{"rank": r, "device": "cuda:0", "uuid": "00000000-0000", "pci": f"box/0000:{0x10 + r:02x}:00"} for r in range(8)]
+    vdist.assert_distinct_devices(iso)
+    vdist.assert_distinct_devices([{"rank": r, "device": "cuda:0", "uuid": "", "pci": f"box/0000:{0x10 + r:02x}:00"} for r in range(2)])
+    with pytest.raises(RuntimeError):
+        vdist.assert_distinct_devices([dict(r, pci="box/0000:10:00") for r in iso[:2]])
+
+
+def test_bench_gpus_8_launcher_builds_the_children_before_any_hip_call(monkeypatch):
+    """`python bench.py --gpus 8` from a plain shell (WORLD_SIZE unset): the parent only counts GPUs in sysfs, builds ONE
+    torch.distributed.run child command (8 ranks, one node, rendezvous on 127.0.0.1, its own argv passed through, dmabuf IPC in the
+    environment) and relays its status — it never initialises HIP (an exec / fork from a GPU-initialised process takes the box down on
+    this pool).  And in the ranks, the distinct-device assertion comes BEFORE the timed region."""
+    import subprocess
+    import sys as _sys
+    import torch
+    sys_path_had = REPO in _sys.path
+    if not sys_path_had:
+        _sys.path.insert(0, REPO)
+    import bench
+    from vaura_amd import dist as vdist
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(vdist, "count_gpus_without_hip", lambda: 8)
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert bench.self_launch(8, argv) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 <= int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-len(argv) - 1].endswith("bench.py") and cmd[-len(argv):] == argv
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert not torch.cuda.is_initialized()
+    # fewer GPUs than ranks: refused with a message, nothing launched
+    seen.clear()
+    monkeypatch.setattr(vdist, "count_gpus_without_hip", lambda: 1)
+    monkeypatch.delenv("VAURA_BENCH_SHARE_GPU", raising=False)
+    assert bench.self_launch(8, argv) == 2 and not seen
+    # order inside main(): self-launch before anything touches the GPU; distinct devices asserted before the timed region
+    src = open(bench.__file__).read()
+    main = src[src.index("def main():"):]
+    assert main.index("sys.exit(self_launch(") < main.index("vdist.init(") < main.index("torch.cuda.set_device(")
+    assert main.index("vdist.assert_distinct_devices(seen)") < main.index("elapsed, (codes, wav) = timed(step)")
+
+
 def test_synthetic_inputs_are_keyed_by_clip_index():
     a = synth.video_features(8, seed=0)
     b = synth.video_features(4, seed=0, first_clip=4)

@@ -91,10 +91,10 @@ __global__ void audio_loudness_gain_kernel(const float* __restrict__ wav, float*
       ++j; acc = 0.f; inblk = 0;
     }
   }
-  float gain = 1.f;
+  float gain = -1.f;                 // negative = "the reference leaves this clip alone" (returns before gain AND compressor); a computed gain is > 0
   const float rms = (float)sqrt(tot / (double)n);
   const int per = gate / step;                                                   // 4 quarter-blocks per gating block
-  const int64_t nblk = (n >= gate && nsteps <= LOUD_MAX_STEPS) ? (n - gate) / step + 1 : 0;
+  const int64_t nblk = (n >= gate && nsteps <= LOUD_MAX_STEPS) ? (n - gate) / step + 1 : 0;     // (longer clips are refused by the launcher)
   if (rms >= energy_floor && nblk > 0) {
     auto energy = [&](int64_t b) { float e = 0.f; for (int q = 0; q < per; ++q) e += S[b + q]; return e / (float)gate; };
     float s1 = 0.f; int c1 = 0;
@@ -123,12 +123,14 @@ __global__ void audio_loudness_gain_kernel(const float* __restrict__ wav, float*
 __global__ __launch_bounds__(256) void audio_gain_clip_kernel(const float* __restrict__ wav, float* __restrict__ out,
                                                               const float* __restrict__ gains, int64_t n, int compressor) {
   const int clip = blockIdx.y;
-  const float g = gains[clip];
+  const float g0 = gains[clip];
+  const bool untouched = g0 < 0.f;                                             // (an explicit flag: a computed gain of exactly 1 still goes through the compressor)
+  const float g = untouched ? 1.f : g0;
   const float* w = wav + (size_t)clip * n;
   float* o = out + (size_t)clip * n;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float y = w[i] * g;
-    if (compressor && g != 1.f) y = tanhf(y);                                   // (the untouched clips return before the compressor)
+    if (compressor && !untouched) y = tanhf(y);                                 // (the untouched clips return before the compressor)
     o[i] = fminf(fmaxf(y, -1.f), 1.f);                                          // _clip_wav (data_utils.py:389-404)
   }
 }
@@ -142,9 +144,13 @@ int vaura_audio_loudness(const float* wav, float* out, int n_clips, int64_t n_sa
                          int compressor, float energy_floor, float* scratch, vaura_stream_t s_) {
   if (!wav || !out || !scratch || n_clips <= 0 || n_samples <= 0 || sample_rate <= 0) return VAURA_ERR_ARG;
   hipStream_t s = as_stream(s_);
-  const int gate = (int)llround(0.4 * (double)sample_rate);
-  const int step = (int)llround((double)gate * 0.25);
+  // Python's round() (what torchaudio's Loudness uses for its block sizes) rounds halves to EVEN: nearbyint in the default rounding mode
+  const int gate = (int)nearbyint(0.4 * (double)sample_rate);
+  const int step = (int)nearbyint((double)gate * 0.25);
+  // Refused LOUDLY rather than computed wrongly or skipped: a gating block that is not four whole steps (e.g. 11 025 Hz), and
+  // clips longer than the LOUD_MAX_STEPS quarter-blocks the scratch holds (412 s at 44.1 kHz) — the reference would normalise those
   if (step <= 0 || gate % step) return VAURA_ERR_SHAPE;
+  if (n_samples / step > LOUD_MAX_STEPS) return VAURA_ERR_SHAPE;
   // biquad coefficients as torchaudio.functional.{treble_biquad, highpass_biquad} derive them (double), normalised by a0, rounded to fp32
   const double PI = 3.14159265358979323846;
   double w0 = 2.0 * PI * 1500.0 / sample_rate, A = exp(4.0 / 40.0 * log(10.0)), alpha = sin(w0) / 2.0 / (1.0 / sqrt(2.0));

@@ -61,8 +61,14 @@ def ranks_seen(device) -> List[dict]:
     dev = torch.device(device)
     me = {"rank": env_rank()[0], "device": str(dev), "name": torch.cuda.get_device_name(dev) if dev.type == "cuda" else "cpu"}
     if dev.type == "cuda":
+        import socket
         props = torch.cuda.get_device_properties(dev)
         me["uuid"] = str(getattr(props, "uuid", ""))
+        # a stable hardware id that survives per-rank HIP_VISIBLE_DEVICES isolation (every rank then sees ITS gpu as cuda:0) and runtimes
+        # that report one uuid for all devices: host + PCI domain:bus:device
+        bus = getattr(props, "pci_bus_id", None)
+        if bus is not None:
+            me["pci"] = f"{socket.gethostname()}/{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(bus):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}"
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [me]
     out = [None] * dist.get_world_size()
@@ -74,9 +80,12 @@ def assert_distinct_devices(seen: List[dict]) -> None:
     """Every rank of a clip-parallel job must sit on its OWN GPU: two ranks with the same device uuid means a launcher bound them
     to one device, and the aggregate rate would be a shared-GPU artefact (and the one-launch MLP's in-launch hand-off would starve,
     csrc/mlp_engine.h).  Raises on every rank that sees the list (all of them: ``ranks_seen`` is an all-gather)."""
-    uu, dv = [r.get("uuid") for r in seen], [r.get("device") for r in seen]
+    uu, dv, pci = [r.get("uuid") for r in seen], [r.get("device") for r in seen], [r.get("pci") for r in seen]
     ids = [(u or d) for u, d in zip(uu, dv)]
-    if len(seen) > 1 and all(uu) and len(set(uu)) == 1 and len(set(dv)) == len(seen):
+    if len(seen) > 1 and all(pci):
+        # host + PCI address: what physically distinguishes two GPUs, whatever the ranks' device indices or the runtime's uuids say
+        ids = pci
+    elif len(seen) > 1 and all(uu) and len(set(uu)) == 1 and len(set(dv)) == len(seen):
         # a runtime that reports ONE uuid for every device (seen on some ROCm builds) while every rank sits on its own device index:
         # the uuid does not distinguish anything there — judge by the device index instead of failing a correct launch
         ids = dv
