@@ -260,8 +260,13 @@ static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
 // aq != nullptr: the next layer's qkv GEMV (K-split, two partial outputs) as a third phase of the same launch
 // att != nullptr (with aq, one row block): the next layer's attention as a fourth phase (flags: 704 words)
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq, uint32_t* flags, int32_t* state, int layer,
-                         hipStream_t s, const VaEngineAttention* att) {
+                         hipStream_t s, const VaEngineAttention* att, const void* warm_ptr, size_t warm_bytes) {
   MlpEngineArgs e;
+  // second flag word, bits 8..12: sixteenths (1..16) of `warm_bytes` the idle workgroups touch (0 = off); bit 13: start early
+  const unsigned six = (va_debug_flags2 >> 8) & 31u;
+  e.pf_ptr = static_cast<const unsigned char*>(warm_ptr);
+  e.pf_lines = (warm_ptr && six) ? (int)((warm_bytes / 128) * (six > 16 ? 16 : six) / 16) : 0;
+  e.pf_early = (int)((va_debug_flags2 >> 13) & 1u);
   e.att_rope = nullptr; e.att_kc = e.att_vc = e.att_out = nullptr; e.att_outp = nullptr; e.att_max_len = 0;
   if (att) {
     if (!aq || a13.R != 1 || !att->rope || !att->kc || !att->vc || !att->out || att->n_head != 16 || att->max_len > 256 || att->max_len < 1)

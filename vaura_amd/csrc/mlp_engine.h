@@ -75,6 +75,12 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
+  // Infinity-Cache warm-up by the 64 workgroups that have no phase-2 / phase-3 duty (round 6): once the first hand-off has passed (the
+  // HBM pipe then runs far below its rate until the launch ends) they touch one dword per 128-byte line of pf_lines lines of what a
+  // LATER launch will stream — the next layer's w1||w3 — so that stream is served from the 256 MiB memory-side cache instead of HBM.
+  const unsigned char* pf_ptr;
+  int pf_lines;            // 0 = off
+  int pf_early;            // 1: start right behind the workgroup's own publish instead of behind the first hand-off
   // ATT instances (round 5): the NEXT layer's attention as a fourth phase — K / V cache of that layer (this (row, head)'s rows are
   // requested while the qkv phase still runs), rope table, outputs (fp32 packed rows + planes for wo); flags + 512 .. 703: qkv producers
   const float* att_rope;
@@ -530,6 +536,30 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   }
   if (bid >= 192) {
     if constexpr (!ATT) {
+      if (e.pf_lines > 0) {
+        // helper: wait (bounded, like a consumer) until every phase-1 producer has published, then touch
+        if (!e.pf_early) {
+          (void)mlpe_poll_flags(e.flags, 64, epoch, e, wid, lane);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        const int t0 = (bid - 192) * (MLPE_NW * 64) + (int)threadIdx.x;       // 0 .. 32767
+        const unsigned char* base = e.pf_ptr;
+        // at most 12 lines per thread (w1||w3 on two planes: 393 216 lines over 32 768 threads); every load is issued before anything
+        // waits, and the destination registers stay live up to the wait (the compiler does not know these asm statements are loads)
+        uint32_t v[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+          const int i = t0 + j * (64 * MLPE_NW * 64);
+          const unsigned char* ptr = base + (size_t)(i < e.pf_lines ? i : t0 % e.pf_lines) * 128;      // past the end: a line already requested
+          asm volatile("global_load_dword %0, %1, off nt" : "=v"(v[j]) : "v"(ptr) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                       "+v"(v[10]), "+v"(v[11])
+                     :
+                     : "memory");
+      }
       VA_STAMP_FLUSH(stamps, 11);
     } else {
       att_request();                           // no w2 / qkv tile here: this (row, head)'s K / V rows at once,
