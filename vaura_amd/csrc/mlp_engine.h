@@ -75,6 +75,7 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
+  // EXPERIMENT builds only (-DVAURA_EXPERIMENT_ENGINES; measured negative: the launch grows by 6.8 .. 10.7 us, profiles/r06_ab_mall_warm.txt).
   // Infinity-Cache warm-up by the 64 workgroups that have no phase-2 / phase-3 duty (round 6): once the first hand-off has passed (the
   // HBM pipe then runs far below its rate until the launch ends) they touch one dword per 128-byte line of pf_lines lines of what a
   // LATER launch will stream — the next layer's w1||w3 — so that stream is served from the 256 MiB memory-side cache instead of HBM.
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   }
   if (bid >= 192) {
     if constexpr (!ATT) {
+#ifdef VAURA_EXPERIMENT_ENGINES      // measured negative (round 6, profiles/r06_ab_mall_warm.txt): experiment builds only
       if (e.pf_lines > 0) {
         // helper: wait (bounded, like a consumer) until every phase-1 producer has published, then touch
         if (!e.pf_early) {
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
                      :
                      : "memory");
       }
+#endif
       VA_STAMP_FLUSH(stamps, 11);
     } else {
       att_request();                           // no w2 / qkv tile here: this (row, head)'s K / V rows at once,
