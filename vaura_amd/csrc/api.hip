@@ -208,7 +208,8 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
       // what the idle workgroups of this launch may warm in the Infinity Cache: the NEXT layer's w1||w3 (its first consumer)
       const void* warm = l + 1 < m.n_layer ? d->layers_host[l + 1].w13 : nullptr;
       const size_t warm_bytes = (size_t)2 * F * D * (d->wdtype == VAURA_W_H2 ? 4 : (va_is_fp8(d->wdtype) ? 1 : 2));
-      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s, with_attn ? &att : nullptr, warm, warm_bytes);
+      rc = va_launch_mlp_engine(a13, a2, with_qkv ? &aqn : nullptr, d->ws_sync, d->state, l, s, with_attn ? &att : nullptr, warm, warm_bytes,
+                                l + 1 < m.n_layer ? d->layers_host[l + 1].wo : nullptr, warm_bytes * D / (2 * F));
       PROF_A(VAURA_K_W13);
       if (rc) return rc;
       qkv_done = with_qkv;

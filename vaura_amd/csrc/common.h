@@ -201,7 +201,8 @@ struct VaEngineAttention {     // the next layer's attention as a fourth phase o
   int n_head, max_len;
 };
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq_next, uint32_t* flags, int32_t* state, int layer,
-                         hipStream_t s, const VaEngineAttention* att = nullptr, const void* warm_ptr = nullptr, size_t warm_bytes = 0);
+                         hipStream_t s, const VaEngineAttention* att = nullptr, const void* warm_ptr = nullptr, size_t warm_bytes = 0,
+                         const void* warm0_ptr = nullptr, size_t warm0_bytes = 0);
 // experiment builds only (-DVAURA_EXPERIMENT_ENGINES: csrc/experiments/)
 int va_launch_attn_wo(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out, uint16_t* outp,
                       int rows, int n_head, int max_len, const int32_t* state, const Gemv3Args& awo, uint32_t* flags, int layer, hipStream_t s);

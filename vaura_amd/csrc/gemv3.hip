@@ -260,13 +260,16 @@ static int launch_mlp_engine_t(const MlpEngineArgs& e, hipStream_t s) {
 // aq != nullptr: the next layer's qkv GEMV (K-split, two partial outputs) as a third phase of the same launch
 // att != nullptr (with aq, one row block): the next layer's attention as a fourth phase (flags: 704 words)
 int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3Args* aq, uint32_t* flags, int32_t* state, int layer,
-                         hipStream_t s, const VaEngineAttention* att, const void* warm_ptr, size_t warm_bytes) {
+                         hipStream_t s, const VaEngineAttention* att, const void* warm_ptr, size_t warm_bytes, const void* warm0_ptr,
+                         size_t warm0_bytes) {
   MlpEngineArgs e;
   // second flag word, bits 8..12: sixteenths (1..16) of `warm_bytes` the idle workgroups touch (0 = off); bit 13: start early
   const unsigned six = (va_debug_flags2 >> 8) & 31u;
   e.pf_ptr = static_cast<const unsigned char*>(warm_ptr);
   e.pf_lines = (warm_ptr && six) ? (int)((warm_bytes / 128) * (six > 16 ? 16 : six) / 16) : 0;
   e.pf_early = (int)((va_debug_flags2 >> 13) & 1u);
+  e.pf_ptr0 = static_cast<const unsigned char*>(warm0_ptr);                 // bit 14: the first region (the next layer's wo), whole
+  e.pf_lines0 = (warm0_ptr && (va_debug_flags2 & 0x4000u)) ? (int)(warm0_bytes / 128) : 0;
   e.att_rope = nullptr; e.att_kc = e.att_vc = e.att_out = nullptr; e.att_outp = nullptr; e.att_max_len = 0;
   if (att) {
     if (!aq || a13.R != 1 || !att->rope || !att->kc || !att->vc || !att->out || att->n_head != 16 || att->max_len > 256 || att->max_len < 1)

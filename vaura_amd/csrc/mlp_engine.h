@@ -81,6 +81,8 @@ struct MlpEngineArgs {
   // LATER launch will stream — the next layer's w1||w3 — so that stream is served from the 256 MiB memory-side cache instead of HBM.
   const unsigned char* pf_ptr;
   int pf_lines;            // 0 = off
+  const unsigned char* pf_ptr0;      // a first region touched before it (the next layer's wo)
+  int pf_lines0;
   int pf_early;            // 1: start right behind the workgroup's own publish instead of behind the first hand-off
   // ATT instances (round 5): the NEXT layer's attention as a fourth phase — K / V cache of that layer (this (row, head)'s rows are
   // requested while the qkv phase still runs), rope table, outputs (fp32 packed rows + planes for wo); flags + 512 .. 703: qkv producers
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
   if (bid >= 192) {
     if constexpr (!ATT) {
 #ifdef VAURA_EXPERIMENT_ENGINES      // measured negative (round 6, profiles/r06_ab_mall_warm.txt): experiment builds only
-      if (e.pf_lines > 0) {
+      if (e.pf_lines + e.pf_lines0 > 0) {
         // helper: wait (bounded, like a consumer) until every phase-1 producer has published, then touch
         if (!e.pf_early) {
           (void)mlpe_poll_flags(e.flags, 64, epoch, e, wid, lane);
@@ -546,15 +548,20 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
           asm volatile("" ::: "memory");
         }
         const int t0 = (bid - 192) * (MLPE_NW * 64) + (int)threadIdx.x;       // 0 .. 32767
-        const unsigned char* base = e.pf_ptr;
         // at most 12 lines per thread (w1||w3 on two planes: 393 216 lines over 32 768 threads); every load is issued before anything
-        // waits, and the destination registers stay live up to the wait (the compiler does not know these asm statements are loads)
-        uint32_t v[12];
+        // waits, and the destination registers stay live up to the wait (the compiler does not know these asm statements are loads).
+        // Two regions: [0, pf_lines0) of pf_ptr0 (the next layer's wo) first, then [0, pf_lines) of pf_ptr (its w1||w3).
+        uint32_t v[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int total = e.pf_lines0 + e.pf_lines;
+        const int npt = (total + 64 * MLPE_NW * 64 - 1) / (64 * MLPE_NW * 64);        // uniform
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-          const int i = t0 + j * (64 * MLPE_NW * 64);
-          const unsigned char* ptr = base + (size_t)(i < e.pf_lines ? i : t0 % e.pf_lines) * 128;      // past the end: a line already requested
-          asm volatile("global_load_dword %0, %1, off nt" : "=v"(v[j]) : "v"(ptr) : "memory");
+          if (j < npt) {
+            int i = t0 + j * (64 * MLPE_NW * 64);
+            if (i >= total) i = t0 % total;                                            // past the end: a line already requested
+            const unsigned char* ptr = i < e.pf_lines0 ? e.pf_ptr0 + (size_t)i * 128 : e.pf_ptr + (size_t)(i - e.pf_lines0) * 128;
+            asm volatile("global_load_dword %0, %1, off nt" : "=v"(v[j]) : "v"(ptr) : "memory");
+          }
         }
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
