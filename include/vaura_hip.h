@@ -130,7 +130,9 @@ typedef struct vaura_decoder {
                               are powers of two, so the tiles are the same bits).  Exact in both directions unless a plane value drops
                               into fp16's subnormals; buys 2^S of head-room before |activation| > 65504 raises
                               VAURA_STATUS_NONFINITE_LOGITS.  0 = the layout every parity number was taken on */
-  int32_t _pad_plane_shift;
+  int32_t kv_dtype;        /* 0: the K / V cache is fp32 (every parity number).  1 (round 6; the low-precision serving configuration, BASELINE
+                              configs[4]): fp16 — kcache / vcache then point at (n_layer, rows, n_head, max_len, head_dim) HALVES holding
+                              fp16(rotated k) / fp16(v); caches of at most 256 positions only (VAURA_ERR_SHAPE otherwise); tolerance reported */
 
   const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
   const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles (VAURA_W_H1 when wdtype is FP8) llama.py:356-361 */
@@ -143,7 +145,7 @@ typedef struct vaura_decoder {
   const float* rope;         /* (max_len, head_dim/2, 2) cos,sin                   llama.py:593-603 */
   const float* cond_proj;    /* packed rows (rows*Tv x cond_dim): vaura_prefill_cond output */
 
-  float*   kcache;           /* (n_layer, rows, n_head, max_len, head_dim) fp32, rotated keys */
+  float*   kcache;           /* (n_layer, rows, n_head, max_len, head_dim) fp32 (fp16 when kv_dtype = 1), rotated keys */
   float*   vcache;           /* same shape                                          */
   int32_t* seq;              /* (B, K, S) pattern sequence, -1 = unknown            vaura_model.py:485-493 */
   int32_t* state;            /* 8 words: [0]=position of the token being fed, [1]=arrival counter, [2]=step index, [3] sequence id,

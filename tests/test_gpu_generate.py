@@ -1564,3 +1564,60 @@ def test_near_tie_detector_never_changes_a_token(tiny_sampler_sd, kw):
         flagged.append(eng.last_near_ties[0])
     assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
     assert flagged[0] == 0 and flagged[2] > flagged[1] and flagged[2] >= 20, flagged
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 6: the fp16 K/V cache (vaura_decoder.kv_dtype = 1; DecoderEngine(kv_dtype="f16")) of the low-precision serving configuration.
+@pytest.mark.parametrize("wdtype", ["h1", "fp8h"])
+def test_fp16_kv_cache_tolerance_and_prefill_consistency(wdtype, monkeypatch):
+    """kv_dtype="f16": the cache holds fp16(rotated k) / fp16(v); everything else of the attention stays fp32.  No reference counterpart
+    (the reference has no cache at all): what is checked is (1) the tolerance against the fp32 cache of the same engine — teacher-forced
+    logits move by ~1e-3 of their RMS (reported) and NOT by zero; (2) the two writers / readers of the cache agree: a 40-frame prompt
+    teacher-forced through the batched prefill path (rope_append_kernel writes fp16, the MFMA prefill attention widens it) and through
+    single decode steps (attention_step256_kernel appends and reads) must leave the same logits at the first sampled position up to
+    fp32 summation order; (3) generation runs in range with a clean status word; (4) a cache longer than 256 positions is refused."""
+    cfg = synth.tiny_sampler(3)
+    sd = synth.sampler_state_dict(cfg, seed=131)
+    B = 5
+    feats = synth.video_features(2 * B, seed=132).to(DEV)
+    idx = torch.randint(0, 1024, (2 * B, 9, 48), generator=torch.Generator().manual_seed(133)).to(DEV)
+    e32 = DecoderEngine(cfg, sd, DEV, wdtype=wdtype)
+    e16 = DecoderEngine(cfg, sd, DEV, wdtype=wdtype, kv_dtype="f16")
+    lg32 = e32.logits_all_positions(idx, feats).cpu()
+    lg16 = e16.logits_all_positions(idx, feats).cpu()
+    assert e16.kcache.dtype == torch.float16 and e16.dec.kv_dtype == 1
+    rel = float((lg16 - lg32).pow(2).mean().sqrt() / lg32.pow(2).mean().sqrt())
+    print(f"fp16 K/V cache [{wdtype}]: teacher-forced logits rel-RMS vs the fp32 cache {rel:.3e}, max abs {float((lg16 - lg32).abs().max()):.3e}")
+    assert 1e-7 < rel < 5e-3, rel
+    assert torch.equal(lg16[:, :, 0], lg32[:, :, 0])                 # position 0 attends to nothing cached: bit-identical
+    # (2) prefill writers / readers against the step kernel
+    prompt = torch.randint(0, 1024, (B, 9, 40), generator=torch.Generator().manual_seed(134)).to(DEV)
+    caches = {}
+    for pp in (192, 1):                                             # one batched pass | position by position (decode steps without sampling)
+        monkeypatch.setattr(DecoderEngine, "PREFILL_POSITIONS", pp)
+        e = DecoderEngine(cfg, sd, DEV, wdtype=wdtype, kv_dtype="f16")
+        tok = e.generate_codes(feats[:B], 41, prompt=prompt, cfg_scale=6.0, use_graph=False).cpu()
+        e.check_status()
+        assert torch.equal(tok[:, :, :40], prompt.cpu()) and int(tok.min()) >= 0 and int(tok.max()) <= 1024
+        caches[pp] = (e.kcache[:, :, :, :40].float().cpu(), e.vcache[:, :, :, :40].float().cpu())
+        del e
+    # layer 0's K / V depend on the writers only; deeper layers also on the readers (a reader that mis-read the fp16 rows would change
+    # every deeper layer's K / V grossly).  The two paths sum in different orders (K-split GEMV + step attention vs GEMM + MFMA prefill
+    # attention): fp16 values may differ by an ulp here and there, nothing more.
+    for a, b in zip(caches[192], caches[1]):
+        same = float((a == b).float().mean())
+        worst = float(((a - b).abs() / (torch.maximum(a.abs(), b.abs()) + 1e-3)).max())
+        print(f"fp16 K/V cache [{wdtype}]: batched prefill vs single steps: {same:.5f} of the cached values identical, worst relative difference {worst:.2e}")
+        assert same > 0.98 and worst < 4e-3, (same, worst)
+    # (3) a sampled run, (4) the refusal
+    monkeypatch.setattr(DecoderEngine, "PREFILL_POSITIONS", 192)
+    tok = e16.generate_codes_checked(feats[:B], 30, cfg_scale=6.0, use_sampling=True, top_k=250, seed=5).cpu()
+    assert int(tok.min()) >= 0 and int(tok.max()) < 1024
+    with pytest.raises(L_VauraHipError()):
+        DecoderEngine(synth.SamplerCfg(num_layers=2, block_size_audio=1024), synth.sampler_state_dict(synth.SamplerCfg(num_layers=2, block_size_audio=1024), seed=1),
+                      DEV, wdtype="h1", kv_dtype="f16").generate_codes(synth.video_features(1, tokens=128, seed=2).to(DEV), 300)
+
+
+def L_VauraHipError():
+    from vaura_amd import _lib as L
+    return L.VauraHipError

@@ -41,7 +41,7 @@ class Decoder(C.Structure):
     _fields_ = [("dims", Dims), ("wdtype", C.c_int32), ("batch", C.c_int32), ("rows", C.c_int32),
                 ("max_len", C.c_int32), ("timesteps", C.c_int32), ("seq_len", C.c_int32),
                 ("n_cond_tokens", C.c_int32), ("prefill_positions", C.c_int32),
-                ("plane_shift", C.c_int32), ("_pad_plane_shift", C.c_int32),
+                ("plane_shift", C.c_int32), ("kv_dtype", C.c_int32),
                 ("layers_host", C.POINTER(LayerWeights)), ("heads", C.c_void_p), ("final_norm", C.c_void_p),
                 ("tok_emb", C.c_void_p), ("tok_proj_w", C.c_void_p), ("tok_proj_b", C.c_void_p), ("tok_table", C.c_void_p),
                 ("empty_video", C.c_void_p), ("rope", C.c_void_p), ("cond_proj", C.c_void_p),

@@ -24,6 +24,8 @@ static int check_decoder(const vaura_decoder* d) {
   if (d->rows != d->batch && d->rows != 2 * d->batch) return VAURA_ERR_ARG;
   if (d->seq_len > d->max_len || d->batch <= 0) return VAURA_ERR_ARG;
   if (d->plane_shift < 0 || d->plane_shift > 24 || (d->plane_shift && !d->ws_h_split)) return VAURA_ERR_ARG;
+  if (d->kv_dtype != 0 && d->kv_dtype != 1) return VAURA_ERR_ARG;
+  if (d->kv_dtype == 1 && (d->max_len > 256 || !d->ws_h_split)) return VAURA_ERR_SHAPE;      // fp16 K / V: the pair path's single-round-trip attention only
   return 0;
 }
 
@@ -163,10 +165,10 @@ static int enqueue_step_bf16(const vaura_decoder* d, const vaura_sampling* sp, i
 #endif
     } else {
     PROF_B(VAURA_K_ATTN);  // rope + cache append + softmax(qK^T)V                     llama.py:234-257
-    rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, d->kcache + l * kv_layer, d->vcache + l * kv_layer, d->ws_attn,
+    rc = va_launch_attention(d->ws_qkv, qkv2, d->rope, va_kv_layer(d, d->kcache, l), va_kv_layer(d, d->vcache, l), d->ws_attn,
                              d->ws_attn_split, rows, H, hd, d->max_len, d->state, 0, d->ws_attn_part,
                              d->ws_attn_part ? va_attention_splits(rows, H, d->max_len) : 1, s,
-                             d->ws_sync ? d->ws_sync + 512 : nullptr, ldexpf(1.f, -d->plane_shift));      // words 512 .. 767: arrival counts of the range-split attention (the MLP / tail engines use 0 .. 511; the attention + wo experiment uses 512 .. only with caches <= 256, where nothing is split)
+                             d->ws_sync ? d->ws_sync + 512 : nullptr, ldexpf(1.f, -d->plane_shift), d->kv_dtype);      // words 512 .. 767: arrival counts of the range-split attention (the MLP / tail engines use 0 .. 511; the attention + wo experiment uses 512 .. only with caches <= 256, where nothing is split)
     PROF_A(VAURA_K_ATTN);
     if (rc) return rc;
     }

@@ -190,6 +190,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_step_kernel(
 // workgroup barriers in total.
 #define ATT1_THREADS 512
 
+// fp16 K/V cache (round 6, vaura_decoder.kv_dtype = 1: the low-precision serving configuration, BASELINE configs[4]): the cache holds
+// fp16(rotated k) / fp16(v), the same [layer][row][head][max_len][96] layout at two bytes per element; everything else (q, scores, softmax,
+// P.V accumulation) stays fp32.  At 32 rows the attention launch IS its K / V stream (44.8 MB of fp32 per layer at the loop's mean length):
+// half the bytes.  A quad of four channels is 8 bytes.
+__device__ __forceinline__ f32x4 kv_quad_to_f32(const uint2 q) {
+  const f16x2 a = __builtin_bit_cast(f16x2, q.x), b = __builtin_bit_cast(f16x2, q.y);
+  return f32x4{(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+}
+__device__ __forceinline__ uint2 kv_quad_to_f16(const f32x4 v) {
+  return uint2{pack_h2((_Float16)v[0], (_Float16)v[1]), pack_h2((_Float16)v[2], (_Float16)v[3])};
+}
+
 // NU = number of 64-position passes that hold cached rows (0..4).  One straight-line body per NU: the compiler
 // then waits with exact vmcnt values (vmcnt retires in order), and short caches issue no dead loads.
 struct NoHook {
@@ -197,7 +209,7 @@ struct NoHook {
 };
 // `after_requests`: called once every request of the attention itself has been issued (the fused attention + wo launch queues
 // its wo weight requests there: behind the K/V rows, which the dependent chain needs first)
-template <int HD, int NU, typename HOOK = NoHook>
+template <int HD, int NU, typename HOOK = NoHook, bool KVH = false>
 __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv, const float* __restrict__ qkv2,
                                                   const float* __restrict__ rope,
                                                   float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ out,
@@ -230,18 +242,28 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   const f32x4 gx2 = reinterpret_cast<const f32x4*>(qkv2 ? qkv2 : qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
   const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
   __builtin_amdgcn_sched_barrier(0);   // keep these first in program order (the scheduler sinks them otherwise)
-  f32x4 kf[NUA][QPL], vf[NUA][QPL];
+  // KVH: kc / vc point at fp16 rows (the launcher offsets them in halves); a quad is 8 bytes and is widened where it is used
+  using KVQ = std::conditional_t<KVH, uint2, f32x4>;
+  KVQ kf[NUA][QPL], vf[NUA][QPL];
+  auto kvrow = [&](const float* base, int p) {
+    if constexpr (KVH) return reinterpret_cast<const KVQ*>(reinterpret_cast<const _Float16*>(base) + (size_t)p * HD);
+    else return reinterpret_cast<const KVQ*>(base + (size_t)p * HD);
+  };
+  auto widen = [&](const KVQ& x) -> f32x4 {
+    if constexpr (KVH) return kv_quad_to_f32(x);
+    else return x;
+  };
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int p = min(u * 64 + prow, pos - 1);
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) kf[u][i] = reinterpret_cast<const f32x4*>(kc + (size_t)p * HD)[sub + 8 * i];
+    for (int i = 0; i < QPL; ++i) kf[u][i] = kvrow(kc, p)[sub + 8 * i];
   }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int p = min(u * 64 + prow, pos - 1);
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) vf[u][i] = reinterpret_cast<const f32x4*>(vc + (size_t)p * HD)[sub + 8 * i];
+    for (int i = 0; i < QPL; ++i) vf[u][i] = kvrow(vc, p)[sub + 8 * i];
   }
 
   after_requests();
@@ -261,9 +283,14 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   y[2] = gx[2] * gcs[2] - gx[3] * gcs[3];
   y[3] = gx[3] * gcs[2] + gx[2] * gcs[3];
   if (which == 2) y = gx;   // v is not rotated
+  if constexpr (KVH) {      // the new position's k / v are what later steps will read back: fp16 values, for this step too
+    if (which >= 1) y = kv_quad_to_f32(kv_quad_to_f16(y));
+  }
   sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
-  if (tid >= QUADS && tid < 3 * QUADS)
-    va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD) + cq, y);
+  if (tid >= QUADS && tid < 3 * QUADS) {
+    if constexpr (KVH) va_st8(reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(which == 1 ? kc : vc) + (size_t)pos * HD) + cq, kv_quad_to_f16(y));
+    else va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD) + cq, y);
+  }
   // Only the LDS writes have to be visible behind this barrier.  __syncthreads() would also drain the vector-memory counter, i.e. wait
   // for EVERY cached K and V row before the first score; with a raw barrier the rows stay in flight and the compiler's own counted
   // waits let pass u's scores start when pass u's rows have landed.  (Measured neutral on the 228-step loop, like the unconditional
@@ -300,7 +327,10 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   float m = snew;   // every wave's running max includes the new position, so it is finite
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const float d = dot8(kf[u]) * scale;
+    f32x4 kw[QPL];
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) kw[i] = widen(kf[u][i]);
+    const float d = dot8(kw) * scale;
     sc[u] = (u * 64 + prow < pos) ? d : -INFINITY;
     m = fmaxf(m, sc[u]);
   }
@@ -315,7 +345,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
     const float e = expf(sc[u] - m);   // exp(-inf) = 0 for the masked slots (they hold a finite, valid row)
     if (sub == 0) l += e;
 #pragma unroll
-    for (int i = 0; i < QPL; ++i) av[i] += vf[u][i] * e;
+    for (int i = 0; i < QPL; ++i) av[i] += widen(vf[u][i]) * e;
   }
   l = wave_sum(l);
 #pragma unroll
@@ -362,7 +392,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
 #endif
 }
 
-template <int HD>
+template <int HD, bool KVH = false>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
     // argument order = what the dependent chain needs first (the leading 14 dwords are preloaded into SGPRs)
     const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
@@ -373,14 +403,16 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
   __shared__ float wm[ATT1_THREADS / 64], wl[ATT1_THREADS / 64];
   const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos), pos <= 255
-  float* kc = kcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
-  float* vc = vcache + ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
+  // KVH: the cache is fp16 — the (row, head) offset in HALVES (the pointer stays float* in the signature: same kernarg layout)
+  const size_t off = ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
+  float* kc = KVH ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(kcache) + off) : kcache + off;
+  float* vc = KVH ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(vcache) + off) : vcache + off;
   switch ((pos + 63) >> 6) {
-    case 0: attention256_body<HD, 0>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    case 1: attention256_body<HD, 1>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    case 2: attention256_body<HD, 2>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    case 3: attention256_body<HD, 3>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    default: attention256_body<HD, 4>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 0: attention256_body<HD, 0, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 1: attention256_body<HD, 1, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 2: attention256_body<HD, 2, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 3: attention256_body<HD, 3, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    default: attention256_body<HD, 4, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
   }
 }
 
@@ -663,7 +695,7 @@ __global__ __launch_bounds__(64) void attention_combine_kernel(const float* __re
 }
 
 // rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
-template <int HD>
+template <int HD, bool KVH = false>
 __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qkv, const float* __restrict__ rope,
                                                           float* __restrict__ kcache, float* __restrict__ vcache, int n_head,
                                                           int max_len, int p0, int rows16) {
@@ -687,8 +719,13 @@ __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qk
   }
   const size_t cbase = (((size_t)row * n_head + h) * (size_t)max_len + pos) * HD;
   if (which == 0) *src = x;
-  if (which == 1) reinterpret_cast<f32x4*>(kcache + cbase)[cq] = x;
-  if (which == 2) reinterpret_cast<f32x4*>(vcache + cbase)[cq] = x;
+  if constexpr (KVH) {
+    if (which == 1) reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(kcache) + cbase)[cq] = kv_quad_to_f16(x);
+    if (which == 2) reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(vcache) + cbase)[cq] = kv_quad_to_f16(x);
+  } else {
+    if (which == 1) reinterpret_cast<f32x4*>(kcache + cbase)[cq] = x;
+    if (which == 2) reinterpret_cast<f32x4*>(vcache + cbase)[cq] = x;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -704,7 +741,7 @@ __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qk
 // accumulator register s the lane already holds.  q was rotated in place and k / v appended by rope_append_kernel.
 #define APF_Q 64
 #define APF_STRIDE 100      // floats per staged K / V row: 16 keys x 4-bank reads land on 64 distinct banks (36 k mod 64)
-template <int HD>
+template <int HD, bool KVH = false>
 __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ kcache,
                                                                 const float* __restrict__ vcache, float* __restrict__ out,
                                                                 uint16_t* __restrict__ outp, int n_head, int max_len, int p0, int n_pos,
@@ -721,8 +758,9 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
   const int qi = q0 + ql;                                       // this lane's query as B-operand column / softmax owner
   const int qpos = p0 + qi;
   const float scale = 1.0f / sqrtf((float)HD);
-  const float* kc = kcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
-  const float* vc = vcache + ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  const size_t kvoff = ((size_t)row * n_head + h) * (size_t)max_len * HD;
+  const float* kc = KVH ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(kcache) + kvoff) : kcache + kvoff;
+  const float* vc = KVH ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(vcache) + kvoff) : vcache + kvoff;
   // Q^T operand: lane (q, g) holds Q[q][24 g + s], s = 0..23 (queries past the chunk read the last valid row; never stored)
   float qreg[KS];
   {
@@ -745,8 +783,13 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     for (int u = tid; u < 64 * (HD / 4); u += 256) {
       const int j = u / (HD / 4), c = u % (HD / 4);
       const int kp = min(kb + j, last_q);
-      *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(kc + (size_t)kp * HD)[c];
-      *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(vc + (size_t)kp * HD)[c];
+      if constexpr (KVH) {      // fp16 cache: widened on the way into the fp32 staging (the products stay exact-fp32 MFMAs on fp16 values)
+        *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = kv_quad_to_f32(reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(kc) + (size_t)kp * HD)[c]);
+        *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = kv_quad_to_f32(reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(vc) + (size_t)kp * HD)[c]);
+      } else {
+        *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(kc + (size_t)kp * HD)[c];
+        *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(vc + (size_t)kp * HD)[c];
+      }
     }
     __syncthreads();
     if (q0 < n_pos) {
@@ -835,9 +878,11 @@ int va_attention_splits(int rows, int n_head, int max_len) {
 
 int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
-                        float* part, int n_split, hipStream_t s, uint32_t* arrivals, float pscale) {
+                        float* part, int n_split, hipStream_t s, uint32_t* arrivals, float pscale, int kv_half) {
   if (!qkv || !rope || !kc || !vc || !out || rows <= 0 || n_head <= 0) return VAURA_ERR_ARG;
   if (head_dim != 96) return VAURA_ERR_SHAPE;
+  // fp16 K / V cache: the single-round-trip kernel only (every 2.56 s configuration); long caches / range splits keep fp32
+  if (kv_half && (max_len > 256 || (part && n_split > 1))) return VAURA_ERR_SHAPE;
   if (part && n_split > 1) {   // few (row, head) pairs over a long cache: split the range, then combine
     if (n_split > 8) return VAURA_ERR_ARG;
     // arrivals (rows * n_head zeroed words, e.g. the decoder's ws_sync + 512): the last split to arrive merges; debug flag bit 19: own launch
@@ -848,8 +893,12 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
     return 0;
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
-    VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
-              n_head, max_len, pos_host, out, outp, pscale);
+    if (kv_half)
+      VA_LAUNCH((attention_step256_kernel<96, true>), dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
+                n_head, max_len, pos_host, out, outp, pscale);
+    else
+      VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
+                n_head, max_len, pos_host, out, outp, pscale);
     return 0;
   }
   const size_t smem = sizeof(float) * (size_t)(3 * 96 + 4 * 96 + 8 + max_len + 4);
@@ -867,6 +916,11 @@ int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, 
   const int H = d->dims.n_head, hd = d->dims.d_model / H;
   if (hd != 96) return VAURA_ERR_SHAPE;
   const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
+  if (d->kv_dtype == 1) {      // fp16 cache: the layer offset in halves
+    VA_LAUNCH((rope_append_kernel<96, true>), dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, va_kv_layer(d, d->kcache, layer),
+              va_kv_layer(d, d->vcache, layer), H, d->max_len, p0, (d->rows + 15) / 16 * 16);
+    return 0;
+  }
   VA_LAUNCH(rope_append_kernel<96>, dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, d->kcache + layer * kv_layer,
             d->vcache + layer * kv_layer, H, d->max_len, p0, (d->rows + 15) / 16 * 16);
   return 0;
@@ -877,6 +931,12 @@ int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n
   const int H = d->dims.n_head, hd = d->dims.d_model / H;
   if (hd != 96) return VAURA_ERR_SHAPE;
   const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
+  if (d->kv_dtype == 1) {
+    VA_LAUNCH((attention_prefill_kernel<96, true>), dim3(H, d->rows, (n_pos + APF_Q - 1) / APF_Q), dim3(256), 0, s, (const float*)d->ws_qkv,
+              (const float*)va_kv_layer(d, d->kcache, layer), (const float*)va_kv_layer(d, d->vcache, layer), d->ws_attn, d->ws_attn_split, H,
+              d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16, ldexpf(1.f, -d->plane_shift));
+    return 0;
+  }
   if (!(va_debug_flags & 16u)) {
     VA_LAUNCH(attention_prefill_kernel<96>, dim3(H, d->rows, (n_pos + APF_Q - 1) / APF_Q), dim3(256), 0, s, (const float*)d->ws_qkv,
               (const float*)(d->kcache + layer * kv_layer), (const float*)(d->vcache + layer * kv_layer), d->ws_attn, d->ws_attn_split, H,
@@ -894,7 +954,7 @@ extern "C" int vaura_attention_step(const float* qkv, const float* rope, float* 
                                     int rows, int n_head, int head_dim, int max_len, int pos, vaura_stream_t s) {
   if (pos < 0 || pos >= max_len) return VAURA_ERR_ARG;
   return va_launch_attention(qkv, nullptr, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos,
-                             nullptr, 1, as_stream(s));
+                             nullptr, 1, as_stream(s), nullptr, 1.f, 0);
 }
 
 extern "C" int vaura_attention_splits(int rows, int n_head, int max_len) { return va_attention_splits(rows, n_head, max_len); }
@@ -904,5 +964,5 @@ extern "C" int vaura_attention_step_split(const float* qkv, const float* rope, f
                                           vaura_stream_t s) {
   if (pos < 0 || pos >= max_len || !part || n_split < 2 || n_split > 8) return VAURA_ERR_ARG;
   return va_launch_attention(qkv, nullptr, rope, kcache, vcache, out, nullptr, rows, n_head, head_dim, max_len, nullptr, pos,
-                             part, n_split, as_stream(s));
+                             part, n_split, as_stream(s), nullptr, 1.f, 0);
 }

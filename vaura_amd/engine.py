@@ -151,7 +151,7 @@ class DecoderEngine:
 
     def __init__(self, cfg: SamplerCfg, sd: Dict[str, torch.Tensor], device="cuda:0", wdtype: str = "auto",
                  one_launch_mlp: bool = True, range_fallback: bool = True, plane_shift: int = 0,
-                 near_tie: str = "report", near_tie_eps: Optional[float] = None):
+                 near_tie: str = "report", near_tie_eps: Optional[float] = None, kv_dtype: str = "f32"):
         """wdtype: storage of the streamed matrices — "auto" | "h1" | "h2" | "fp8" | "fp8h" | "f32" (``resolve_weight_dtype``).
         one_launch_mlp: let the library run w1||w3 -> w2 of a layer as ONE launch with an in-launch hand-off where the shape
         is eligible (1..16 decoder rows, fp16-plane weights, >= 256 CUs; csrc/mlp_engine.h: bit-identical results, -5..7 % on the
@@ -176,6 +176,11 @@ class DecoderEngine:
         self.near_ties = 0                   # decisions flagged so far (all calls)
         self.last_near_ties = (0, None)      # (count, first flagged step) of the last checked call
         self.near_tie_reruns = 0
+        # K / V cache: "f32" (every parity number) or "f16" (round 6; the low-precision serving configuration, BASELINE configs[4] together
+        # with weight_dtype="fp8h": fp16(rotated k) / fp16(v), half the attention's stream; caches of at most 256 positions, plane storages)
+        if kv_dtype not in ("f32", "f16"):
+            raise L.VauraHipError(f"kv_dtype must be f32 | f16, got {kv_dtype!r}")
+        self.kv_dtype = kv_dtype
         self.plane_shift = int(plane_shift)
         if not 0 <= self.plane_shift <= 24:
             raise L.VauraHipError(f"plane_shift must be in 0..24, got {plane_shift}")
@@ -299,7 +304,13 @@ class DecoderEngine:
             rp = self._rows_padded(rows) * pp     # decode uses the first position's worth of row blocks
             f32 = dict(dtype=torch.float32, device=self.dev)
             self.rope = rope_table(max_len, c.head_dim, c.rope_base).to(self.dev)
-            self.kcache = torch.zeros(c.num_layers, rows, c.nhead, max_len, c.head_dim, **f32)
+            if self.kv_dtype == "f16":
+                if max_len > 256 or not self.planes:
+                    raise L.VauraHipError(f"kv_dtype='f16' serves caches of at most 256 positions on the fp16-plane storages (got max_len {max_len}, "
+                                          f"weights {self.wdtype})")
+                self.kcache = torch.zeros(c.num_layers, rows, c.nhead, max_len, c.head_dim, dtype=torch.float16, device=self.dev)
+            else:
+                self.kcache = torch.zeros(c.num_layers, rows, c.nhead, max_len, c.head_dim, **f32)
             self.vcache = torch.zeros_like(self.kcache)
             self.seq = torch.zeros(batch, K, S, dtype=torch.int32, device=self.dev)
             self.state = torch.zeros(8, dtype=torch.int32, device=self.dev)   # include/vaura_hip.h: position, arrivals, step, id, STATUS, spare
@@ -329,6 +340,7 @@ class DecoderEngine:
         d.timesteps, d.seq_len, d.n_cond_tokens = timesteps, S, n_cond_tokens
         d.prefill_positions = self._prefill_positions
         d.plane_shift = self.plane_shift
+        d.kv_dtype = 1 if self.kv_dtype == "f16" else 0
         d.layers_host = C.cast(self.layers, C.POINTER(L.LayerWeights))
         d.heads, d.final_norm = L.ptr(self.heads), L.ptr(self.final_norm)
         d.tok_emb, d.tok_proj_w, d.tok_proj_b = L.ptr(self.tok_emb), L.ptr(self.tok_w), L.ptr(self.tok_b)
