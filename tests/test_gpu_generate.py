@@ -1589,7 +1589,7 @@ def test_fp16_kv_cache_tolerance_and_prefill_consistency(wdtype, monkeypatch):
     rel = float((lg16 - lg32).pow(2).mean().sqrt() / lg32.pow(2).mean().sqrt())
     print(f"fp16 K/V cache [{wdtype}]: teacher-forced logits rel-RMS vs the fp32 cache {rel:.3e}, max abs {float((lg16 - lg32).abs().max()):.3e}")
     assert 1e-7 < rel < 5e-3, rel
-    assert torch.equal(lg16[:, :, 0], lg32[:, :, 0])                 # position 0 attends to nothing cached: bit-identical
+    # (position 0 differs too: the new position's own k / v are the fp16 values later steps will read back)
     # (2) prefill writers / readers against the step kernel
     prompt = torch.randint(0, 1024, (B, 9, 40), generator=torch.Generator().manual_seed(134)).to(DEV)
     caches = {}
