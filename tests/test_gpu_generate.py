@@ -1608,7 +1608,9 @@ def test_fp16_kv_cache_tolerance_and_prefill_consistency(wdtype, monkeypatch):
         same = float((a == b).float().mean())
         worst = float((a - b).abs().max() / a.abs().max())              # in units of the cache's largest value (an fp16 ulp there is 1e-3)
         print(f"fp16 K/V cache [{wdtype}]: batched prefill vs single steps: {same:.5f} of the cached values identical, worst difference {worst:.2e} of the largest value")
-        assert same > 0.97 and worst < 2e-3, (same, worst)
+        # ("fp8h": a prompt pass multiplies BOTH activation planes — the exact fp8 arithmetic —, a decode step the hi plane only: the values
+        # differ in the last fp16 bit about half the time, by design; the bound on the size of a difference is the same)
+        assert same > (0.97 if wdtype == "h1" else 0.3) and worst < 2e-3, (same, worst)
     # (3) a sampled run, (4) the refusal
     monkeypatch.setattr(DecoderEngine, "PREFILL_POSITIONS", 192)
     tok = e16.generate_codes_checked(feats[:B], 30, cfg_scale=6.0, use_sampling=True, top_k=250, seed=5).cpu()
