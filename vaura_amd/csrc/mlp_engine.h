@@ -96,6 +96,13 @@ struct MlpEngineArgs {
 
 #define MLPE_NW 8
 #define MLPE_SPIN_LIMIT 20000
+// TIMING-ONLY ablation (experiment builds: -DMLPE_ABL_X8, WRONG RESULTS): the activation planes fetched 8 bytes per lane instead of 16 — what an
+// fp8 activation format would move — to price that format before building it (round 6)
+#ifdef MLPE_ABL_X8
+#define MLPE_XLOAD(rs, voff, soff, aux) [&] { const auto v2_ = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, aux); return u32x4{v2_[0], v2_[1], 0x3c003c00u, 0x3c003c00u}; }()
+#else
+#define MLPE_XLOAD(rs, voff, soff, aux) __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux)
+#endif
 
 // RBK = row blocks per weight pass (round 5; gemv3_kernel.h): 2 for 17..32 decoder rows.  The reduction tiles double (48 KB), so the
 // ring gives up a quarter (12 KB per wave) and one more k-group pair per plane travels in registers.
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int g = 0; g < GB; ++g)
 #pragma unroll
           for (int p = 0; p < XPL; ++p)
-            xb[r][b % NXB][g][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xl16, (int)(((r * VA_NPL + p) * (K / 8) * 16 + (w * G + b * GB + g) * 64) * 16), 0);
+            xb[r][b % NXB][g][p] = MLPE_XLOAD(xrs, xl16, (int)(((r * VA_NPL + p) * (K / 8) * 16 + (w * G + b * GB + g) * 64) * 16), 0);
       }
     };
     if constexpr (WBATCH) load_w(0, GB, 0);
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       for (int j = j0; j < j1; ++j)
 #pragma unroll
         for (int p = 0; p < XPL; ++p)
-          xb[r][j][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, ((r * VA_NPL + p) * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
+          xb[r][j][p] = MLPE_XLOAD(xrs, vx, ((r * VA_NPL + p) * (K / 8) * 16 + (w * G2 + j) * 128) * 16, 16 /* sc1 */);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -882,7 +889,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int g = 0; g < G; ++g)
 #pragma unroll
           for (int p = 0; p < XPL; ++p)
-            xq[r][g][p] = __builtin_amdgcn_raw_buffer_load_b128(hrs, xl16, (int)(((r * VA_NPL + p) * (KQ / 8) * 16 + (kgo + w3 * G + g) * 64) * 16), 16 /* sc1 */);
+            xq[r][g][p] = MLPE_XLOAD(hrs, xl16, (int)(((r * VA_NPL + p) * (KQ / 8) * 16 + (kgo + w3 * G + g) * 64) * 16), 16 /* sc1 */);
       }
       constexpr int NSSQ = KQ / 64;
       float ssq[NSSQ];
