@@ -444,7 +444,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       ws1[1] = *reinterpret_cast<const f32x4*>(e.p1.wscale + (size_t)(bid * 2 + 1) * 16 + 4 * q);
     }
     __builtin_amdgcn_sched_barrier(0);                 // every request of the first batch is out before anything is waited for
+#ifndef MLPE_DIAG2
     VA_STAMP(stamps, 1);                               // phase 1: first batch requested
+#endif
     f32x4 acc[RBK][T][NACC];
 #pragma unroll
     for (int r = 0; r < RBK; ++r)
@@ -489,7 +491,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // opens the kernel.  LDS operations of a wave execute in order:
     // the word lands behind the tiles (release: the compiler keeps that order too).
     if (lane == 0) __hip_atomic_store(arrive + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef MLPE_DIAG2
     VA_STAMP(stamps, 2);                               // phase 1: products done, tiles in LDS
+#endif
     if (epw) {
       float ssp = 0.f;
 #pragma unroll
@@ -541,7 +545,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       }
       if (lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + bid), "v"(epoch) : "memory");
       if (MLPE_REL && lane == 0) __hip_atomic_store(arrive + 16, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef MLPE_DIAG2
       VA_STAMP(stamps, 3);                             // wave 0: published
+#endif
     }
   }
   if (bid >= 192) {
@@ -654,7 +660,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         if (Q2 < 4) prefetch_q(std::integral_constant<int, 3>{});
       }
     } else if (!(e.abl & 4)) prefetch_w2();
+#ifndef MLPE_DIAG2
     if (wid != 0) VA_STAMP(stamps, 3);                 // waves 1..7: w2 slice requested
+#endif
 
     // ---- hand-off: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest
     if (wid == 0) {
@@ -707,7 +715,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     VA_WAIT_VM(0);
-#ifndef MLPE_DIAG
+#if !defined(MLPE_DIAG) && !defined(MLPE_DIAG2)
     VA_STAMP(stamps, 5);                               // (diagnostic build) weights and planes landed
 #endif
     f32x4 acc[RBK][2][NACC];
@@ -829,6 +837,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         load_wq_g(std::integral_constant<int, 2>{});
       };
       if (lane == 0) __hip_atomic_store(arrive2 + wid, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MLPE_DIAG2      // second diagnostic stamp set (-DVAURA_STAMPS -DMLPE_DIAG2): the phase 2 -> 3 chain.  slot 1 <- phase-2 products done, 2 <- wave 0
+      VA_STAMP(stamps, 1);   // saw all tiles + epilogue stores issued, 3 <- phase 2 published (drained + flag), 5 <- hand-off 2 passed, 6 <- done
+#endif
       f32x4 wsq = f32x4{1.f, 1.f, 1.f, 1.f};
       const bool epq = wid < TQ * RBK;                 // this wave finishes tile (wid % TQ) of row block (wid / TQ) of the qkv phase
       const int rq = wid / TQ, tq = wid - rq * TQ;
@@ -861,6 +872,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         for (int i = 1; i < NW; ++i) v += red[((wid * NW + i) * 2 + (q >> 1)) * 64 + src];
         v *= ws2;
         if (mine && wid * 16 < a.rows) gemv3_epilogue<1, E3_RESID>(a, wid, tile, lane, &v, &pre);
+#ifdef MLPE_DIAG2
+        VA_STAMP(stamps, 2);
+#endif
         if (wid == 0 && !MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         // publish phase 2: h, its partial sums of squares and its planes are out (write-through), drained, then the flag (two row
         // blocks: wave 1 drains its block's stores and tells wave 0, which publishes for both)
@@ -874,11 +888,17 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         }
         if (wid == 0 && lane == 0) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(e.flags + 256 + bid), "v"(epoch) : "memory");
         if (wid == 0 && MLPE_REL && lane == 0) __hip_atomic_store(arrive + 17, ltag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MLPE_DIAG2
+        VA_STAMP(stamps, 3);
+#endif
         load_wq();
       }
       (void)mlpe_poll_flags(e.flags + 256, 48, epoch, e, wid, lane);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef MLPE_DIAG2
+      VA_STAMP(stamps, 5);
+#endif
       const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aq.XP), 0, aq.R * VA_NPL * (KQ / 8) * 256, 0x00020000);
       const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(aq.ss_in), 0, RBK * 96 * 16 * 4, 0x00020000);
       u32x4 xq[RBK][G][XPL];
