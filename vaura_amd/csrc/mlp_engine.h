@@ -726,28 +726,57 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #pragma unroll
         for (int p = 0; p < NACC; ++p) acc[r][nh][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     // products of row block r over pairs [j0, j1): k order inside a row block is that of gemv3h_kernel, whatever the interleaving
+    // the A operands of pair j, weight-row half nh: from the LDS ring (pairs [0, PL); fp8: all of them, widened) or from registers
+    constexpr int WFN = F32 ? 2 : 1;
+    auto wfetch = [&](int j, int nh, f16x8* wf) {
+      if constexpr (FP8) {      // half sb of the pair's fragment: 8 bytes of lane (la + 8 nh, q)
+        const uint2 pr = *reinterpret_cast<const uint2*>(myring + j * 1024 + (la + 8 * nh + 16 * q) * 16 + sb * 8);
+        wf[0] = fp8x8_to_f16(pr.x, pr.y);
+      } else if (j < PL) {
+        const u32x4* fr = reinterpret_cast<const u32x4*>(myring + ((2 * j + sb) * WH) * 1024) + (la + 8 * nh + 16 * q);
+        wf[0] = __builtin_bit_cast(f16x8, fr[0]);
+        if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, fr[64]);
+      } else {
+        wf[0] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][0]);
+        if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][WH - 1]);
+      }
+    };
+    // Round 6: the fragments of pair j + 1 are fetched (LDS read, fp8 widening) BEFORE the products of pair j are issued — the stamps
+    // (profiles/r06_engine_stamps_diag2.txt) show 1.0 .. 1.7 us between "planes landed" and "products done" for 0.2 .. 0.4 us of matrix
+    // instructions: every pair paid its LDS round trip (and the fp8 -> fp16 conversion) in front of its own products.  Same products into
+    // the same accumulators in the same order: bit-identical.  (-DMLPE_NO_WPIPE: the previous form, for the A/B.)
     auto products = [&](auto rc, auto j0c, auto j1c) {
       constexpr int r = decltype(rc)::value, j0 = decltype(j0c)::value, j1 = decltype(j1c)::value;
+#ifdef MLPE_NO_WPIPE
 #pragma unroll
       for (int j = j0; j < j1; ++j) {
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
-          f16x8 wf[F32 ? 2 : 1];
-          if constexpr (FP8) {      // half sb of the pair's fragment: 8 bytes of lane (la + 8 nh, q)
-            const uint2 pr = *reinterpret_cast<const uint2*>(myring + j * 1024 + (la + 8 * nh + 16 * q) * 16 + sb * 8);
-            wf[0] = fp8x8_to_f16(pr.x, pr.y);
-          } else if (j < PL) {
-            const u32x4* fr = reinterpret_cast<const u32x4*>(myring + ((2 * j + sb) * WH) * 1024) + (la + 8 * nh + 16 * q);
-            wf[0] = __builtin_bit_cast(f16x8, fr[0]);
-            if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, fr[64]);
-          } else {
-            wf[0] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][0]);
-            if constexpr (F32) wf[1] = __builtin_bit_cast(f16x8, wreg[j - PL][nh][WH - 1]);
-          }
+          f16x8 wf[WFN];
+          wfetch(j, nh, wf);
           mfma_group<WT>(wf, xb[r][j], acc[r][nh]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#else
+      f16x8 cur[2][WFN], nxt[2][WFN];
+      wfetch(j0, 0, cur[0]);
+      wfetch(j0, 1, cur[1]);
+#pragma unroll
+      for (int j = j0; j < j1; ++j) {
+        if (j + 1 < j1) {
+          wfetch(j + 1, 0, nxt[0]);
+          wfetch(j + 1, 1, nxt[1]);
+        }
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) mfma_group<WT>(cur[nh], xb[r][j], acc[r][nh]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int i = 0; i < WFN; ++i) cur[nh][i] = nxt[nh][i];
+      }
+#endif
     };
     if constexpr (RBK == 1) {
       products(I0{}, I0{}, IG{});
