@@ -42,14 +42,14 @@ def algorithmic_bytes_per_launch(kind: str, cfg: synth.SamplerCfg, wbytes: int, 
     return float(n * (2 if kind == "heads" and wbytes == 1 else wbytes))   # fp8 keeps the heads in bf16
 
 
-def decode_loop_bytes(cfg: synth.SamplerCfg, wbytes: int, rows: int, steps: int) -> float:
-    """sum_L [ W*b_w + 24*2*Bs*1536*b_kv*(L+1) ], fp32 KV (SURVEY.md §8d with b_kv = 4)."""
+def decode_loop_bytes(cfg: synth.SamplerCfg, wbytes: int, rows: int, steps: int, kvbytes: int = 4) -> float:
+    """sum_L [ W*b_w + 24*2*Bs*1536*b_kv*(L+1) ]; b_kv = 4 (fp32 K/V: every parity configuration) or 2 (kv_dtype="f16")."""
     D, F = cfg.d_model, cfg.ffn_dim
     Wb = cfg.num_layers * (3 * D * D + D * D + 3 * F * D) * wbytes + \
         cfg.num_codebooks * cfg.d_codebook * D * (2 if wbytes == 1 else wbytes)
     tot = 0.0
     for Lc in range(1, steps + 1):
-        tot += Wb + cfg.num_layers * 2 * rows * D * 4 * (Lc + 1)
+        tot += Wb + cfg.num_layers * 2 * rows * D * kvbytes * (Lc + 1)
     return tot
 
 
@@ -57,15 +57,15 @@ def extra_configs(args, dev, cfg, ccfg, sd, eng_h2, codec_pair, stream):
     """Short timed regions of the BASELINE configs the headline line does not run (all on the un-rounded synthetic checkpoint `sd`):
       rows32_h2          the reference's default batch (configs/generate_vgg.yaml:41: 16 clips, cfg 6 -> 32 decoder rows), h2
       c4                 BASELINE configs[3]: 10.24 s single pass (T=880, 128 video tokens, block_size_audio 1024), B=4, cfg 1, h2
-      fp8h_mx8_rows32    BASELINE configs[4]'s per-GPU shape: fp8 weights against the hi activation plane (weight_dtype="fp8h"), block-
-                         scaled fp8 codec, 16 clips, cfg 6 — with "tol vs bf16 reported": logits / tokens against the one-plane
+      fp8h_kv16_mx8_rows32  BASELINE configs[4]'s per-GPU shape: fp8 weights against the hi activation plane (weight_dtype="fp8h"), fp16 K/V
+                         cache, block-scaled fp8 codec, 16 clips, cfg 6 — with "tol vs bf16 reported": logits / tokens against the one-plane
                          ("h1" = the bf16-class) engine on the same checkpoint, waveform against the fp16-pair codec
       longform           row f1: 10.24 s clips through the sliding-window caller (scripts/generate.py:327-369), 8 clips, cfg 6, h2"""
     from vaura_amd.longform import COMPRESSION_MODEL_FRAME_RATE, chunk_schedule
     res = {}
     kw6 = dict(use_sampling=True, temp=1.0, top_k=args.top_k, top_p=0.0, cfg_scale=6.0, seed=1234, clip_base=0, use_graph=True)
 
-    def region(e, cdc, feats, T, kw, wbytes, rows, cfgx, steps=3, warm=1):
+    def region(e, cdc, feats, T, kw, wbytes, rows, cfgx, steps=3, warm=1, kvbytes=4):
         with torch.cuda.stream(stream):
             for _ in range(warm):
                 cdc.decode(e.generate_codes(feats, T, **kw))
@@ -87,7 +87,7 @@ def extra_configs(args, dev, cfg, ccfg, sd, eng_h2, codec_pair, stream):
         tl = sum(a.elapsed_time(b) for a, b, _ in ev) / steps
         tc = sum(b.elapsed_time(c) for _, b, c in ev) / steps
         Bx = feats.shape[0]
-        lb = decode_loop_bytes(cfgx, wbytes, rows, T + K_CB - 1)
+        lb = decode_loop_bytes(cfgx, wbytes, rows, T + K_CB - 1, kvbytes)
         return {"value": round(Bx * K_CB * T / dt, 1), "unit": "codec tokens/s", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
                 "decode_loop_ms": round(tl, 3), "codec_ms": round(tc, 3), "rows": rows,
                 "decode_loop_roofline": {"bound": "hbm", "achieved": round(lb / (tl * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -142,11 +142,17 @@ def extra_configs(args, dev, cfg, ccfg, sd, eng_h2, codec_pair, stream):
     torch.cuda.empty_cache()
 
     # -- configs[4]'s per-GPU shape + its tolerance report
-    e8 = DecoderEngine(cfg, sd, dev, wdtype="fp8h")
     c8 = CodecEngine(ccfg, synth.codec_state_dict(ccfg, seed=0), dev, precision="mx8")
-    r, codes8 = region(e8, c8, f16, 220, kw6, 1, 32, cfg)
+    e8f = DecoderEngine(cfg, sd, dev, wdtype="fp8h")                   # the same storage with the fp32 K/V cache of the parity configurations
+    r32, _ = region(e8f, c8, f16, 220, kw6, 1, 32, cfg)
+    del e8f
+    torch.cuda.empty_cache()
+    e8 = DecoderEngine(cfg, sd, dev, wdtype="fp8h", kv_dtype="f16")
+    r, codes8 = region(e8, c8, f16, 220, kw6, 1, 32, cfg, kvbytes=2)
+    r["with_fp32_kv_cache"] = {k: r32[k] for k in ("value", "ms_per_step", "decode_loop_ms", "decode_loop_roofline")}
     r["workload"] = ("configs[4] per GPU: 16 clips x 2.56 s, cfg 6 (32 rows), top-k 250; per-layer matrices fp8 e4m3 + row scales multiplied against the "
-                     "hi fp16 activation plane (weight_dtype='fp8h'), one-plane heads, fp32 K/V; codec on the block-scaled fp8 MFMA (mx8)")
+                     "hi fp16 activation plane (weight_dtype='fp8h'), one-plane heads, fp16 K/V cache (kv_dtype='f16'); codec on the block-scaled "
+                     "fp8 MFMA (mx8).  The roofline bytes count the K/V stream at 2 bytes per element")
     idx = codes8[:2, :, :24].contiguous()
     lg8 = e8.logits_all_positions(idx, f16[:2]).float().cpu()
     wav8 = c8.decode(codes8)
@@ -167,13 +173,13 @@ def extra_configs(args, dev, cfg, ccfg, sd, eng_h2, codec_pair, stream):
     steps_of = torch.arange(220)[None, :] + 1 + torch.arange(K_CB)[:, None]
     first = [int(steps_of[c8c[b] != cbc[b]].min()) if not torch.equal(c8c[b], cbc[b]) else 229 for b in range(16)]
     r["tolerance_vs_bf16"] = {
-        "what": "fp8h engine against the one-plane fp16 ('h1', 16-bit weights) engine on the same checkpoint, same Philox noise; synthetic "
+        "what": "fp8h + fp16-K/V engine against the one-plane fp16 ('h1', 16-bit weights, fp32 K/V) engine on the same checkpoint, same Philox noise; synthetic "
                 "random-init weights: logits are nearly flat, so sampled sequences separate at the first near-tie and stay apart",
         "logits_rel_rms": round(float((lg8 - lgb).pow(2).mean().sqrt() / lgb.pow(2).mean().sqrt()), 5),
         "logits_max_abs": round(float((lg8 - lgb).abs().max()), 5), "logits_top1_agreement": round(float((lg8.argmax(-1) == lgb.argmax(-1)).float().mean()), 4),
         "sampled_token_agreement_220_frames": round(float((c8c == cbc).float().mean()), 4), "median_first_divergence_step": int(sorted(first)[8]),
         "waveform_rms_mx8_vs_f16pair_codec_same_tokens": round(wrms, 5), "waveform_signal_rms": round(sig, 5)}
-    res["fp8h_mx8_rows32"] = r
+    res["fp8h_kv16_mx8_rows32"] = r
     return res
 
 
@@ -348,7 +354,7 @@ def main():
     ap.add_argument("--no-plugin", action="store_true", help="skip timing VAURAModel.generate() through the plugin classes")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true",
-                    help="skip the short timed regions of the other BASELINE configs (extra_configs: c4, rows32_h2, fp8h_mx8_rows32, longform)")
+                    help="skip the short timed regions of the other BASELINE configs (extra_configs: c4, rows32_h2, fp8h_kv16_mx8_rows32, longform)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
