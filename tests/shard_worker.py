@@ -47,9 +47,12 @@ def main():
     all_wav = vdist.gather_clips(wav, counts)
     assert all_codes.is_cuda and all_wav.is_cuda
     vdist.barrier()
+    seen = vdist.ranks_seen(dev)                                       # all_gather_object over the product backend
+    worst = vdist.max_over_ranks(float(rank), dev)                     # all_reduce(MAX) on a device tensor
     if rank == 0:
-        np.savez(a.out, codes=all_codes.cpu().numpy(), wav=all_wav.cpu().numpy(), world=world)
-    if world > 1:
+        np.savez(a.out, codes=all_codes.cpu().numpy(), wav=all_wav.cpu().numpy(), world=world,
+                 backend=(torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"), n_seen=len(seen), worst=worst)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

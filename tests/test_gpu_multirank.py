@@ -48,6 +48,25 @@ def test_two_ranks_gather_what_one_rank_generates(tmp_path, total):
     assert np.array_equal(a["wav"], b["wav"]) and np.isfinite(a["wav"]).all() and np.abs(a["wav"]).max() > 0
 
 
+def test_rccl_world_of_one_executes_the_product_backend(tmp_path):
+    """What a 1-GPU box CAN execute of the N > 1 product path: the RCCL backend itself.  One rank, VAURA_DIST_FORCE_GROUP=1:
+    ``init_process_group("nccl", device_id=cuda:0)`` creates the communicator on the device, and the final gathers (``all_gather`` of
+    DEVICE tensors), the barrier, ``all_gather_object`` and the MAX all-reduce all go through RCCL instead of being skipped — the
+    branches of vaura_amd/dist.py that gloo runs never touch.  Result == the plain single-process run, bit for bit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(HERE, "shard_worker.py")
+    one = tmp_path / "one.npz"
+    r = subprocess.run([sys.executable, worker, "--out", str(one), "--total", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    forced = tmp_path / "forced.npz"
+    envf = dict(env, VAURA_DIST_FORCE_GROUP="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, worker, "--out", str(forced), "--total", "4"], env=envf, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(one), np.load(forced)
+    assert str(a["backend"]) == "none" and str(b["backend"]) == "nccl" and int(b["n_seen"]) == 1 and float(b["worst"]) == 0.0
+    assert np.array_equal(a["codes"], b["codes"]) and np.array_equal(a["wav"], b["wav"])
+
+
 def _torchrun(world, args, env, timeout):
     return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *args], env=env,

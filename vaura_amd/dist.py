@@ -21,12 +21,22 @@ def env_rank() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _single() -> bool:
+    """True when the collectives may be skipped: no group, or a group of ONE rank that was not asked for explicitly.  With
+    VAURA_DIST_FORCE_GROUP=1 a world of one rank still creates its RCCL communicator and sends every helper through the real
+    collective calls — the only way a 1-GPU box can execute ``init_process_group("nccl", device_id=...)`` and the device-tensor branches
+    of the gathers at all (tests/test_gpu_multirank.py::test_rccl_world_of_one...)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("VAURA_DIST_FORCE_GROUP") != "1"
+
+
 def init(backend: str = "nccl", device_index: int | None = None) -> Tuple[int, int, int]:
     """Join the job's process group.  With the product backend ("nccl" = RCCL) the rank first binds its own GPU
     (``device_index``, default LOCAL_RANK) and hands it to ``init_process_group(device_id=...)``: the communicator is then
     created eagerly on that device instead of on whatever device the first collective happens to see."""
     rank, local, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("VAURA_DIST_FORCE_GROUP") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -69,7 +79,7 @@ def ranks_seen(device) -> List[dict]:
         bus = getattr(props, "pci_bus_id", None)
         if bus is not None:
             me["pci"] = f"{socket.gethostname()}/{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(bus):02x}:{int(getattr(props, 'pci_device_id', 0)):02x}"
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return [me]
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, me)
@@ -97,7 +107,7 @@ def assert_distinct_devices(seen: List[dict]) -> None:
 
 def gather_floats(x: float, device) -> List[float]:
     """The same scalar from every rank (per-rank timings of the bench record)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return [x]
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
@@ -116,7 +126,7 @@ def shard(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_clips(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
     """All-gather per-rank results (clip dim 0, possibly ragged) into global clip order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return local
     world = dist.get_world_size()
     mx = max(counts)
@@ -136,12 +146,12 @@ def gather_clips(local: torch.Tensor, counts: List[int]) -> torch.Tensor:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         dist.barrier()
 
 
 def max_over_ranks(x: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return x
     t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
