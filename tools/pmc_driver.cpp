@@ -78,7 +78,7 @@ template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * 
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights h1|h2] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
-  int wd = VAURA_W_H1, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1;
+  int wd = VAURA_W_H1, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1, kv16 = 0;
   const char* stamps_out = nullptr;
   std::vector<unsigned> variants{0u};
   std::vector<unsigned> variants2{0u};        // the second flag word of each variant: --flags F or F:F2 (vaura_set_debug_flags2)
@@ -99,6 +99,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--kv")) kv16 = !strcmp(argv[i + 1], "f16");          // fp16 K / V cache (vaura_decoder.kv_dtype = 1)
     else if (!strcmp(argv[i], "--stamps")) stamps_out = argv[i + 1];
   }
   void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
@@ -114,6 +115,7 @@ int main(int argc, char** argv) {
   d.dims = vaura_dims{NL, D, H, F, K, V, 512, 1024, 768, 8, 7, 1e-5f};
   d.wdtype = wd; d.batch = batch; d.rows = rows; d.max_len = ML; d.timesteps = T; d.seq_len = S; d.n_cond_tokens = Tv;
   d.prefill_positions = 0;
+  d.kv_dtype = kv16;           // (the caches below are allocated at the fp32 size either way)
   std::vector<vaura_layer_weights> lw(NL);
   for (int l = 0; l < NL; ++l) {
     lw[l].wqkv = dev_weight(3 * D, D, wd); lw[l].wo = dev_weight(D, D, wd);

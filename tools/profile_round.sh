@@ -21,22 +21,30 @@ MDRV=$ROOT/tools/mfma_driver
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/pmc_driver.cpp -o $DRV -ldl -lpthread || exit 1
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/mfma_driver.cpp -o $MDRV -ldl || exit 1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin > $OUT/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin --no-extra-configs > $OUT/bench_stats.log 2>&1
 tail -n 1 $OUT/bench_stats.log | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c4 -- python3 $ROOT/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-second --no-plugin > $OUT/bench_stats_c4.log 2>&1
 tail -n 1 $OUT/bench_stats_c4.log | cut -c1-200
+# round 6: the counter passes cover EVERY cache length of the loop (228 steps from position 0), not positions 100..123
 for W in h2 h1; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights $W --steps 24 --pos0 100 > $OUT/drv_stats_$W.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights $W --steps 228 --pos0 0 > $OUT/drv_stats_$W.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights $W --steps 24 --pos0 100 > $OUT/drv_${C}_$W.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights $W --steps 228 --pos0 0 > $OUT/drv_${C}_$W.log 2>&1
   done
   tail -n 1 $OUT/drv_stats_$W.log
 done
+# configs[4]'s per-GPU shape: fp8 weights against the hi activation plane, fp16 K / V, 32 rows
+W=fp8h_rows32
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights fp8h --kv f16 --rows 32 --steps 228 --pos0 0 > $OUT/drv_stats_$W.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights fp8h --kv f16 --rows 32 --steps 228 --pos0 0 > $OUT/drv_${C}_$W.log 2>&1
+done
+tail -n 1 $OUT/drv_stats_$W.log
 # 17..32 decoder rows (the reference's default batch 16 under CFG): the two-row-block instances, two planes
 W=h2_rows32
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights h2 --rows 32 --steps 24 --pos0 100 > $OUT/drv_stats_$W.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights h2 --rows 32 --steps 228 --pos0 0 > $OUT/drv_stats_$W.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights h2 --rows 32 --steps 24 --pos0 100 > $OUT/drv_${C}_$W.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights h2 --rows 32 --steps 228 --pos0 0 > $OUT/drv_${C}_$W.log 2>&1
 done
 tail -n 1 $OUT/drv_stats_$W.log
 for M in codec avclip prefill_h2 prefill_h1; do
@@ -61,6 +69,9 @@ if [ -f $S ]; then
     tail -n 8 $OUT/stamps_$W.log
   done
 fi
-# gpurun merges at most 64 MiB back: keep the stats and counter tables, drop the per-dispatch traces and databases
+# summarise HERE (the per-dispatch counter tables of the 228-step passes are tens of MB each): gpurun_out/profiles_<tag>/ is what travels back
+python3 tools/summarize_profile.py $TAG $ROOT/gpurun_out/profiles_$TAG > $OUT/summary.log 2>&1; tail -n 40 $OUT/summary.log
+# gpurun merges at most 64 MiB back: keep the stats tables, drop the per-dispatch traces, counter tables and databases
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
+find $OUT -name "*counter_collection.csv" -size +2M -delete
 du -sh $OUT; find $OUT -name "*.csv" | wc -l

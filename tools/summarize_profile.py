@@ -22,7 +22,10 @@ from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/prof_{tag}"
-os.makedirs("profiles", exist_ok=True)
+# second argument: where the summaries go (default profiles/).  tools/profile_round.sh runs this ON the GPU box into gpurun_out/profiles_<tag>/
+# — the per-dispatch counter tables of 228-step passes are too large to travel back — and the builder copies that directory into profiles/.
+DST = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+os.makedirs(DST, exist_ok=True)
 
 
 def newest(pattern):
@@ -74,11 +77,11 @@ def write_stats(path, dst, header):
 
 
 stats = newest(f"{src}/stats/**/*kernel_stats.csv")
-rows = write_stats(stats, f"profiles/{tag}_bench_kernel_stats.csv",
+rows = write_stats(stats, f"{DST}/{tag}_bench_kernel_stats.csv",
                    "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin   (auto -> h2 storage, un-rounded checkpoint)")
 bench_names = {clean(r["Name"]) for r in rows}
 log = [l for l in open(f"{src}/bench_stats.log").read().splitlines() if l.startswith("{")]
-open(f"profiles/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else "{}") + "\n")
+open(f"{DST}/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else "{}") + "\n")
 
 
 def per_kernel(path, counter):
@@ -92,13 +95,15 @@ def per_kernel(path, counter):
 
 
 names = {}
-for w in ("h2", "h1", "h2_rows32"):
+for w in ("h2", "h1", "h2_rows32", "fp8h_rows32"):
     st = newest(f"{src}/drv_stats_{w}/**/*kernel_stats.csv")
     if not st:
         continue
     rows_n = 32 if w.endswith("rows32") else 16
-    drows = write_stats(st, f"profiles/{tag}_driver_kernel_stats_{w}.csv",
-                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {w[:2]} --rows {rows_n} --steps 24 --pos0 100")
+    wname = w.split("_")[0]
+    kvflag = " --kv f16" if wname == "fp8h" else ""
+    drows = write_stats(st, f"{DST}/{tag}_driver_kernel_stats_{w}.csv",
+                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {wname}{kvflag} --rows {rows_n} --steps 228 --pos0 0")
     avg_ns = {clean(r["Name"]): float(r["AverageNs"]) for r in drows}
     names[w] = {stage_of(n): n for n in avg_ns if stage_of(n)}
     fetch = per_kernel(f"{src}/drv_FETCH_SIZE_{w}", "FETCH_SIZE")
@@ -108,9 +113,9 @@ for w in ("h2", "h1", "h2_rows32"):
         missing = sorted(step_kernels - bench_names)
         if missing:
             raise SystemExit(f"PMC kernel names not in the bench's kernel stats (stale build?): {missing}")
-    out = {"weights": w[:2], "rows": rows_n, "kernels": {},
+    out = {"weights": wname, "rows": rows_n, "kv_cache": "f16" if kvflag else "f32", "kernels": {},
            "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- tools/pmc_driver libvaura_hip.so "
-                     f"--weights {w[:2]} --rows {rows_n} --steps 24 --pos0 100 (cache length 100..123)",
+                     f"--weights {wname}{kvflag} --rows {rows_n} --steps 228 --pos0 0 (EVERY cache length of the loop: averages over all 228 steps)",
            "formula": "hbm_bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half the "
                       "bytes of wide coalesced reads on gfx950; WRITE_SIZE is exact)"}
     for k in sorted(step_kernels):
@@ -119,12 +124,12 @@ for w in ("h2", "h1", "h2_rows32"):
         out["kernels"][k] = {"stage": stage_of(k), "launches": n, "FETCH_SIZE_KiB_raw": fs, "WRITE_SIZE_KiB_raw": ws,
                              "hbm_read_bytes_per_launch": fs * 2048, "hbm_write_bytes_per_launch": ws * 1024,
                              "hbm_bytes_per_launch": fs * 2048 + ws * 1024, "avg_ns_same_driver_run": avg_ns.get(k)}
-    json.dump(out, open(f"profiles/{tag}_pmc_hbm_bytes_{w}.json", "w"), indent=1)
+    json.dump(out, open(f"{DST}/{tag}_pmc_hbm_bytes_{w}.json", "w"), indent=1)
     for k, v in out["kernels"].items():
         print(f"{w} {v['stage']:6s} {v['hbm_bytes_per_launch'] / 1e6:8.2f} MB  {(v['avg_ns_same_driver_run'] or 0) / 1e3:7.2f} us  {k[:80]}")
 stats_c4 = newest(f"{src}/stats_c4/**/*kernel_stats.csv")
 if stats_c4:
-    crow = write_stats(stats_c4, f"profiles/{tag}_c4_kernel_stats.csv",
+    crow = write_stats(stats_c4, f"{DST}/{tag}_c4_kernel_stats.csv",
                        "rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-second --no-plugin")
     c4 = {}
     for r in sorted(crow, key=lambda r: -float(r["TotalDurationNs"])):       # per stage: the kernel with the largest total time
@@ -133,7 +138,7 @@ if stats_c4:
             c4[st_] = clean(r["Name"])
     names["c4"] = c4
 if names:
-    json.dump(names, open("profiles/kernel_names.json", "w"), indent=1)
+    json.dump(names, open(f"{DST}/kernel_names.json", "w"), indent=1)
 
 # ---- MFMA-bound stages (tools/mfma_driver): time, MFMA work and busy cycles, LDS conflicts, HBM bytes per kernel
 def counters(path):
@@ -149,7 +154,7 @@ for m in ("codec", "avclip", "prefill_h2", "prefill_h1"):
     st = newest(f"{src}/mfma_stats_{m}/**/*kernel_stats.csv")
     if not st:
         continue
-    mrows = write_stats(st, f"profiles/{tag}_{m}_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- tools/mfma_driver libvaura_hip.so {m} 8   (3 passes of the stage)")
+    mrows = write_stats(st, f"{DST}/{tag}_{m}_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- tools/mfma_driver libvaura_hip.so {m} 8   (3 passes of the stage)")
     A, Bc = counters(f"{src}/mfma_pmcA_{m}"), counters(f"{src}/mfma_pmcB_{m}")
     Fz, Wz = counters(f"{src}/mfma_FETCH_SIZE_{m}"), counters(f"{src}/mfma_WRITE_SIZE_{m}")
     out = {"stage": m, "clips": 8, "source": f"tools/profile_round.sh {tag}: rocprofv3 --kernel-trace --pmc ... -- tools/mfma_driver libvaura_hip.so {m} 8 "
@@ -185,10 +190,10 @@ for m in ("codec", "avclip", "prefill_h2", "prefill_h1"):
             rec["hbm_bytes_per_launch"] = Fz[k].get("FETCH_SIZE", 0.0) * 2048 + Wz.get(k, {}).get("WRITE_SIZE", 0.0) * 1024
         out["kernels"][k] = rec
         print(f"{m:6s} {rec['avg_us']:9.2f} us x{rec['calls']:4d} {rec.get('mfma_tflops', 0):7.1f} TF busy {rec.get('mfma_busy_frac', 0):.3f} lds-conf {rec.get('lds_conflict_frac', 0):.3f}  {k[:70]}")
-    json.dump(out, open(f"profiles/{tag}_{m}_mfma.json", "w"), indent=1)
+    json.dump(out, open(f"{DST}/{tag}_{m}_mfma.json", "w"), indent=1)
 
 for f in glob.glob(f"{src}/stamps_*.json"):
     base = os.path.basename(f).replace("stamps_", "")
-    open(f"profiles/{tag}_stage_stamps_{base}", "w").write(open(f).read())
+    open(f"{DST}/{tag}_stage_stamps_{base}", "w").write(open(f).read())
 for r in rows[:14]:
     print(clean(r["Name"])[:70].ljust(70), r["Calls"].rjust(7), "%9.2f us" % (float(r["AverageNs"]) / 1e3), r["Percentage"])
