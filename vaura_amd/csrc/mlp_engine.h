@@ -75,6 +75,8 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
+  int pollwg;              // 1: hand-off 1 in its round-4 form (wave 0 polls all 256 producers, a barrier releases the workgroup); 0 (default,
+                           // round 6): every wave polls the 32 producers of its own K slice and goes on by itself
   // EXPERIMENT builds only (-DVAURA_EXPERIMENT_ENGINES; measured negative: the launch grows by 6.8 .. 10.7 us, profiles/r06_ab_mall_warm.txt).
   // Infinity-Cache warm-up by the 64 workgroups that have no phase-2 / phase-3 duty (round 6): once the first hand-off has passed (the
   // HBM pipe then runs far below its rate until the launch ends) they touch one dword per 128-byte line of pf_lines lines of what a
@@ -664,7 +666,29 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     if (wid != 0) VA_STAMP(stamps, 3);                 // waves 1..7: w2 slice requested
 #endif
 
-    // ---- hand-off: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest
+    // ---- hand-off 1.  Round 6: EVERY WAVE polls only the producers of ITS OWN K slice — k-group pairs [8 w, 8 w + 8) = ffn tiles
+    //      [32 w, 32 w + 32) = phase-1 workgroups 32 w .. 32 w + 31 (lanes 0..7: four flags each) — and goes on to its planes and products by
+    //      itself: no workgroup barrier.  The hand-off used to pass for the whole workgroup when the LAST of the 256 producers had published
+    //      (stamps: 2.9 us behind the median one with two planes); now seven of eight waves have multiplied their slice by then and only the
+    //      wave that needs the slowest producer still has its 16 KB round trip + 16 products to go.  Same loads, same products, same order.
+    //      (e.pollwg = 1, second flag word bit 5: the previous form — wave 0 polls all 256, a raw barrier releases the rest — for the A/B.)
+    if (!e.pollwg) {
+      const bool broken = (mlpe_ld_sc1(reinterpret_cast<const uint32_t*>(e.state + 4)) & VAURA_STATUS_HANDOFF_TIMEOUT) != 0;
+      const uint32_t* fp = e.flags + 32 * w + 4 * (lane & 7);
+      int spin = 0;
+      for (;;) {
+        u32x4 f;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(f) : "v"(fp) : "memory");
+        const bool ok = f.x == epoch && f.y == epoch && f.z == epoch && f.w == epoch;
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull || broken || (e.abl & 1)) break;
+        if (++spin >= MLPE_SPIN_LIMIT) {
+          if (lane == 0) __hip_atomic_fetch_or(e.state_rw + 4, VAURA_STATUS_HANDOFF_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+    } else {
     if (wid == 0) {
       const bool broken = (mlpe_ld_sc1(reinterpret_cast<const uint32_t*>(e.state + 4)) & VAURA_STATUS_HANDOFF_TIMEOUT) != 0;
       int spin = 0;
@@ -684,6 +708,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     // before anybody may request the planes.  Only control has to pass here: the planes are requested behind it in program order.
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    }
     VA_STAMP(stamps, 4);                               // hand-off barrier passed (wave 0: its poll matched just before)
     if (e.abl & 4) prefetch_w2();
 
