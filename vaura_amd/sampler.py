@@ -57,7 +57,7 @@ class Transformer(nn.Module):
                  norm_first: bool = False, num_codebooks: int = 2, positional_embedder: str = "sinusoidal",
                  use_visual_conditioning: bool = True, use_delay_strategy: bool = False,
                  cond_feature_channel_scaler: int = 2, weight_dtype: str = "auto", one_launch_mlp: bool = True,
-                 plane_shift: int = 0):
+                 plane_shift: int = 0, near_tie: str = "report", kv_dtype: str = "f32"):
         super().__init__()
         layer_norm_eps = float(layer_norm_eps)      # PyYAML reads the reference's `layer_norm_eps: 1e-5` as a string (OmegaConf does not)
         self.cfg = SamplerCfg(num_layers=num_layers, d_model=d_model, nhead=nhead, d_codebook=d_codebook,
@@ -83,6 +83,9 @@ class Transformer(nn.Module):
         self.one_launch_mlp = one_launch_mlp
         # every activation plane set stored x 2^-plane_shift (engine.DecoderEngine): for a checkpoint known to carry massive activations
         self.plane_shift = int(plane_shift)
+        # near-tie detector policy (engine.DecoderEngine: off | report | rerun) and K/V cache type (f32 | f16: configs[4] with "fp8h")
+        self.near_tie = near_tie
+        self.kv_dtype = kv_dtype
 
         D, F = c.d_model, c.ffn_dim
         shapes = {
@@ -137,13 +140,14 @@ class Transformer(nn.Module):
     def engine(self) -> DecoderEngine:
         """Pack the current parameters for the HIP path (once per device / weight dtype / parameter state)."""
         dev = self.norm.weight.device
-        key = (str(dev), self.weight_dtype, self.one_launch_mlp, self.plane_shift, self._weights_fingerprint())
+        key = (str(dev), self.weight_dtype, self.one_launch_mlp, self.plane_shift, self.near_tie, self.kv_dtype, self._weights_fingerprint())
         if self._engine is None or self._engine_key != key:
             if dev.type != "cuda":
                 raise L.VauraHipError("vaura_amd.sampler.Transformer runs on a HIP device only; call .to('cuda') first")
             sd = {k: v for k, v in self.state_dict().items()}
             self._engine = DecoderEngine(self.cfg, sd, dev, wdtype=self.weight_dtype, one_launch_mlp=self.one_launch_mlp,
-                                         plane_shift=self.plane_shift if self.weight_dtype != "f32" else 0)
+                                         plane_shift=self.plane_shift if self.weight_dtype != "f32" else 0,
+                                         near_tie=self.near_tie, kv_dtype=self.kv_dtype)
             self._engine_key = key
         return self._engine
 
