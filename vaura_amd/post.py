@@ -60,7 +60,9 @@ def _normalize_loudness(wav: torch.Tensor, sample_rate: int, loudness_headroom_d
     scratch = torch.empty(L.lib().vaura_audio_loudness_scratch_elems(clips), dtype=torch.float32, device=x.device)
     L.check(L.lib().vaura_audio_loudness(L.ptr(x), L.ptr(out), clips, n, sample_rate, loudness_headroom_db, int(loudness_compressor),
                                          float(energy_floor), L.ptr(scratch), L.current_stream()), "vaura_audio_loudness")
-    out.loudness_gains = scratch[:clips]          # the gains that were applied (tests; 1 = left alone)
+    g = scratch[:clips]
+    out.loudness_untouched = g < 0                # the library marks clips the reference leaves alone (quiet / too short / no gated block) with a negative gain
+    out.loudness_gains = torch.where(g < 0, torch.ones_like(g), g)       # the gains that were applied (1 = left alone)
     return out
 
 
