@@ -18,8 +18,8 @@ unsigned va_debug_flags_get() { return va_debug_flags; }
 // A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows;
 // bit 2: EXPERIMENT, the next layer's attention as a fourth phase of the one-launch MLP (api.hip: measured slower);
 // bit 3: fp8 weights keep round 4's one-workgroup-per-tile kernels for wo / w2 (the A/B of the fp8 row-split instances);
-// bit 4: fp8 weights never take the one-launch MLP; bit 5: hand-off 1 of the one-launch MLP polled by wave 0 for the whole workgroup
-// (round 4's form; default since round 6: every wave polls the producers of its own K slice); bits 8..14: experiment builds only
+// bit 4: fp8 weights never take the one-launch MLP; bit 5 and bits 8..14: experiment builds only (-DVAURA_EXPERIMENT_ENGINES: hand-off 1 of the
+// one-launch MLP polled per wave; Infinity-Cache warm-up by its idle workgroups — both measured negative in round 6)
 unsigned va_debug_flags2 = 0;
 unsigned va_debug_flags2_get() { return va_debug_flags2; }
 static bool rb2(const Gemv3Args& a) { return a.R >= 2 && !(va_debug_flags2 & 1u); }
@@ -292,8 +292,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
-  e.pollwg = (int)((va_debug_flags2 >> 5) & 1u);    // second flag word, bit 5: hand-off 1 polled by wave 0 for the whole workgroup (round 4's form)
-  if (e.abl & 4) e.pollwg = 1;                      // (the no-run-ahead ablation requests w2 behind the workgroup barrier)
+  e.pollwave = ((va_debug_flags2 >> 5) & 1u) && !(e.abl & 4);    // second flag word, bit 5 (experiment builds): hand-off 1 polled per wave
   if (a13.R == 2) {       // 17..32 decoder rows: both row blocks per weight fragment
     if (a13.wq == 1) return aq ? launch_mlp_engine_t<1, true, 2>(e, s) : launch_mlp_engine_t<1, false, 2>(e, s);
     if (a13.wq == 3) return aq ? launch_mlp_engine_t<3, true, 2>(e, s) : launch_mlp_engine_t<3, false, 2>(e, s);

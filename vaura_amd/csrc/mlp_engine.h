@@ -75,8 +75,7 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
-  int pollwg;              // 1: hand-off 1 in its round-4 form (wave 0 polls all 256 producers, a barrier releases the workgroup); 0 (default,
-                           // round 6): every wave polls the 32 producers of its own K slice and goes on by itself
+  int pollwave;            // experiment builds only (measured negative, round 6): 1 = every wave polls the 32 producers of its own K slice
   // EXPERIMENT builds only (-DVAURA_EXPERIMENT_ENGINES; measured negative: the launch grows by 6.8 .. 10.7 us, profiles/r06_ab_mall_warm.txt).
   // Infinity-Cache warm-up by the 64 workgroups that have no phase-2 / phase-3 duty (round 6): once the first hand-off has passed (the
   // HBM pipe then runs far below its rate until the launch ends) they touch one dword per 128-byte line of pf_lines lines of what a
@@ -666,13 +665,13 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
     if (wid != 0) VA_STAMP(stamps, 3);                 // waves 1..7: w2 slice requested
 #endif
 
-    // ---- hand-off 1.  Round 6: EVERY WAVE polls only the producers of ITS OWN K slice — k-group pairs [8 w, 8 w + 8) = ffn tiles
-    //      [32 w, 32 w + 32) = phase-1 workgroups 32 w .. 32 w + 31 (lanes 0..7: four flags each) — and goes on to its planes and products by
-    //      itself: no workgroup barrier.  The hand-off used to pass for the whole workgroup when the LAST of the 256 producers had published
-    //      (stamps: 2.9 us behind the median one with two planes); now seven of eight waves have multiplied their slice by then and only the
-    //      wave that needs the slowest producer still has its 16 KB round trip + 16 products to go.  Same loads, same products, same order.
-    //      (e.pollwg = 1, second flag word bit 5: the previous form — wave 0 polls all 256, a raw barrier releases the rest — for the A/B.)
-    if (!e.pollwg) {
+    // ---- hand-off 1: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest.
+    //      (Round 6, measured NEGATIVE and kept in experiment builds only — -DVAURA_EXPERIMENT_ENGINES, second flag word bit 5: every wave
+    //      polling just the 32 producers of its own K slice, no workgroup barrier.  Bit-identical, and slower: two planes + 0.6 %, one plane
+    //      + 3.3 %, fp8h + 2.1 % on whole loops (profiles/r06_ab_pollwave.txt) — eight pollers per consumer instead of one hammer the flag
+    //      lines the producers are still storing to, and a wave's poll waits for its own w2 prefetch.)
+#ifdef VAURA_EXPERIMENT_ENGINES
+    if (e.pollwave) {
       const bool broken = (mlpe_ld_sc1(reinterpret_cast<const uint32_t*>(e.state + 4)) & VAURA_STATUS_HANDOFF_TIMEOUT) != 0;
       const uint32_t* fp = e.flags + 32 * w + 4 * (lane & 7);
       int spin = 0;
@@ -688,7 +687,9 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         __builtin_amdgcn_s_sleep(2);
       }
       asm volatile("" ::: "memory");
-    } else {
+    } else
+#endif
+    {
     if (wid == 0) {
       const bool broken = (mlpe_ld_sc1(reinterpret_cast<const uint32_t*>(e.state + 4)) & VAURA_STATUS_HANDOFF_TIMEOUT) != 0;
       int spin = 0;
