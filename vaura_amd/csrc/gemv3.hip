@@ -18,8 +18,9 @@ unsigned va_debug_flags_get() { return va_debug_flags; }
 // A/B of the two-row-block instances and the control of their bit-identity test); bit 1: the one-launch MLP refuses 17..32 rows;
 // bit 2: EXPERIMENT, the next layer's attention as a fourth phase of the one-launch MLP (api.hip: measured slower);
 // bit 3: fp8 weights keep round 4's one-workgroup-per-tile kernels for wo / w2 (the A/B of the fp8 row-split instances);
-// bit 4: fp8 weights never take the one-launch MLP; bit 5 and bits 8..14: experiment builds only (-DVAURA_EXPERIMENT_ENGINES: hand-off 1 of the
-// one-launch MLP polled per wave; Infinity-Cache warm-up by its idle workgroups — both measured negative in round 6)
+// bit 4: fp8 weights never take the one-launch MLP; bits 5, 6, 12..15: row f2's linear layers (vit.hip); bit 7 and bits 16..22: experiment
+// builds only (-DVAURA_EXPERIMENT_ENGINES: hand-off 1 of the one-launch MLP polled per wave; Infinity-Cache warm-up by its idle
+// workgroups — both measured negative in round 6)
 unsigned va_debug_flags2 = 0;
 unsigned va_debug_flags2_get() { return va_debug_flags2; }
 static bool rb2(const Gemv3Args& a) { return a.R >= 2 && !(va_debug_flags2 & 1u); }
@@ -264,13 +265,13 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
                          hipStream_t s, const VaEngineAttention* att, const void* warm_ptr, size_t warm_bytes, const void* warm0_ptr,
                          size_t warm0_bytes) {
   MlpEngineArgs e;
-  // second flag word, bits 8..12: sixteenths (1..16) of `warm_bytes` the idle workgroups touch (0 = off); bit 13: start early
-  const unsigned six = (va_debug_flags2 >> 8) & 31u;
+  // second flag word, bits 16..20: sixteenths (1..16) of `warm_bytes` the idle workgroups touch (0 = off); bit 21: start early
+  const unsigned six = (va_debug_flags2 >> 16) & 31u;
   e.pf_ptr = static_cast<const unsigned char*>(warm_ptr);
   e.pf_lines = (warm_ptr && six) ? (int)((warm_bytes / 128) * (six > 16 ? 16 : six) / 16) : 0;
-  e.pf_early = (int)((va_debug_flags2 >> 13) & 1u);
-  e.pf_ptr0 = static_cast<const unsigned char*>(warm0_ptr);                 // bit 14: the first region (the next layer's wo), whole
-  e.pf_lines0 = (warm0_ptr && (va_debug_flags2 & 0x4000u)) ? (int)(warm0_bytes / 128) : 0;
+  e.pf_early = (int)((va_debug_flags2 >> 21) & 1u);
+  e.pf_ptr0 = static_cast<const unsigned char*>(warm0_ptr);                 // bit 22: the first region (the next layer's wo), whole
+  e.pf_lines0 = (warm0_ptr && (va_debug_flags2 & 0x400000u)) ? (int)(warm0_bytes / 128) : 0;
   e.att_rope = nullptr; e.att_kc = e.att_vc = e.att_out = nullptr; e.att_outp = nullptr; e.att_max_len = 0;
   if (att) {
     if (!aq || a13.R != 1 || !att->rope || !att->kc || !att->vc || !att->out || att->n_head != 16 || att->max_len > 256 || att->max_len < 1)
@@ -292,7 +293,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
-  e.pollwave = ((va_debug_flags2 >> 5) & 1u) && !(e.abl & 4);    // second flag word, bit 5 (experiment builds): hand-off 1 polled per wave
+  e.pollwave = ((va_debug_flags2 >> 7) & 1u) && !(e.abl & 4);    // second flag word, bit 7 (experiment builds): hand-off 1 polled per wave
   if (a13.R == 2) {       // 17..32 decoder rows: both row blocks per weight fragment
     if (a13.wq == 1) return aq ? launch_mlp_engine_t<1, true, 2>(e, s) : launch_mlp_engine_t<1, false, 2>(e, s);
     if (a13.wq == 3) return aq ? launch_mlp_engine_t<3, true, 2>(e, s) : launch_mlp_engine_t<3, false, 2>(e, s);

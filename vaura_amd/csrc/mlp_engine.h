@@ -666,7 +666,7 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
 #endif
 
     // ---- hand-off 1: wave 0 polls the 256 producer flags (lane i: flags 4i .. 4i + 3), bounded; the barrier releases the rest.
-    //      (Round 6, measured NEGATIVE and kept in experiment builds only — -DVAURA_EXPERIMENT_ENGINES, second flag word bit 5: every wave
+    //      (Round 6, measured NEGATIVE and kept in experiment builds only — -DVAURA_EXPERIMENT_ENGINES, second flag word bit 7: every wave
     //      polling just the 32 producers of its own K slice, no workgroup barrier.  Bit-identical, and slower: two planes + 0.6 %, one plane
     //      + 3.3 %, fp8h + 2.1 % on whole loops (profiles/r06_ab_pollwave.txt) — eight pollers per consumer instead of one hammer the flag
     //      lines the producers are still storing to, and a wave's poll waits for its own w2 prefetch.)
