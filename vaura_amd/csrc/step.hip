@@ -157,6 +157,33 @@ __device__ __forceinline__ float block_max(float v, float* sv) {
   __syncthreads();
   return fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
 }
+// two maxima with ONE barrier pair (the near-tie detector's scale next to the softmax's maximum)
+__device__ __forceinline__ void block_max2(float& a, float& b, float* sv) {
+  a = wave_max(a);
+  b = wave_max(b);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = a; sv[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+  b = fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7]));
+}
+// the near-tie screen's four quantities with ONE barrier pair: two maxima and two counts
+__device__ __forceinline__ void block_tie4(float& m0, float& m1, int& c0, int& c1, float* sv, int* si) {
+  m0 = wave_max(m0);
+  m1 = wave_max(m1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    const int wv = threadIdx.x >> 6;
+    sv[wv] = m0; sv[4 + wv] = m1; si[wv] = c0; si[4 + wv] = c1;
+  }
+  __syncthreads();
+  m0 = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+  m1 = fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7]));
+  c0 = si[0] + si[1] + si[2] + si[3];
+  c1 = si[4] + si[5] + si[6] + si[7];
+}
 __device__ __forceinline__ int block_count(int v, int* si) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -201,10 +228,9 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
   // is never changed here.  What the host does with it is policy (engine.py near_tie: report | rerun on the exact-fp32 twin).
   bool near_tie = false;
   float tie_delta = 0.f;       // absolute bound on a mixed logit's error
-  if (a.tie_eps > 0.f && !a.probs_in) {
-    const float scale = block_max(amax, sv);
-    tie_delta = a.tie_eps * scale * (a.cfg_scale > 1.0f ? 2.f * a.cfg_scale - 1.f : 1.f);
-  }
+  const bool tie_on = a.tie_eps > 0.f && !a.probs_in;
+  const float tie_mix = a.tie_eps * (a.cfg_scale > 1.0f ? 2.f * a.cfg_scale - 1.f : 1.f);
+  if (tie_on && !(a.use_sampling && a.temp > 0.0f)) tie_delta = tie_mix * block_max(amax, sv);      // greedy: its own reduction; sampled: with the softmax's maximum
   // Range guard of the fp16-plane activation format (gemv3_kernel.h split2): an activation beyond fp16's 65504 becomes inf in its
   // hi plane, inf - inf = NaN in the lo plane, and from there NaN in the residual stream of that row for the rest of the clip —
   // so EVERY overflow anywhere in the step (or in a teacher-forced prefix, through the K/V cache) arrives here as a non-finite
@@ -243,7 +269,13 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[j] = x[j] / a.temp;
-      const float mx = block_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), sv);
+      float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+      if (tie_on) {
+        block_max2(mx, amax, sv);
+        tie_delta = tie_mix * amax;
+      } else {
+        mx = block_max(mx, sv);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) p[j] = expf(x[j] - mx);
       const float den = block_sum((p[0] + p[1]) + (p[2] + p[3]), sv);
@@ -446,13 +478,9 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_kernel(const float* __rest
             if (i == ri && p_raw[j] <= thr_keep * (1.f + band)) wedge = 1;
           }
         }
-        second = block_max(second, sv);
+        block_tie4(second, cand, nbelow, wedge, sv, si);             // one barrier pair for all four
         near_tie = (rv - second) < rv * band;
-        if (thr_keep > 0.f) {      // (block-uniform)
-          cand = block_max(cand, sv);
-          const int nb = block_count(nbelow, si), nw = block_count(wedge, si);
-          if (cand >= rv * (1.f - band) || (nb > 0 && nw > 0)) near_tie = true;
-        }
+        if (thr_keep > 0.f && (cand >= rv * (1.f - band) || (nbelow > 0 && wedge > 0))) near_tie = true;
       }
     }
   }
