@@ -57,5 +57,5 @@ def parity_report():
             print("parity:", line)
         # a partial session (-k ...) must not overwrite the record of a whole one: the headline golden is the marker
         whole = any(e.get("golden") == "full_topk250_cfg6_raw_B2_T220" and e.get("storage") == "h2" for e in rep.entries) and \
-            any(e.get("golden") == "full_c4_greedy_B1_T880" for e in rep.entries)
+            any(e.get("golden") == "full_c4_greedy_B1_T880" for e in rep.entries) and len(rep.entries) >= 30
         rep.write(os.path.join(REPO, "gpurun_out", "r06_parity.json" if whole else "r06_parity_partial.json"))
