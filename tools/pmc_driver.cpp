@@ -78,7 +78,7 @@ template <typename T> static T* dev_zero(size_t n) { T* p; CK(hipMalloc(&p, n * 
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: %s <libvaura_hip.so> [--weights h1|h2] [--steps N] [--pos0 P] [--rows R]\n", argv[0]); return 1; }
-  int wd = VAURA_W_H1, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1, kv16 = 0;
+  int wd = VAURA_W_H1, steps = 24, pos0 = 100, rows = 16, rounds = 0, chains = 1, kv16 = 0, stride = 1;
   const char* stamps_out = nullptr;
   std::vector<unsigned> variants{0u};
   std::vector<unsigned> variants2{0u};        // the second flag word of each variant: --flags F or F:F2 (vaura_set_debug_flags2)
@@ -99,6 +99,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--pos0")) pos0 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--stride")) stride = atoi(argv[i + 1]);              // counter passes: positions pos0, pos0 + stride, ... (the caches are pre-filled)
     else if (!strcmp(argv[i], "--kv")) kv16 = !strcmp(argv[i + 1], "f16");          // fp16 K / V cache (vaura_decoder.kv_dtype = 1)
     else if (!strcmp(argv[i], "--stamps")) stamps_out = argv[i + 1];
   }
@@ -300,12 +301,18 @@ int main(int argc, char** argv) {
   const int32_t st0[4] = {pos0, 0, 0, 1};
   CK(hipMemcpy(d.state, st0, sizeof st0, hipMemcpyHostToDevice));
   for (int i = 0; i < steps; ++i) {
+    if (stride > 1) {      // a SAMPLE of cache lengths over the whole loop (every K / V row exists: the caches were filled at start) — a counter
+      CK(hipStreamSynchronize(st));                                  // pass over all 228 x 76 dispatches takes ~15 min per counter under rocprofv3
+      const int32_t p = pos0 + i * stride;
+      CK(hipMemcpy(d.state, &p, sizeof p, hipMemcpyHostToDevice));
+    }
     const int rc = step(&d, &sp, 1, st);
     if (rc) { fprintf(stderr, "vaura_decode_step: %d\n", rc); return 3; }
   }
   CK(hipStreamSynchronize(st));
   int32_t st1[4];
   CK(hipMemcpy(st1, d.state, sizeof st1, hipMemcpyDeviceToHost));
-  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d\n", steps, wname(wd), rows, pos0, st1[0] - 1);
-  return st1[0] == pos0 + steps ? 0 : 4;
+  const int last = pos0 + (steps - 1) * stride;
+  printf("pmc_driver: %d steps, weights %s, rows %d, positions %d..%d stride %d\n", steps, wname(wd), rows, pos0, last, stride);
+  return st1[0] == last + 1 ? 0 : 4;
 }

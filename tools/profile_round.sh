@@ -11,42 +11,52 @@
 #   4. in-kernel s_memrealtime stamps of the diagnostic build (wave 0 only, and every wave) -> per-phase json
 set -u
 TAG=${1:-r03}
+PART=${2:-all}          # all | decode (bench stats + the decode-step driver passes) | mfma (codec / extractor / prefill stages + stamps)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-rm -rf $OUT; mkdir -p $OUT
-exec > $OUT/round.log 2>&1
+[ "$PART" = "mfma" ] || rm -rf $OUT
+mkdir -p $OUT
+exec >> $OUT/round_$PART.log 2>&1
+# after every profiler call: drop what the summariser does not read (per-dispatch traces, databases) — a killed run must still fit gpurun's 64 MiB
+clean() { find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete; }
 LIB=$ROOT/vaura_amd/csrc/libvaura_hip.so
 DRV=$ROOT/tools/pmc_driver
 MDRV=$ROOT/tools/mfma_driver
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/pmc_driver.cpp -o $DRV -ldl -lpthread || exit 1
 /opt/rocm/bin/hipcc -O2 -std=c++17 --offload-arch=gfx950 $ROOT/tools/mfma_driver.cpp -o $MDRV -ldl || exit 1
 cd /tmp && export TMPDIR=/tmp
+if [ "$PART" != "mfma" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin --no-extra-configs > $OUT/bench_stats.log 2>&1
 tail -n 1 $OUT/bench_stats.log | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c4 -- python3 $ROOT/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-second --no-plugin > $OUT/bench_stats_c4.log 2>&1
 tail -n 1 $OUT/bench_stats_c4.log | cut -c1-200
-# round 6: the counter passes cover EVERY cache length of the loop (228 steps from position 0), not positions 100..123
+# round 6: the counter passes SAMPLE the whole loop — 24 cache lengths 10, 19, ..., 217 (mean 113.5 = the loop's mean) — instead of positions
+# 100..123; all 228 x 76 dispatches under rocprofv3 counters take ~15 min per pass (first attempt: killed at 45 min)
 for W in h2 h1; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights $W --steps 228 --pos0 0 > $OUT/drv_stats_$W.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights $W --steps 24 --pos0 10 --stride 9 > $OUT/drv_stats_$W.log 2>&1
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights $W --steps 228 --pos0 0 > $OUT/drv_${C}_$W.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights $W --steps 24 --pos0 10 --stride 9 > $OUT/drv_${C}_$W.log 2>&1
   done
   tail -n 1 $OUT/drv_stats_$W.log
+  clean
 done
 # configs[4]'s per-GPU shape: fp8 weights against the hi activation plane, fp16 K / V, 32 rows
 W=fp8h_rows32
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights fp8h --kv f16 --rows 32 --steps 228 --pos0 0 > $OUT/drv_stats_$W.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights fp8h --kv f16 --rows 32 --steps 24 --pos0 10 --stride 9 > $OUT/drv_stats_$W.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights fp8h --kv f16 --rows 32 --steps 228 --pos0 0 > $OUT/drv_${C}_$W.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights fp8h --kv f16 --rows 32 --steps 24 --pos0 10 --stride 9 > $OUT/drv_${C}_$W.log 2>&1
 done
 tail -n 1 $OUT/drv_stats_$W.log
 # 17..32 decoder rows (the reference's default batch 16 under CFG): the two-row-block instances, two planes
 W=h2_rows32
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights h2 --rows 32 --steps 228 --pos0 0 > $OUT/drv_stats_$W.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/drv_stats_$W -- $DRV $LIB --weights h2 --rows 32 --steps 24 --pos0 10 --stride 9 > $OUT/drv_stats_$W.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights h2 --rows 32 --steps 228 --pos0 0 > $OUT/drv_${C}_$W.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/drv_${C}_$W -- $DRV $LIB --weights h2 --rows 32 --steps 24 --pos0 10 --stride 9 > $OUT/drv_${C}_$W.log 2>&1
 done
 tail -n 1 $OUT/drv_stats_$W.log
+clean
+fi
+if [ "$PART" != "decode" ]; then
 for M in codec avclip prefill_h2 prefill_h1; do
   case $M in prefill_h2) A="prefill 8 4";; prefill_h1) A="prefill 8 3";; *) A="$M 8";; esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_stats_$M -- $MDRV $LIB $A > $OUT/mfma_stats_$M.log 2>&1
@@ -56,6 +66,7 @@ for M in codec avclip prefill_h2 prefill_h1; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/mfma_${C}_$M -- $MDRV $LIB $A > $OUT/mfma_${C}_$M.log 2>&1
   done
   tail -n 1 $OUT/mfma_stats_$M.log
+  clean
 done
 cd $ROOT
 S=vaura_amd/csrc/libvaura_hip_stamps.so
@@ -69,8 +80,10 @@ if [ -f $S ]; then
     tail -n 8 $OUT/stamps_$W.log
   done
 fi
+fi
+cd $ROOT
 # summarise HERE (the per-dispatch counter tables of the 228-step passes are tens of MB each): gpurun_out/profiles_<tag>/ is what travels back
-python3 tools/summarize_profile.py $TAG $ROOT/gpurun_out/profiles_$TAG > $OUT/summary.log 2>&1; tail -n 40 $OUT/summary.log
+python3 tools/summarize_profile.py $TAG $ROOT/gpurun_out/profiles_$TAG > $OUT/summary_$PART.log 2>&1; tail -n 40 $OUT/summary_$PART.log
 # gpurun merges at most 64 MiB back: keep the stats tables, drop the per-dispatch traces, counter tables and databases
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete; find $OUT -name "*agent_info.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +2M -delete

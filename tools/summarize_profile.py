@@ -77,11 +77,13 @@ def write_stats(path, dst, header):
 
 
 stats = newest(f"{src}/stats/**/*kernel_stats.csv")
-rows = write_stats(stats, f"{DST}/{tag}_bench_kernel_stats.csv",
-                   "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin   (auto -> h2 storage, un-rounded checkpoint)")
-bench_names = {clean(r["Name"]) for r in rows}
-log = [l for l in open(f"{src}/bench_stats.log").read().splitlines() if l.startswith("{")]
-open(f"{DST}/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else "{}") + "\n")
+rows, bench_names = [], set()
+if stats:        # (absent when only the MFMA part of the round ran on this box: tools/profile_round.sh <tag> mfma)
+    rows = write_stats(stats, f"{DST}/{tag}_bench_kernel_stats.csv",
+                       "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-second --no-plugin --no-extra-configs   (auto -> h2 storage, un-rounded checkpoint)")
+    bench_names = {clean(r["Name"]) for r in rows}
+    log = [l for l in open(f"{src}/bench_stats.log").read().splitlines() if l.startswith("{")]
+    open(f"{DST}/{tag}_bench_under_rocprof.json", "w").write((log[-1] if log else "{}") + "\n")
 
 
 def per_kernel(path, counter):
@@ -103,19 +105,19 @@ for w in ("h2", "h1", "h2_rows32", "fp8h_rows32"):
     wname = w.split("_")[0]
     kvflag = " --kv f16" if wname == "fp8h" else ""
     drows = write_stats(st, f"{DST}/{tag}_driver_kernel_stats_{w}.csv",
-                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {wname}{kvflag} --rows {rows_n} --steps 228 --pos0 0")
+                        f"rocprofv3 --kernel-trace --stats -- tools/pmc_driver vaura_amd/csrc/libvaura_hip.so --weights {wname}{kvflag} --rows {rows_n} --steps 24 --pos0 10 --stride 9")
     avg_ns = {clean(r["Name"]): float(r["AverageNs"]) for r in drows}
     names[w] = {stage_of(n): n for n in avg_ns if stage_of(n)}
     fetch = per_kernel(f"{src}/drv_FETCH_SIZE_{w}", "FETCH_SIZE")
     write = per_kernel(f"{src}/drv_WRITE_SIZE_{w}", "WRITE_SIZE")
     step_kernels = {k for k in fetch if stage_of(k)}
-    if w == "h2":
+    if w == "h2" and bench_names:
         missing = sorted(step_kernels - bench_names)
         if missing:
             raise SystemExit(f"PMC kernel names not in the bench's kernel stats (stale build?): {missing}")
     out = {"weights": wname, "rows": rows_n, "kv_cache": "f16" if kvflag else "f32", "kernels": {},
            "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- tools/pmc_driver libvaura_hip.so "
-                     f"--weights {wname}{kvflag} --rows {rows_n} --steps 228 --pos0 0 (EVERY cache length of the loop: averages over all 228 steps)",
+                     f"--weights {wname}{kvflag} --rows {rows_n} --steps 24 --pos0 10 --stride 9 (24 cache lengths sampled over the WHOLE loop: 10, 19, ..., 217, mean 113.5 = the loop's mean)",
            "formula": "hbm_bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half the "
                       "bytes of wide coalesced reads on gfx950; WRITE_SIZE is exact)"}
     for k in sorted(step_kernels):
