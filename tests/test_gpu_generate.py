@@ -1088,6 +1088,36 @@ def test_range_guard_detects_overflow_and_the_checked_call_reruns_it_in_fp32():
     assert e4.range_fallbacks == 0 and torch.equal(got4, ref4)
 
 
+def test_range_fallback_of_a_lossy_storage_decodes_the_model_the_storage_holds():
+    """the exact-fp32 twin of a LOSSY storage (fp8 / fp8h) must hold the dequantised matrices — the model every other call of
+    the job is decoded by — not the original state dict.  A x3000 checkpoint on the fp8 engine overflows the planes, the checked call is
+    re-run on the twin, and the result equals the oracle on `quant.fp8_effective_state_dict(checkpoint)` (and differs from the oracle on
+    the unquantised one: the two models are different)."""
+    import warnings
+    from oracle import generate_oracle as go
+    from oracle.decoder_oracle import DecoderOracle
+    from vaura_amd import quant
+    cfg = synth.tiny_sampler(2)
+    sd = dict(synth.sampler_state_dict(cfg, seed=81))
+    big = dict(sd)
+    for k in sd:
+        if k.endswith("attention_norm.weight") or k.endswith("ffn_norm.weight") or k == "norm.weight":
+            big[k] = sd[k] * 3000.0
+        if "tok_embeddings" in k and k.endswith("out_proj.weight_g"):
+            big[k] = sd[k] * 3000.0
+    feats = synth.video_features(2, seed=82)
+    eng = DecoderEngine(cfg, big, DEV, wdtype="fp8")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = eng.generate_codes_checked(feats.to(DEV), 12, cfg_scale=6.0).cpu()
+    assert eng.range_fallbacks == 1 and eng._range_twin is not None and eng._twin_lossy
+    assert any("DEQUANTISED" in str(x.message) for x in w)
+    ref_eff = go.generate(DecoderOracle(quant.fp8_effective_state_dict(big), cfg.num_layers, cfg.nhead), feats, 12, mode="cached", cfg_scale=6.0)
+    ref_raw = go.generate(DecoderOracle(big, cfg.num_layers, cfg.nhead), feats, 12, mode="cached", cfg_scale=6.0)
+    assert torch.equal(got, ref_eff)
+    assert not torch.equal(ref_eff, ref_raw)
+
+
 def test_plane_shift_moves_the_fp16_plane_range_up_at_the_same_speed(golden, full_sampler_sd_raw, parity_report):
     """DecoderEngine(plane_shift=S): every activation plane set is stored times 2^-S, its consuming matrix times 2^S (exact both ways
     while the lo plane stays out of fp16's subnormals), so the planes end at 65504 * 2^S.
