@@ -580,7 +580,7 @@ def main():
         out["codec_roofline"] = {"bound": "mfma", "achieved": round(mpp * out["codec_tflops"], 1), "peak": cpeak, "unit": "TFLOP/s",
                                  "frac": round(mpp * out["codec_tflops"] / cpeak, 4), "algorithmic_tflops": out["codec_tflops"],
                                  "matrix_instructions_per_product": mpp, "codec_ms": round(t_codec, 3),
-                                 "counters": "profiles/r05_codec_mfma.json (tools/mfma_driver under rocprofv3 --pmc; builder: committed record, NOT measured by this run)"}
+                                 "counters": "profiles/r06_codec_mfma.json (tools/mfma_driver under rocprofv3 --pmc; builder: committed record, NOT measured by this run)"}
 
         # per-kernel, live: every launch of one eager 228-step pass carries its own start/stop events on the stream it is launched on
         # (hipExtLaunchKernelGGL via vaura_profile_loop): the kernel's execution alone.  rocprofv3's kernel trace of the replayed loop
