@@ -40,6 +40,17 @@ for wd, sd in (("h1", synth.sampler_state_dict(cfg, seed=0, round_bf16=True)), (
     eng.check_status()
     del eng
     torch.cuda.empty_cache()
+# round 6: configs[4]'s engine (fp8 weights against the hi plane, fp16 K/V cache), 32 rows, with and without a prompt
+eng = DecoderEngine(cfg, synth.sampler_state_dict(cfg, seed=0, round_bf16=False), dev, wdtype="fp8h", kv_dtype="f16")
+feats16 = synth.video_features(16, seed=0).to(dev)
+screen("decode loop, fp8h + fp16 K/V, 16 clips (32 rows), top-k 250, cfg 6", lambda: eng.generate_codes(feats16, 220, use_sampling=True, top_k=250, cfg_scale=6.0, seed=7),
+       max(4, N // 4))
+prompt16 = torch.randint(0, 1024, (16, 9, 166), generator=torch.Generator().manual_seed(2)).to(dev)
+screen("prompt prefill + loop, fp8h + fp16 K/V, 32 rows", lambda: eng.generate_codes(feats16, 221, prompt=prompt16, use_sampling=True, top_k=250, cfg_scale=6.0, seed=7),
+       max(4, N // 4))
+eng.check_status()
+del eng
+torch.cuda.empty_cache()
 ccfg = synth.FULL_CODEC
 csd = dict(synth.codec_state_dict(ccfg, seed=0))
 csd.update(synth.codec_encoder_state_dict(ccfg, seed=0))
