@@ -227,6 +227,20 @@ def test_bench_gpus_8_launcher_builds_the_children_before_any_hip_call(monkeypat
     assert main.index("vdist.assert_distinct_devices(seen)") < main.index("elapsed, (codes, wav) = timed(step)")
 
 
+def test_sampler_plugin_takes_the_round6_options_and_rebuilds_its_engine_key():
+    """`near_tie:` / `kv_dtype:` of the sampler plugin are stored, enter the engine cache key, and bad values are
+    refused by the engine's own checks (no GPU needed for any of this: the engine is built lazily on first use)."""
+    from vaura_amd.sampler import Transformer
+    kw = synth.tiny_sampler(2).yaml_params()
+    m = Transformer(**kw, near_tie="rerun", kv_dtype="f16", weight_dtype="fp8h")
+    assert (m.near_tie, m.kv_dtype, m.weight_dtype) == ("rerun", "f16", "fp8h")
+    assert Transformer(**kw).near_tie == "report" and Transformer(**kw).kv_dtype == "f32"
+    from vaura_amd.engine import NEAR_TIE_EPS, WEIGHT_DTYPES, resolve_weight_dtype
+    assert "fp8h" in WEIGHT_DTYPES and resolve_weight_dtype({}, "fp8h") == "fp8h" and 1.2e-6 <= NEAR_TIE_EPS < 2e-6
+    with pytest.raises(L.VauraHipError):
+        resolve_weight_dtype({}, "fp4")
+
+
 def test_synthetic_inputs_are_keyed_by_clip_index():
     a = synth.video_features(8, seed=0)
     b = synth.video_features(4, seed=0, first_clip=4)
