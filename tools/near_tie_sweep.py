@@ -46,6 +46,17 @@ gc = load("full_chunk_greedy_cfg6_raw_B2_Tp166_T221.npz")
 fc = synth.video_features(2, seed=int(gc["feat_seed"])).to(DEV)
 prompt = torch.from_numpy(gc["prompt"].astype(np.int64)).to(DEV)
 run(eng, "later chunk, greedy cfg 6 (h2, B=2; holds the literal tie at step 175: 3.8e-6)", lambda: eng.generate_codes(fc, 221, prompt=prompt, cfg_scale=6.0))
+# how often a plain production call is flagged at the product's bound: 24 different 8-clip cfg-6 top-k-250 calls (Philox seeds), 15 840 decisions each
+from vaura_amd.engine import NEAR_TIE_EPS  # noqa: E402
+eng.near_tie_eps = NEAR_TIE_EPS
+eng._free_graph()
+counts = []
+for seed in range(24):
+    eng.generate_codes(synth.video_features(8, seed=100 + seed).to(DEV), 220, use_sampling=True, temp=1.0, top_k=250, cfg_scale=6.0, seed=seed)
+    eng.check_status()
+    counts.append(eng.last_near_ties[0])
+print(f"24 production-shaped calls (B=8, cfg 6, top-k 250, 15 840 decisions each) at eps {NEAR_TIE_EPS:.1e}: flagged per call {counts}; "
+      f"mean {sum(counts) / len(counts):.2f}, calls with none {sum(c == 0 for c in counts)}/24", flush=True)
 del eng
 torch.cuda.empty_cache()
 g4 = load("full_c4_greedy_B1_T880.npz")
