@@ -293,6 +293,7 @@ int va_launch_mlp_engine(const Gemv3Args& a13, const Gemv3Args& a2, const Gemv3A
   e.p2.wscale = weight_scales(a2, 1536, 4096);
   e.flags = flags; e.state = state; e.state_rw = state; e.layer = layer;
   e.abl = (int)((va_debug_flags >> 28) & 15u);      // bits 28..31: timing ablations of the engine (tools only)
+  e.qlocal = (int)((va_debug_flags2 >> 23) & 1u);
   e.pollwave = ((va_debug_flags2 >> 7) & 1u) && !(e.abl & 4);    // second flag word, bit 7 (experiment builds): hand-off 1 polled per wave
   if (a13.R == 2) {       // 17..32 decoder rows: both row blocks per weight fragment
     if (a13.wq == 1) return aq ? launch_mlp_engine_t<1, true, 2>(e, s) : launch_mlp_engine_t<1, false, 2>(e, s);

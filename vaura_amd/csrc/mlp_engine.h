@@ -75,6 +75,7 @@ struct MlpEngineArgs {
   int layer;
   int abl;                 // timing ablations (tools only; 1 gives wrong results): 1 = no flag wait, 4 = no run-ahead (w2's weights requested
                            // behind the hand-off barrier)
+  int qlocal;              // experiment builds only (no effect, round 6): the qkv phase's work items of head h on XCD h % 8 + plain stores
   int pollwave;            // experiment builds only (measured negative, round 6): 1 = every wave polls the 32 producers of its own K slice
   // EXPERIMENT builds only (-DVAURA_EXPERIMENT_ENGINES; measured negative: the launch grows by 6.8 .. 10.7 us, profiles/r06_ab_mall_warm.txt).
   // Infinity-Cache warm-up by the 64 workgroups that have no phase-2 / phase-3 duty (round 6): once the first hand-off has passed (the
@@ -859,8 +860,13 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
       // EXPERIMENT build -DMLPE_ATT_LOCAL (ATT instances): the qkv work items of head h on the XCD of h's attention workgroups (XCD =
       // workgroup id % 8 = h % 8): item s 64 + 4 h + sub goes to workgroup (h % 8) + 8 ((h / 8) 12 + 4 s + sub), so that the hand-off
       // of the q / k / v quads stays inside one L2 (consumer loads sc0 instead of sc1)
+      // Round 6 (e.qlocal, second flag word bit 23 — A/B): the same relabelling for the ordinary instances, ACROSS the kernel boundary: the
+      // attention launch that follows puts (head h, row r) on XCD h % 8 too, so if an XCD's L2 keeps what its own workgroups stored
+      // (plain stores, written back by the end-of-kernel release) the new q / k / v quads are L2 hits there instead of a memory-side read.
 #ifdef MLPE_ATT_LOCAL
       const int qid = ATT ? (((bid >> 3) % 12) >> 2) * 64 + 4 * ((bid & 7) + 8 * ((bid >> 3) / 12)) + (((bid >> 3) % 12) & 3) : bid;
+#elif defined(VAURA_EXPERIMENT_ENGINES)      // measured: no effect (profiles/r06_ab_qlocal.txt) — the kernel-start acquire leaves nothing of the previous launch in L2
+      const int qid = (!ATT && e.qlocal) ? (((bid >> 3) % 12) >> 2) * 64 + 4 * ((bid & 7) + 8 * ((bid >> 3) / 12)) + (((bid >> 3) % 12) & 3) : bid;
 #else
       const int qid = bid;
 #endif
@@ -1027,6 +1033,11 @@ __global__ __launch_bounds__(MLPE_NW * 64) void mlp_engine_kernel(const void* __
         if (ks > 0) aq.out = aq.out2;
 #ifdef MLPE_ATT_LOCAL
         if constexpr (ATT) {     // plain store: the line stays in this XCD's L2, where the head's attention workgroups read it (sc1 loads)
+          reinterpret_cast<f32x4*>(aq.out)[((size_t)rq * (aq.N / 4) + (size_t)(tile0q + tq) * 4) * 16 + lane] = v;
+        } else
+#endif
+#ifdef VAURA_EXPERIMENT_ENGINES
+        if (!ATT && e.qlocal) {  // plain store (see qid above)
           reinterpret_cast<f32x4*>(aq.out)[((size_t)rq * (aq.N / 4) + (size_t)(tile0q + tq) * 4) * 16 + lane] = v;
         } else
 #endif
