@@ -132,7 +132,8 @@ typedef struct vaura_decoder {
                               VAURA_STATUS_NONFINITE_LOGITS.  0 = the layout every parity number was taken on */
   int32_t kv_dtype;        /* 0: the K / V cache is fp32 (every parity number).  1 (round 6; the low-precision serving configuration, BASELINE
                               configs[4]): fp16 — kcache / vcache then point at (n_layer, rows, n_head, max_len, head_dim) HALVES holding
-                              fp16(rotated k) / fp16(v); caches of at most 256 positions only (VAURA_ERR_SHAPE otherwise); tolerance reported */
+                              fp16(rotated k) / fp16(v); caches of at most 256 positions only (VAURA_ERR_SHAPE otherwise); tolerance reported.
+                              2: OCP e4m3 bytes of the same layout (unscaled, saturating at +-448): a quarter of the fp32 stream, ~1e-2 class */
 
   const vaura_layer_weights* layers_host; /* HOST array [n_layer] of device pointers */
   const void*  heads;        /* (n_codebooks*vocab x d_model) MFMA tiles (VAURA_W_H1 when wdtype is FP8) llama.py:356-361 */

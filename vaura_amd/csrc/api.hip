@@ -24,8 +24,8 @@ static int check_decoder(const vaura_decoder* d) {
   if (d->rows != d->batch && d->rows != 2 * d->batch) return VAURA_ERR_ARG;
   if (d->seq_len > d->max_len || d->batch <= 0) return VAURA_ERR_ARG;
   if (d->plane_shift < 0 || d->plane_shift > 24 || (d->plane_shift && !d->ws_h_split)) return VAURA_ERR_ARG;
-  if (d->kv_dtype != 0 && d->kv_dtype != 1) return VAURA_ERR_ARG;
-  if (d->kv_dtype == 1 && (d->max_len > 256 || !d->ws_h_split)) return VAURA_ERR_SHAPE;      // fp16 K / V: the pair path's single-round-trip attention only
+  if (d->kv_dtype < 0 || d->kv_dtype > 2) return VAURA_ERR_ARG;
+  if (d->kv_dtype != 0 && (d->max_len > 256 || !d->ws_h_split)) return VAURA_ERR_SHAPE;      // fp16 / fp8 K / V: the pair path's single-round-trip attention only
   return 0;
 }
 

@@ -201,6 +201,36 @@ __device__ __forceinline__ f32x4 kv_quad_to_f32(const uint2 q) {
 __device__ __forceinline__ uint2 kv_quad_to_f16(const f32x4 v) {
   return uint2{pack_h2((_Float16)v[0], (_Float16)v[1]), pack_h2((_Float16)v[2], (_Float16)v[3])};
 }
+// kv_dtype = 2: OCP e4m3, unscaled (rotated keys and values of this model are O(1..100); values beyond +-448 saturate): a quad is 4 bytes
+__device__ __forceinline__ f32x4 kv_quad8_to_f32(const uint32_t q) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)q, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)q, true);
+  const float a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+  return f32x4{a0, a1, b0, b1};
+}
+__device__ __forceinline__ uint32_t kv_quad_to_f8(const f32x4 v) {
+  auto sat = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+  int q = __builtin_amdgcn_cvt_pk_fp8_f32(sat(v[0]), sat(v[1]), 0, false);
+  q = __builtin_amdgcn_cvt_pk_fp8_f32(sat(v[2]), sat(v[3]), q, true);
+  return (uint32_t)q;
+}
+// K / V storage of a kernel instance: KVT = vaura_decoder.kv_dtype (0 fp32, 1 fp16, 2 fp8 e4m3); Q = one quad (4 channels) as stored
+template <int KVT> struct KvT;
+template <> struct KvT<0> {
+  using Q = f32x4; using E = float;
+  static __device__ __forceinline__ f32x4 widen(const Q& q) { return q; }
+  static __device__ __forceinline__ Q narrow(const f32x4& v) { return v; }
+};
+template <> struct KvT<1> {
+  using Q = uint2; using E = _Float16;
+  static __device__ __forceinline__ f32x4 widen(const Q& q) { return kv_quad_to_f32(q); }
+  static __device__ __forceinline__ Q narrow(const f32x4& v) { return kv_quad_to_f16(v); }
+};
+template <> struct KvT<2> {
+  using Q = uint32_t; using E = uint8_t;
+  static __device__ __forceinline__ f32x4 widen(const Q& q) { return kv_quad8_to_f32(q); }
+  static __device__ __forceinline__ Q narrow(const f32x4& v) { return kv_quad_to_f8(v); }
+};
 
 // NU = number of 64-position passes that hold cached rows (0..4).  One straight-line body per NU: the compiler
 // then waits with exact vmcnt values (vmcnt retires in order), and short caches issue no dead loads.
@@ -209,7 +239,7 @@ struct NoHook {
 };
 // `after_requests`: called once every request of the attention itself has been issued (the fused attention + wo launch queues
 // its wo weight requests there: behind the K/V rows, which the dependent chain needs first)
-template <int HD, int NU, typename HOOK = NoHook, bool KVH = false>
+template <int HD, int NU, typename HOOK = NoHook, int KVT = 0>
 __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv, const float* __restrict__ qkv2,
                                                   const float* __restrict__ rope,
                                                   float* __restrict__ kc, float* __restrict__ vc, float* __restrict__ out,
@@ -242,17 +272,15 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   const f32x4 gx2 = reinterpret_cast<const f32x4*>(qkv2 ? qkv2 : qkv)[packed_quad(row, (which * D + h * HD + cq * 4) >> 2, 3 * D)];
   const f32x4 gcs = *reinterpret_cast<const f32x4*>(rope + ((size_t)pos * (HD / 2) + cq * 2) * 2);  // c0 s0 c1 s1
   __builtin_amdgcn_sched_barrier(0);   // keep these first in program order (the scheduler sinks them otherwise)
-  // KVH: kc / vc point at fp16 rows (the launcher offsets them in halves); a quad is 8 bytes and is widened where it is used
-  using KVQ = std::conditional_t<KVH, uint2, f32x4>;
+  // KVT != 0: kc / vc point at fp16 / fp8 rows (the kernel offsets them in ELEMENTS of that type); a quad is 8 / 4 bytes and is widened
+  // where it is used
+  using KV = KvT<KVT>;
+  using KVQ = typename KV::Q;
   KVQ kf[NUA][QPL], vf[NUA][QPL];
   auto kvrow = [&](const float* base, int p) {
-    if constexpr (KVH) return reinterpret_cast<const KVQ*>(reinterpret_cast<const _Float16*>(base) + (size_t)p * HD);
-    else return reinterpret_cast<const KVQ*>(base + (size_t)p * HD);
+    return reinterpret_cast<const KVQ*>(reinterpret_cast<const typename KV::E*>(base) + (size_t)p * HD);
   };
-  auto widen = [&](const KVQ& x) -> f32x4 {
-    if constexpr (KVH) return kv_quad_to_f32(x);
-    else return x;
-  };
+  auto widen = [&](const KVQ& x) -> f32x4 { return KV::widen(x); };
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int p = min(u * 64 + prow, pos - 1);
@@ -283,12 +311,13 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
   y[2] = gx[2] * gcs[2] - gx[3] * gcs[3];
   y[3] = gx[3] * gcs[2] + gx[2] * gcs[3];
   if (which == 2) y = gx;   // v is not rotated
-  if constexpr (KVH) {      // the new position's k / v are what later steps will read back: fp16 values, for this step too
-    if (which >= 1) y = kv_quad_to_f32(kv_quad_to_f16(y));
+  if constexpr (KVT != 0) {      // the new position's k / v are what later steps will read back: the stored (fp16 / fp8) values, for this step too
+    if (which >= 1) y = KV::widen(KV::narrow(y));
   }
   sqkv[tid < 3 * QUADS ? tid : 3 * QUADS + (tid & 63)] = y;
   if (tid >= QUADS && tid < 3 * QUADS) {
-    if constexpr (KVH) va_st8(reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(which == 1 ? kc : vc) + (size_t)pos * HD) + cq, kv_quad_to_f16(y));
+    if constexpr (KVT == 1) va_st8(reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(which == 1 ? kc : vc) + (size_t)pos * HD) + cq, kv_quad_to_f16(y));
+    else if constexpr (KVT == 2) va_st4(reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(which == 1 ? kc : vc) + (size_t)pos * HD) + cq, __builtin_bit_cast(float, kv_quad_to_f8(y)));
     else va_st16(reinterpret_cast<f32x4*>((which == 1 ? kc : vc) + (size_t)pos * HD) + cq, y);
   }
   // Only the LDS writes have to be visible behind this barrier.  __syncthreads() would also drain the vector-memory counter, i.e. wait
@@ -392,7 +421,7 @@ __device__ __forceinline__ void attention256_body(const float* __restrict__ qkv,
 #endif
 }
 
-template <int HD, bool KVH = false>
+template <int HD, int KVT = 0>
 __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
     // argument order = what the dependent chain needs first (the leading 14 dwords are preloaded into SGPRs)
     const int32_t* __restrict__ pos_dev, float* __restrict__ kcache, float* __restrict__ vcache, const float* __restrict__ qkv,
@@ -403,16 +432,16 @@ __global__ __launch_bounds__(ATT1_THREADS) void attention_step256_kernel(
   __shared__ f32x4 wacc[ATT1_THREADS / 64][QUADS];
   __shared__ float wm[ATT1_THREADS / 64], wl[ATT1_THREADS / 64];
   const int pos = pos_dev ? pos_dev[0] : pos_host;   // cache holds [0, pos), pos <= 255
-  // KVH: the cache is fp16 — the (row, head) offset in HALVES (the pointer stays float* in the signature: same kernarg layout)
+  // KVT != 0: the cache is fp16 / fp8 — the (row, head) offset in ELEMENTS of that type (the pointer stays float* in the signature: same kernarg layout)
   const size_t off = ((size_t)blockIdx.y * n_head + blockIdx.x) * (size_t)max_len * HD;
-  float* kc = KVH ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(kcache) + off) : kcache + off;
-  float* vc = KVH ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(vcache) + off) : vcache + off;
+  float* kc = reinterpret_cast<float*>(reinterpret_cast<typename KvT<KVT>::E*>(kcache) + off);
+  float* vc = reinterpret_cast<float*>(reinterpret_cast<typename KvT<KVT>::E*>(vcache) + off);
   switch ((pos + 63) >> 6) {
-    case 0: attention256_body<HD, 0, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    case 1: attention256_body<HD, 1, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    case 2: attention256_body<HD, 2, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    case 3: attention256_body<HD, 3, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
-    default: attention256_body<HD, 4, NoHook, KVH>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 0: attention256_body<HD, 0, NoHook, KVT>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 1: attention256_body<HD, 1, NoHook, KVT>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 2: attention256_body<HD, 2, NoHook, KVT>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    case 3: attention256_body<HD, 3, NoHook, KVT>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
+    default: attention256_body<HD, 4, NoHook, KVT>(qkv, qkv2, rope, kc, vc, out, outp, n_head, pos, sqkv, wacc, wm, wl, pscale); break;
   }
 }
 
@@ -695,7 +724,7 @@ __global__ __launch_bounds__(64) void attention_combine_kernel(const float* __re
 }
 
 // rope(q, k) + K/V append for every (row, head, position) of a teacher-forced chunk; q is rotated in place
-template <int HD, bool KVH = false>
+template <int HD, int KVT = 0>
 __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qkv, const float* __restrict__ rope,
                                                           float* __restrict__ kcache, float* __restrict__ vcache, int n_head,
                                                           int max_len, int p0, int rows16) {
@@ -719,9 +748,10 @@ __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qk
   }
   const size_t cbase = (((size_t)row * n_head + h) * (size_t)max_len + pos) * HD;
   if (which == 0) *src = x;
-  if constexpr (KVH) {
-    if (which == 1) reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(kcache) + cbase)[cq] = kv_quad_to_f16(x);
-    if (which == 2) reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(vcache) + cbase)[cq] = kv_quad_to_f16(x);
+  if constexpr (KVT != 0) {
+    using KV = KvT<KVT>;
+    if (which == 1) reinterpret_cast<typename KV::Q*>(reinterpret_cast<typename KV::E*>(kcache) + cbase)[cq] = KV::narrow(x);
+    if (which == 2) reinterpret_cast<typename KV::Q*>(reinterpret_cast<typename KV::E*>(vcache) + cbase)[cq] = KV::narrow(x);
   } else {
     if (which == 1) reinterpret_cast<f32x4*>(kcache + cbase)[cq] = x;
     if (which == 2) reinterpret_cast<f32x4*>(vcache + cbase)[cq] = x;
@@ -741,7 +771,7 @@ __global__ __launch_bounds__(128) void rope_append_kernel(float* __restrict__ qk
 // accumulator register s the lane already holds.  q was rotated in place and k / v appended by rope_append_kernel.
 #define APF_Q 64
 #define APF_STRIDE 100      // floats per staged K / V row: 16 keys x 4-bank reads land on 64 distinct banks (36 k mod 64)
-template <int HD, bool KVH = false>
+template <int HD, int KVT = 0>
 __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __restrict__ qkv, const float* __restrict__ kcache,
                                                                 const float* __restrict__ vcache, float* __restrict__ out,
                                                                 uint16_t* __restrict__ outp, int n_head, int max_len, int p0, int n_pos,
@@ -759,8 +789,8 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
   const int qpos = p0 + qi;
   const float scale = 1.0f / sqrtf((float)HD);
   const size_t kvoff = ((size_t)row * n_head + h) * (size_t)max_len * HD;
-  const float* kc = KVH ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(kcache) + kvoff) : kcache + kvoff;
-  const float* vc = KVH ? reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(vcache) + kvoff) : vcache + kvoff;
+  const float* kc = reinterpret_cast<const float*>(reinterpret_cast<const typename KvT<KVT>::E*>(kcache) + kvoff);
+  const float* vc = reinterpret_cast<const float*>(reinterpret_cast<const typename KvT<KVT>::E*>(vcache) + kvoff);
   // Q^T operand: lane (q, g) holds Q[q][24 g + s], s = 0..23 (queries past the chunk read the last valid row; never stored)
   float qreg[KS];
   {
@@ -783,9 +813,10 @@ __global__ __launch_bounds__(256) void attention_prefill_kernel(const float* __r
     for (int u = tid; u < 64 * (HD / 4); u += 256) {
       const int j = u / (HD / 4), c = u % (HD / 4);
       const int kp = min(kb + j, last_q);
-      if constexpr (KVH) {      // fp16 cache: widened on the way into the fp32 staging (the products stay exact-fp32 MFMAs on fp16 values)
-        *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = kv_quad_to_f32(reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(kc) + (size_t)kp * HD)[c]);
-        *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = kv_quad_to_f32(reinterpret_cast<const uint2*>(reinterpret_cast<const _Float16*>(vc) + (size_t)kp * HD)[c]);
+      if constexpr (KVT != 0) {      // fp16 / fp8 cache: widened on the way into the fp32 staging (the products stay exact-fp32 MFMAs on the stored values)
+        using KV = KvT<KVT>;
+        *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = KV::widen(reinterpret_cast<const typename KV::Q*>(reinterpret_cast<const typename KV::E*>(kc) + (size_t)kp * HD)[c]);
+        *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = KV::widen(reinterpret_cast<const typename KV::Q*>(reinterpret_cast<const typename KV::E*>(vc) + (size_t)kp * HD)[c]);
       } else {
         *reinterpret_cast<f32x4*>(Ks + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(kc + (size_t)kp * HD)[c];
         *reinterpret_cast<f32x4*>(Vs + j * APF_STRIDE + 4 * c) = reinterpret_cast<const f32x4*>(vc + (size_t)kp * HD)[c];
@@ -893,8 +924,11 @@ int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, 
     return 0;
   }
   if (max_len <= 256) {   // static per descriptor (the step graph is captured once): single-round-trip kernel
-    if (kv_half)
-      VA_LAUNCH((attention_step256_kernel<96, true>), dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
+    if (kv_half == 1)
+      VA_LAUNCH((attention_step256_kernel<96, 1>), dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
+                n_head, max_len, pos_host, out, outp, pscale);
+    else if (kv_half == 2)
+      VA_LAUNCH((attention_step256_kernel<96, 2>), dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
                 n_head, max_len, pos_host, out, outp, pscale);
     else
       VA_LAUNCH(attention_step256_kernel<96>, dim3(n_head, rows), dim3(ATT1_THREADS), 0, s, pos_dev, kc, vc, qkv, qkv2, rope,
@@ -916,9 +950,13 @@ int va_launch_rope_append(const vaura_decoder* d, int layer, int p0, int n_pos, 
   const int H = d->dims.n_head, hd = d->dims.d_model / H;
   if (hd != 96) return VAURA_ERR_SHAPE;
   const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
-  if (d->kv_dtype == 1) {      // fp16 cache: the layer offset in halves
-    VA_LAUNCH((rope_append_kernel<96, true>), dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, va_kv_layer(d, d->kcache, layer),
-              va_kv_layer(d, d->vcache, layer), H, d->max_len, p0, (d->rows + 15) / 16 * 16);
+  if (d->kv_dtype == 1 || d->kv_dtype == 2) {      // fp16 / fp8 cache: the layer offset in elements of that type
+    if (d->kv_dtype == 1)
+      VA_LAUNCH((rope_append_kernel<96, 1>), dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, va_kv_layer(d, d->kcache, layer),
+                va_kv_layer(d, d->vcache, layer), H, d->max_len, p0, (d->rows + 15) / 16 * 16);
+    else
+      VA_LAUNCH((rope_append_kernel<96, 2>), dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, va_kv_layer(d, d->kcache, layer),
+                va_kv_layer(d, d->vcache, layer), H, d->max_len, p0, (d->rows + 15) / 16 * 16);
     return 0;
   }
   VA_LAUNCH(rope_append_kernel<96>, dim3(H, d->rows, n_pos), dim3(128), 0, s, d->ws_qkv, d->rope, d->kcache + layer * kv_layer,
@@ -931,10 +969,16 @@ int va_launch_attention_prefill(const vaura_decoder* d, int layer, int p0, int n
   const int H = d->dims.n_head, hd = d->dims.d_model / H;
   if (hd != 96) return VAURA_ERR_SHAPE;
   const size_t kv_layer = (size_t)d->rows * H * (size_t)d->max_len * hd;
-  if (d->kv_dtype == 1) {
-    VA_LAUNCH((attention_prefill_kernel<96, true>), dim3(H, d->rows, (n_pos + APF_Q - 1) / APF_Q), dim3(256), 0, s, (const float*)d->ws_qkv,
-              (const float*)va_kv_layer(d, d->kcache, layer), (const float*)va_kv_layer(d, d->vcache, layer), d->ws_attn, d->ws_attn_split, H,
-              d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16, ldexpf(1.f, -d->plane_shift));
+  if (d->kv_dtype == 1 || d->kv_dtype == 2) {
+    const dim3 grid(H, d->rows, (n_pos + APF_Q - 1) / APF_Q);
+    if (d->kv_dtype == 1)
+      VA_LAUNCH((attention_prefill_kernel<96, 1>), grid, dim3(256), 0, s, (const float*)d->ws_qkv, (const float*)va_kv_layer(d, d->kcache, layer),
+                (const float*)va_kv_layer(d, d->vcache, layer), d->ws_attn, d->ws_attn_split, H, d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16,
+                ldexpf(1.f, -d->plane_shift));
+    else
+      VA_LAUNCH((attention_prefill_kernel<96, 2>), grid, dim3(256), 0, s, (const float*)d->ws_qkv, (const float*)va_kv_layer(d, d->kcache, layer),
+                (const float*)va_kv_layer(d, d->vcache, layer), d->ws_attn, d->ws_attn_split, H, d->max_len, p0, n_pos, (d->rows + 15) / 16 * 16,
+                ldexpf(1.f, -d->plane_shift));
     return 0;
   }
   if (!(va_debug_flags & 16u)) {

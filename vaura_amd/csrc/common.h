@@ -184,10 +184,12 @@ int va_attention_splits(int rows, int n_head, int max_len);   // workgroups per 
 int va_launch_attention(const float* qkv, const float* qkv2, const float* rope, float* kc, float* vc, float* out,
                         uint16_t* outp, int rows, int n_head, int head_dim, int max_len, const int32_t* pos_dev, int pos_host,
                         float* part, int n_split, hipStream_t s, uint32_t* arrivals = nullptr, float pscale = 1.f, int kv_half = 0);
-// K / V cache of one layer: the layer stride in ELEMENTS, the elements fp32 or (vaura_decoder.kv_dtype = 1) fp16
+// K / V cache of one layer: the layer stride in ELEMENTS, the elements fp32 or (vaura_decoder.kv_dtype = 1 / 2) fp16 / fp8 e4m3
 static inline float* va_kv_layer(const vaura_decoder* d, float* base, int layer) {
   const size_t kv_layer = (size_t)d->rows * d->dims.n_head * (size_t)d->max_len * (size_t)(d->dims.d_model / d->dims.n_head);
-  return d->kv_dtype == 1 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base) + layer * kv_layer) : base + layer * kv_layer;
+  if (d->kv_dtype == 1) return reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(base) + layer * kv_layer);
+  if (d->kv_dtype == 2) return reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(base) + layer * kv_layer);
+  return base + layer * kv_layer;
 }
 struct Gemv3Args;
 static inline bool va_is_fp8(int wdtype) { return wdtype == VAURA_W_FP8 || wdtype == VAURA_W_FP8H; }   // e4m3 tile pairs (both activation arithmetics)
