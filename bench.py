@@ -147,9 +147,18 @@ def extra_configs(args, dev, cfg, ccfg, sd, eng_h2, codec_pair, stream):
     r32, _ = region(e8f, c8, f16, 220, kw6, 1, 32, cfg)
     del e8f
     torch.cuda.empty_cache()
+    e8k = DecoderEngine(cfg, sd, dev, wdtype="fp8h", kv_dtype="f8")    # ... and with e4m3 K/V (unscaled, saturating): a ~4e-2-class option
+    idx8 = torch.randint(0, 1024, (2, K_CB, 24), generator=torch.Generator().manual_seed(11)).to(dev)
+    r8k, _ = region(e8k, c8, f16, 220, kw6, 1, 32, cfg, kvbytes=1)
+    lg8k = e8k.logits_all_positions(idx8, f16[:2]).float().cpu()
+    del e8k
+    torch.cuda.empty_cache()
     e8 = DecoderEngine(cfg, sd, dev, wdtype="fp8h", kv_dtype="f16")
     r, codes8 = region(e8, c8, f16, 220, kw6, 1, 32, cfg, kvbytes=2)
+    lg8h = e8.logits_all_positions(idx8, f16[:2]).float().cpu()
     r["with_fp32_kv_cache"] = {k: r32[k] for k in ("value", "ms_per_step", "decode_loop_ms", "decode_loop_roofline")}
+    r["with_fp8_kv_cache"] = {k: r8k[k] for k in ("value", "ms_per_step", "decode_loop_ms", "decode_loop_roofline")}
+    r["with_fp8_kv_cache"]["logits_rel_rms_vs_fp16_kv"] = round(float((lg8k - lg8h).pow(2).mean().sqrt() / lg8h.pow(2).mean().sqrt()), 5)
     r["workload"] = ("configs[4] per GPU: 16 clips x 2.56 s, cfg 6 (32 rows), top-k 250; per-layer matrices fp8 e4m3 + row scales multiplied against the "
                      "hi fp16 activation plane (weight_dtype='fp8h'), one-plane heads, fp16 K/V cache (kv_dtype='f16'); codec on the block-scaled "
                      "fp8 MFMA (mx8).  The roofline bytes count the K/V stream at 2 bytes per element")
