@@ -100,7 +100,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(argv[i], "--rows")) rows = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--chains")) chains = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--stride")) stride = atoi(argv[i + 1]);              // counter passes: positions pos0, pos0 + stride, ... (the caches are pre-filled)
-    else if (!strcmp(argv[i], "--kv")) kv16 = !strcmp(argv[i + 1], "f16");          // fp16 K / V cache (vaura_decoder.kv_dtype = 1)
+    else if (!strcmp(argv[i], "--kv")) kv16 = !strcmp(argv[i + 1], "f16") ? 1 : (!strcmp(argv[i + 1], "f8") ? 2 : 0);   // fp16 / e4m3 K / V cache (vaura_decoder.kv_dtype)
     else if (!strcmp(argv[i], "--stamps")) stamps_out = argv[i + 1];
   }
   void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
