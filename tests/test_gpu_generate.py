@@ -725,8 +725,8 @@ def test_fp8h_hi_plane_activations_tolerance_against_fp8_and_bf16(full_sampler_s
     B = 16
     feats = synth.video_features(B, seed=15).to(DEV)
     out = {}
-    for wd in ("fp8h", "fp8", "h1"):
-        eng = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype=wd)
+    for wd in ("fp8h", "fp8", "h1", "fp8h+kv16", "fp8h+kv8"):
+        eng = DecoderEngine(cfg, full_sampler_sd, DEV, wdtype=wd.split("+")[0], kv_dtype={"kv16": "f16", "kv8": "f8"}.get(wd.split("+")[-1], "f32"))
         tok = eng.generate_codes(feats, 220, cfg_scale=6.0).cpu()
         eng.check_status()
         if wd == "fp8h":
@@ -751,6 +751,12 @@ def test_fp8h_hi_plane_activations_tolerance_against_fp8_and_bf16(full_sampler_s
           f"first difference at step {min(first)}; vs the bf16 model: fp8h {r_h16:.3e}, fp8 {r_816:.3e}")
     assert r_h8 < 0.02 * r_816 + 2e-3 and r_h16 < 1.05 * r_816 + 1e-3      # the lo plane is noise under the fp8 weights' own error
     assert top1 > 0.97
+    # configs[4]'s measured configuration at FULL depth: the fp16 K/V cache on top (and the e4m3 option), against fp8h with the fp32 cache
+    r_kv16, r_kv8 = rel(out["fp8h+kv16"][1], out["fp8h"][1]), rel(out["fp8h+kv8"][1], out["fp8h"][1])
+    print(f"fp8h + fp16 K/V vs fp8h (fp32 K/V), full depth: logits rel-RMS {r_kv16:.3e}; e4m3 K/V: {r_kv8:.3e} (the fp8 weights themselves: {r_816:.3e})")
+    assert r_kv16 < 5e-3 and r_kv8 < 0.8 * r_816
+    for k in ("fp8h+kv16", "fp8h+kv8"):
+        assert int(out[k][0].min()) >= 0 and int(out[k][0].max()) < 1024
 
 
 def test_configs4_full_depth_first_frames_against_the_oracle_on_the_dequantised_checkpoint(full_sampler_sd):
